@@ -1,0 +1,88 @@
+"""Config plumbing for the converter boundary.
+
+Mirrors the reference's JSON -> nested attribute-bag loader
+(reference: openvoice/utils.py:6-43 ``get_hparams_from_file`` / ``HParams``) so
+``ToneColorConverter(config_path, device)`` accepts the released ``config.json``
+files unchanged.  Only the config loader is in scope;
+the watermark bit codec and the sentence splitters are not on the converter path.
+"""
+import json
+
+
+class HParams:
+    """Nested attribute bag: ``hps.data.sampling_rate`` and ``hps['data']`` both work,
+    and ``**hps.model`` expands (needs ``keys`` + ``__getitem__``), as the reference's
+    constructor call does (reference: openvoice/api.py:23-28)."""
+
+    def __init__(self, **kwargs):
+        for key, value in kwargs.items():
+            self[key] = HParams(**value) if isinstance(value, dict) else value
+
+    def keys(self):
+        return self.__dict__.keys()
+
+    def items(self):
+        return self.__dict__.items()
+
+    def values(self):
+        return self.__dict__.values()
+
+    def __len__(self):
+        return len(self.__dict__)
+
+    def __getitem__(self, key):
+        return getattr(self, key)
+
+    def __setitem__(self, key, value):
+        setattr(self, key, value)
+
+    def __contains__(self, key):
+        return key in self.__dict__
+
+    def __repr__(self):
+        return repr(self.__dict__)
+
+
+def get_hparams_from_file(config_path):
+    with open(config_path, "r", encoding="utf-8") as handle:
+        return HParams(**json.load(handle))
+
+
+# Hyper-parameters of the released converter checkpoints (tag [K]).
+# Used by bench.py / tests when no config.json is supplied; never hard-wired in the engine.
+CONVERTER_MODEL_CONFIG = dict(
+    inter_channels=192,
+    hidden_channels=192,
+    filter_channels=768,
+    n_heads=2,
+    n_layers=6,
+    kernel_size=3,
+    p_dropout=0.1,
+    resblock="1",
+    resblock_kernel_sizes=[3, 7, 11],
+    resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+    upsample_rates=[8, 8, 2, 2],
+    upsample_initial_channel=512,
+    upsample_kernel_sizes=[16, 16, 4, 4],
+    gin_channels=256,
+)
+
+CONVERTER_DATA_CONFIG = dict(
+    sampling_rate=22050,
+    filter_length=1024,
+    hop_length=256,
+    win_length=1024,
+    n_speakers=0,
+)
+
+
+def default_converter_hparams(version="v2"):
+    """An ``HParams`` equal to what ``get_hparams_from_file`` yields for the released
+    converter ``config.json`` (V2 adds ``_version_`` and ``zero_g``; reference:
+    openvoice/api.py:110, openvoice/models.py:423,465,495,498)."""
+    model = dict(CONVERTER_MODEL_CONFIG)
+    cfg = dict(data=dict(CONVERTER_DATA_CONFIG), model=model)
+    if version == "v2":
+        cfg["_version_"] = "v2"
+        model["zero_g"] = True
+    return HParams(**cfg)

@@ -1,0 +1,77 @@
+"""Pins the oracle (oracle/vc_oracle.py) to outputs of the unmodified reference.
+
+The fixtures under tests/golden/ were produced by oracle/make_golden.py, which imports the
+reference from /root/reference.  Tolerances: the restatement folds weight-norm once instead of
+per forward and otherwise issues the same ATen ops, so agreement is at fp32 round-off level.
+"""
+import glob
+import os
+
+import pytest
+import torch
+
+from oracle import vc_oracle
+from oracle.make_golden import weight_fingerprint
+from openvoice_amd.utils import CONVERTER_MODEL_CONFIG
+
+VC_CASES = ["vc_b2_t17", "vc_b3_t65_ragged_zero_g", "vc_b1_t40_tau0"]
+
+
+def _load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name + ".pt"), weights_only=False)
+
+
+def test_fixtures_present(golden_dir):
+    assert len(glob.glob(os.path.join(golden_dir, "*.pt"))) >= 5
+
+
+@pytest.mark.parametrize("name", VC_CASES)
+def test_weight_generator_has_not_drifted(golden_dir, synth_sd, name):
+    rec = _load(golden_dir, name)
+    now = weight_fingerprint(synth_sd)
+    for key, val in rec["weight_fingerprint"].items():
+        assert abs(now[key] - val) <= 1e-9 * abs(val), key
+
+
+@pytest.mark.parametrize("name", VC_CASES)
+def test_spectrogram_matches_reference(golden_dir, name):
+    rec = _load(golden_dir, name)
+    spec = vc_oracle.spectrogram(rec["wave"])
+    assert spec.shape == rec["spec"].shape
+    assert (spec - rec["spec"]).abs().max().item() <= 1e-4 * rec["spec"].abs().max().item()
+
+
+@pytest.mark.parametrize("name", VC_CASES)
+def test_voice_conversion_matches_reference(golden_dir, synth_sd, name):
+    rec = _load(golden_dir, name)
+    case = rec["case"]
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        o_hat, mask, (z, z_p, z_hat) = vc_oracle.voice_conversion(
+            synth_sd, CONVERTER_MODEL_CONFIG, rec["spec"], rec["lengths"], rec["g_src"], rec["g_tgt"],
+            case["tau"], rec["noise"], zero_g=case["zero_g"])
+    assert torch.equal(mask, rec["y_mask"])
+    for got, key, tol in ((z, "z", 2e-5), (z_p, "z_p", 5e-5), (z_hat, "z_hat", 1e-4), (o_hat, "o_hat", 2e-5)):
+        err = (got - rec[key]).abs().max().item()
+        assert err <= tol, (key, err)
+    if case["lengths"]:
+        for b, n in enumerate(case["lengths"]):
+            assert z_hat[b, :, n:].abs().max().item() == 0.0 if n < z_hat.shape[2] else True
+
+
+@pytest.mark.parametrize("name", VC_CASES + ["ref_enc_b2_t200"])
+def test_reference_encoder_matches_reference(golden_dir, synth_sd, name):
+    rec = _load(golden_dir, name)
+    with torch.no_grad():
+        se = vc_oracle.reference_encoder(synth_sd, rec["spec"].transpose(1, 2))
+    assert se.shape == rec["ref_enc"].shape
+    assert (se - rec["ref_enc"]).abs().max().item() <= 2e-5
+
+
+def test_param_spec_matches_reference_schema(golden_dir):
+    from openvoice_amd.params import converter_param_spec
+    schema = torch.load(os.path.join(golden_dir, "converter_state_dict_schema.pt"), weights_only=False)
+    spec = converter_param_spec(513, **CONVERTER_MODEL_CONFIG)
+    assert set(spec) == set(schema)
+    for key, shape in schema.items():
+        assert tuple(spec[key]) == tuple(shape), key
