@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Throughput of the tone-colour-converter hot path on MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1] / configs[2]): per GPU a batch of 32 synthetic 10 s utterances at
+22.05 kHz (220 500 samples -> T = 861 frames), converter model of the released hyper-parameters
+with calibrated random weights, fp32.  One step = waveform already resident in HBM -> linear
+spectrogram -> posterior encoder -> flow (src forward, tgt reverse) -> HiFi-GAN generator -> waveform
+in HBM, including the per-batch RCCL broadcast of the packed src/tgt speaker embeddings when N > 1.
+Prints ONE JSON line on rank 0 (contract in the task statement): value = aggregate real-time factor
+(audio seconds produced per wall second over all GPUs).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+SAMPLE_RATE = 22050
+
+
+def synth_wave(batch, samples, seed, device):
+    """Sum of 5 random sinusoids (80-4000 Hz) + 0.01 N(0,1), peak 0.9."""
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    freqs = 80.0 + 3920.0 * torch.rand(batch, 5, 1, generator=gen)
+    phases = 2 * torch.pi * torch.rand(batch, 5, 1, generator=gen)
+    amps = 0.2 + torch.rand(batch, 5, 1, generator=gen)
+    t = torch.arange(samples, dtype=torch.float32)[None, None, :] / SAMPLE_RATE
+    wave = (amps * torch.sin(2 * torch.pi * freqs * t + phases)).sum(1)
+    wave = wave + 0.01 * torch.randn(batch, samples, generator=gen)
+    wave = 0.9 * wave / wave.abs().amax(dim=1, keepdim=True)
+    return wave.to(device)
+
+
+def cpu_baseline(sd, cfg, seconds, budget_s=20.0):
+    """The oracle (CPU restatement of the reference path, 'port') on this box's host cores:
+    B = 1 utterances of the same length, repeated until ~budget_s of CPU work."""
+    from oracle import vc_oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    samples = int(seconds * SAMPLE_RATE)
+    wave = synth_wave(1, samples, 7, "cpu")
+    gen = torch.Generator().manual_seed(8)
+    g_src, g_tgt = 0.1 * torch.randn(1, 256, 1, generator=gen), 0.1 * torch.randn(1, 256, 1, generator=gen)
+
+    def one():
+        with torch.no_grad():
+            spec = vc_oracle.spectrogram(wave)
+            noise = torch.randn(1, cfg["inter_channels"], spec.shape[2], generator=gen)
+            lengths = torch.tensor([spec.shape[2]])
+            return vc_oracle.voice_conversion(sd, cfg, spec, lengths, g_src, g_tgt, 0.3, noise, zero_g=True)[0]
+
+    one()  # warm-up (also folds nothing: the oracle re-folds weight-norm per call like the reference)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 16:
+            break
+    return dict(value=round(n * seconds / el, 3), unit="x real-time (audio s / wall s)", cores=cores, kind="port",
+                utterances_per_s=round(n / el, 4),
+                sample=f"{n} x (B=1, {seconds:g} s utterance) oracle voice_conversion incl. spectrogram, "
+                       f"torch CPU fp32, {cores} threads, {el:.1f} s wall")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--seconds", type=float, default=10.0, help="utterance length")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from openvoice_amd.mel_processing import spectrogram_torch
+    from openvoice_amd.models import SynthesizerTrn
+    from openvoice_amd.parallel import broadcast_speaker_embeddings
+    from openvoice_amd.params import synthetic_state_dict
+    from openvoice_amd.utils import default_converter_hparams
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    hps = default_converter_hparams("v2")
+    cfg = dict(hps.model.items())
+    sd = synthetic_state_dict(cfg, hps.data.filter_length // 2 + 1, seed=1234)
+    model = SynthesizerTrn(0, hps.data.filter_length // 2 + 1, n_speakers=0, **cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    engine = model.engine()
+
+    B = args.batch
+    samples = int(args.seconds * SAMPLE_RATE)
+    wave = synth_wave(B, samples, 1000 + rank, dev)           # resident in HBM before timing starts
+    gen = torch.Generator().manual_seed(1)
+    se = (0.1 * torch.randn(1, 256, 1, generator=gen), 0.1 * torch.randn(1, 256, 1, generator=gen))
+    d = hps.data
+
+    def step():
+        src_se, tgt_se = broadcast_speaker_embeddings(se[0] if rank == 0 else None, se[1] if rank == 0 else None,
+                                                      256, dev) if world > 1 else (se[0].to(dev), se[1].to(dev))
+        spec = spectrogram_torch(wave, d.filter_length, d.sampling_rate, d.hop_length, d.win_length, center=False)
+        lengths = torch.full((B,), spec.shape[2], dtype=torch.int64, device=dev)
+        o_hat, _, _ = model.voice_conversion(spec, lengths, src_se, tgt_se, tau=0.3)
+        return o_hat, spec.shape[2]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        o_hat, frames = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    assert o_hat.shape == (B, 1, frames * engine.total_upsample) and bool(torch.isfinite(o_hat).all())
+
+    # ---- roofline of the dominant kernel: the MFMA conv family on the 72 MRF (ResBlock) convs ----
+    engine.profile = []
+    step()
+    torch.cuda.synchronize()
+    prof, engine.profile = engine.profile, None
+    by_tag = {}
+    for tag, flops, e0, e1 in prof:
+        rec = by_tag.setdefault(tag, [0, 0.0, 0.0])
+        rec[0] += 1
+        rec[1] += flops
+        rec[2] += e0.elapsed_time(e1) * 1e-3
+    n_mrf, f_mrf, t_mrf = by_tag["mrf"]
+    achieved = f_mrf / t_mrf / 1e12
+    all_flops = sum(r[1] for r in by_tag.values())
+    all_conv_s = sum(r[2] for r in by_tag.values())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        utt_s = world * B * args.steps / elapsed
+        out = {
+            "metric": "real_time_factor",
+            "value": round(utt_s * args.seconds, 2),
+            "unit": "x real-time (audio s / wall s)",
+            "utterances_per_s": round(utt_s, 3),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"ToneColorConverter.convert path, {B} x {args.seconds:g} s @ 22.05 kHz per GPU "
+                                   f"(T={frames} frames), fp32, calibrated random weights",
+                       "batch_per_gpu": B, "global_batch": B * world, "utterance_s": args.seconds,
+                       "parallelism": f"dp{world} (utterance sharding, RCCL broadcast of src/tgt se)"},
+            "per_batch_latency_rtf": round(args.seconds / (ms * 1e-3), 2),
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "ovk::conv1d_mfma_kernel on the MRF ResBlock convs",
+                         "launches_per_step": n_mrf, "avg_launch_ms": round(t_mrf / n_mrf * 1e3, 4),
+                         "alg_gflop_per_launch": round(f_mrf / n_mrf / 1e9, 2),
+                         "all_conv_alg_tflop_per_step": round(all_flops / 1e12, 3),
+                         "all_conv_ms_per_step": round(all_conv_s * 1e3, 2),
+                         "whole_step_tflops": round(all_flops / (ms * 1e-3) / 1e12, 2)},
+            "by_kernel_group_ms": {k: round(v[2] * 1e3, 3) for k, v in sorted(by_tag.items())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, cfg, args.seconds, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

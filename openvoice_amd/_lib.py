@@ -1,0 +1,75 @@
+"""ctypes binding of libopenvoice_amd.so (the C ABI declared in include/openvoice_amd.h).
+
+There is no CPU fallback: if the shared library is missing or a launch fails, the caller gets
+an exception.  ``python -c "import __graft_entry__ as g; g.build()"`` (or
+``make -C openvoice_amd/csrc``) produces the library in-tree.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libopenvoice_amd.so")
+
+OV_OK = 0
+OV_ERRORS = {-1: "OV_E_BADARG", -2: "OV_E_UNSUPPORTED", -3: "OV_E_ALIGN", -4: "OV_E_LAUNCH"}
+
+EPI_LINEAR, EPI_GATE, EPI_RESSKIP, EPI_COUPLE, EPI_POSTERIOR, EPI_CONVT = range(6)
+F_MASK_V = 1
+F_OUT2_INIT = 2
+
+_fp = ctypes.c_void_p
+
+
+class ConvParams(ctypes.Structure):
+    """Mirror of ``ov_conv1d_params`` (include/openvoice_amd.h)."""
+    _fields_ = [
+        ("x", _fp), ("w", _fp), ("bias", _fp), ("bias_b", _fp), ("out", _fp), ("res", _fp),
+        ("add", _fp), ("out2", _fp), ("mask", _fp),
+        ("x_bstride", ctypes.c_int64), ("out_bstride", ctypes.c_int64), ("res_bstride", ctypes.c_int64),
+        ("add_bstride", ctypes.c_int64), ("out2_bstride", ctypes.c_int64), ("bias_b_bstride", ctypes.c_int64),
+        ("B", ctypes.c_int32), ("Cin", ctypes.c_int32), ("L", ctypes.c_int32), ("M", ctypes.c_int32),
+        ("Cout", ctypes.c_int32), ("K", ctypes.c_int32), ("dil", ctypes.c_int32), ("epi", ctypes.c_int32),
+        ("flags", ctypes.c_int32), ("split", ctypes.c_int32), ("phase_s", ctypes.c_int32),
+        ("in_slope", ctypes.c_float), ("scale", ctypes.c_float),
+    ]
+
+
+# name -> (restype, argtypes); kept in one table so tests can check every header symbol exists.
+SIGNATURES = {
+    "ov_version": (ctypes.c_int, []),
+    "ov_conv1d_pack_size": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "ov_conv1d_pack_rows": (ctypes.c_int, [ctypes.c_int]),
+    "ov_conv1d_pack_f32": (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
+    "ov_conv1d_f32": (ctypes.c_int, [ctypes.POINTER(ConvParams), _fp]),
+    "ov_conv_post_tanh_f32": (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_float, _fp]),
+    "ov_linear_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
+    "ov_sequence_mask_f32": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, _fp]),
+}
+
+_lib = None
+
+
+class OvError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the library was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OvError(f"{LIB_PATH} not found: build the HIP extension first "
+                          f"(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib
+
+
+def check(code, what):
+    if code != OV_OK:
+        raise OvError(f"{what} failed: {OV_ERRORS.get(code, code)}")

@@ -1,0 +1,206 @@
+// C ABI of libopenvoice_amd.so: dispatch of the MFMA conv family + the small non-GEMM kernels.
+// Signatures and reference citations: include/openvoice_amd.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include "conv1d_mfma.h"
+#include "openvoice_amd.h"
+
+namespace ovk {
+
+// ---------------------------------------------------------------------------------------------
+// conv_post + tanh (C_out = 1): not GEMM-shaped (M = 1), HBM-bound.  Each thread produces four
+// consecutive samples from three aligned 16-byte loads per input channel; the [C][K] weight sits
+// in LDS.  reference: openvoice/models.py:287-289.
+// ---------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void conv_post_tanh_vec_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ w,
+                                                                 float* __restrict__ out, int C, int L,
+                                                                 float slope) {
+  constexpr int PAD = (K - 1) / 2;
+  static_assert(PAD <= 4, "halo must fit one float4 on each side");
+  extern __shared__ float wsm[];
+  for (int i = threadIdx.x; i < C * K; i += 256) wsm[i] = w[i];
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int64_t t = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (t >= L) return;
+  const float* xb = x + (int64_t)b * C * L;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < C; ++c) {
+    const float* xr = xb + (int64_t)c * L + t;
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+    if (t >= 4) lo = *reinterpret_cast<const f32x4*>(xr - 4);
+    const f32x4 mid = *reinterpret_cast<const f32x4*>(xr);
+    if (t + 4 < L) hi = *reinterpret_cast<const f32x4*>(xr + 4);
+    float v[12] = {lo[0], lo[1], lo[2], lo[3], mid[0], mid[1], mid[2], mid[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v[i] = lrelu(v[i], slope);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const float wj = wsm[c * K + j];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) acc[o] = fmaf(wj, v[4 + o + j - PAD], acc[o]);
+    }
+  }
+  f32x4 r = {tanhf(acc[0]), tanhf(acc[1]), tanhf(acc[2]), tanhf(acc[3])};
+  *reinterpret_cast<f32x4*>(out + (int64_t)b * L + t) = r;
+}
+
+__global__ __launch_bounds__(256) void conv_post_tanh_scalar_kernel(const float* __restrict__ x,
+                                                                    const float* __restrict__ w,
+                                                                    float* __restrict__ out, int C, int L,
+                                                                    int K, float slope) {
+  extern __shared__ float wsm[];
+  for (int i = threadIdx.x; i < C * K; i += 256) wsm[i] = w[i];
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= L) return;
+  const int pad = (K - 1) / 2;
+  const float* xb = x + (int64_t)b * C * L;
+  float acc = 0.f;
+  for (int c = 0; c < C; ++c)
+    for (int j = 0; j < K; ++j) {
+      const int64_t tt = t + j - pad;
+      if (tt >= 0 && tt < L) acc = fmaf(wsm[c * K + j], lrelu(xb[(int64_t)c * L + tt], slope), acc);
+    }
+  out[(int64_t)b * L + t] = tanhf(acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// y[b][m] = bias[m] + w[m][:] . x[b][:]   -- one wave64 per output, butterfly reduction.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ y,
+                                                     int M, int Kdim) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  if (m >= M) return;
+  const float* wr = w + (int64_t)m * Kdim;
+  const float* xr = x + (int64_t)b * Kdim;
+  float acc = 0.f;
+  for (int k = lane; k < Kdim; k += 64) acc = fmaf(wr[k], xr[k], acc);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) y[(int64_t)b * M + m] = acc + (bias ? bias[m] : 0.f);
+}
+
+__global__ void sequence_mask_kernel(const int64_t* __restrict__ lengths, float* __restrict__ mask, int T) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < T) mask[(int64_t)b * T + t] = t < lengths[b] ? 1.f : 0.f;
+}
+
+static const ConvVariant* find_variant(int K, int dil, int tile, int vec) {
+  const ConvVariant* tabs[4] = {kVariantsA, kVariantsB, kVariantsC, kVariantsS};
+  const int ns[4] = {kNumVariantsA, kNumVariantsB, kNumVariantsC, kNumVariantsS};
+  for (int t = 0; t < 4; ++t)
+    for (int i = 0; i < ns[t]; ++i) {
+      const ConvVariant& v = tabs[t][i];
+      if (v.K == K && v.dil == dil && v.tile == tile && v.vec == vec) return &v;
+    }
+  return nullptr;
+}
+
+}  // namespace ovk
+
+using namespace ovk;
+
+extern "C" {
+
+int ov_version(void) { return 100; }
+
+int ov_conv1d_pack_rows(int Cout) { return (Cout + 127) / 128 * 128; }
+
+size_t ov_conv1d_pack_size(int Cout, int Cin, int K) {
+  if (Cout <= 0 || Cin <= 0 || K <= 0) return 0;
+  const size_t mtiles = ov_conv1d_pack_rows(Cout) / 32;
+  return mtiles * ((size_t)packed_units(Cin) * K + 1) * REC;
+}
+
+int ov_conv1d_pack_f32(const float* w, int Cout, int Cin, int K, float* dst) {
+  if (!w || !dst || Cout <= 0 || Cin <= 0 || K <= 0) return OV_E_BADARG;
+  const int mtiles = ov_conv1d_pack_rows(Cout) / 32;
+  const int nu = packed_units(Cin);
+  const size_t recs = (size_t)nu * K + 1;
+  std::memset(dst, 0, ov_conv1d_pack_size(Cout, Cin, K) * sizeof(float));
+  for (int mt = 0; mt < mtiles; ++mt)
+    for (int U = 0; U < nu; ++U)
+      for (int g = 0; g < K; ++g) {
+        float* rec = dst + ((size_t)mt * recs + (size_t)U * K + g) * REC;
+        for (int lane = 0; lane < 64; ++lane)
+          for (int u = 0; u < 4; ++u) {
+            const int s = 4 * g + u, pp = s / K, tap = s - pp * K;
+            const int ci = UNIT * U + 2 * pp + (lane >> 5);
+            const int co = 32 * mt + (lane & 31);
+            if (co < Cout && ci < Cin) rec[lane * 4 + u] = w[((size_t)co * Cin + ci) * K + tap];
+          }
+      }
+  return OV_OK;
+}
+
+int ov_conv1d_f32(const ov_conv1d_params* p, ov_stream_t stream) {
+  if (!p || !p->x || !p->w || !p->out) return OV_E_BADARG;
+  if (p->B <= 0 || p->Cin <= 0 || p->L <= 0 || p->M <= 0 || p->Cout <= 0 || p->K <= 0 || p->dil <= 0)
+    return OV_E_BADARG;
+  if (p->B > 65535) return OV_E_BADARG;
+  const int epi = p->epi;
+  if (epi < OV_EPI_LINEAR || epi > OV_EPI_CONVT) return OV_E_BADARG;
+  if ((epi == OV_EPI_GATE || epi == OV_EPI_POSTERIOR) && (p->M % 64 != 0)) return OV_E_BADARG;
+  if (epi == OV_EPI_POSTERIOR && !p->res) return OV_E_BADARG;
+  if (epi == OV_EPI_RESSKIP && (!p->out2 || p->split % 32 != 0)) return OV_E_BADARG;
+  if (epi == OV_EPI_CONVT) {
+    if (p->phase_s <= 0 || 32 % p->phase_s != 0) return OV_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(p->out) & 15) || (p->out_bstride & 3)) return OV_E_ALIGN;
+  }
+  if ((reinterpret_cast<uintptr_t>(p->w) & 15)) return OV_E_ALIGN;
+  int tile = TILE_128x128;
+  if (p->M <= 32 && epi != OV_EPI_GATE && epi != OV_EPI_POSTERIOR) tile = TILE_32x512;
+  else if (p->M <= 64) tile = TILE_64x256;
+  const bool can_vec = (p->L % 4 == 0) && !(reinterpret_cast<uintptr_t>(p->x) & 15) && (p->x_bstride % 4 == 0);
+  const ConvVariant* v = nullptr;
+  if (can_vec) v = find_variant(p->K, p->dil, tile, 1);
+  if (!v && can_vec && tile != TILE_128x128) v = find_variant(p->K, p->dil, TILE_128x128, 1);
+  if (!v) v = find_variant(p->K, p->dil, TILE_128x128, 0);
+  if (!v) return OV_E_UNSUPPORTED;
+  return v->fn(p, static_cast<hipStream_t>(stream));
+}
+
+int ov_conv_post_tanh_f32(const float* x, const float* w, float* out, int B, int C, int L, int K,
+                          float in_slope, ov_stream_t stream) {
+  if (!x || !w || !out || B <= 0 || C <= 0 || L <= 0 || K <= 0 || (K & 1) == 0 || B > 65535) return OV_E_BADARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t smem = (size_t)C * K * sizeof(float);
+  const bool vec = (K == 7) && (L % 4 == 0) && !(reinterpret_cast<uintptr_t>(x) & 15) &&
+                   !(reinterpret_cast<uintptr_t>(out) & 15);
+  if (vec) {
+    dim3 grid((L / 4 + 255) / 256, B);
+    hipLaunchKernelGGL(conv_post_tanh_vec_kernel<7>, grid, dim3(256), smem, st, x, w, out, C, L, in_slope);
+  } else {
+    dim3 grid((L + 255) / 256, B);
+    hipLaunchKernelGGL(conv_post_tanh_scalar_kernel, grid, dim3(256), smem, st, x, w, out, C, L, K, in_slope);
+  }
+  return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
+}
+
+int ov_linear_f32(const float* x, const float* w, const float* bias, float* y, int B, int M, int Kdim,
+                  ov_stream_t stream) {
+  if (!x || !w || !y || B <= 0 || M <= 0 || Kdim <= 0 || B > 65535) return OV_E_BADARG;
+  dim3 grid((M + 3) / 4, B);
+  hipLaunchKernelGGL(linear_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, w, bias, y, M, Kdim);
+  return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
+}
+
+int ov_sequence_mask_f32(const int64_t* lengths, float* mask, int B, int T, ov_stream_t stream) {
+  if (!lengths || !mask || B <= 0 || T <= 0 || B > 65535) return OV_E_BADARG;
+  dim3 grid((T + 255) / 256, B);
+  hipLaunchKernelGGL(sequence_mask_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), lengths, mask, T);
+  return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
+}
+
+}  // extern "C"

@@ -1,0 +1,355 @@
+"""Host-side driver of the MI355X tone-colour-converter kernels.
+
+``ConverterEngine`` owns the load-time weight transforms (weight-norm folding, Flip folding,
+gate/posterior row pairing, transposed-conv phase split, MFMA fragment packing) and issues the
+kernel launches of one ``voice_conversion`` call through the C ABI (include/openvoice_amd.h) on
+torch's current HIP stream.  PyTorch is used for device memory and streams only: every op between
+``spec [B,513,T]`` and ``o_hat [B,1,256T]`` is a kernel from libopenvoice_amd.so.
+
+Reference path being replaced: SynthesizerTrn.voice_conversion (openvoice/models.py:492-499) =
+PosteriorEncoder (models.py:212-221) -> ResidualCouplingBlock forward with g_src and reverse with
+g_tgt (models.py:390-397) -> Generator (models.py:272-291).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ConvParams, EPI_CONVT, EPI_COUPLE, EPI_GATE, EPI_LINEAR, EPI_POSTERIOR, EPI_RESSKIP,
+                   F_MASK_V, F_OUT2_INIT)
+from .params import ENC_Q_LAYERS, FLOW_LAYERS, N_FLOWS, effective_weight
+
+LRELU_SLOPE = 0.1       # reference: openvoice/modules.py:14
+FINAL_LRELU_SLOPE = 0.01  # F.leaky_relu default at openvoice/models.py:287
+
+
+def _ptr(t, offset_elems=0):
+    return ctypes.c_void_p(t.data_ptr() + 4 * offset_elems)
+
+
+class PackedConv:
+    """One conv layer in kernel-ready form: fragment-packed weights + bias in packed row order."""
+
+    def __init__(self, w_dense, bias, device, K, dil=1, cout=None):
+        lib = _lib.load()
+        w_dense = w_dense.detach().to(torch.float32).cpu().contiguous()
+        rows, cin, k = w_dense.shape
+        assert k == K
+        self.rows = rows                        # meaningful packed rows (M of the launch)
+        self.cout = rows if cout is None else cout
+        self.cin, self.K, self.dil = cin, K, dil
+        n = lib.ov_conv1d_pack_size(rows, cin, K)
+        packed = torch.empty(n, dtype=torch.float32)
+        _lib.check(lib.ov_conv1d_pack_f32(_ptr(w_dense), rows, cin, K, _ptr(packed)), "ov_conv1d_pack_f32")
+        self.w = packed.to(device)
+        pack_rows = lib.ov_conv1d_pack_rows(rows)
+        b = torch.zeros(pack_rows, dtype=torch.float32)
+        if bias is not None:
+            b[:rows] = bias.detach().float().cpu()
+        self.has_bias = bias is not None
+        self.bias = b.to(device)
+
+
+def gate_row_order(hidden):
+    """Packed row order pairing row c (tanh | m) with row c+hidden (sigmoid | logs) in adjacent
+    32-row MFMA tiles, so both halves of a gate land in the same lane of one wave."""
+    assert hidden % 32 == 0
+    idx = []
+    for q in range(hidden // 32):
+        idx += list(range(32 * q, 32 * q + 32)) + list(range(hidden + 32 * q, hidden + 32 * q + 32))
+    return torch.tensor(idx, dtype=torch.long)
+
+
+def conv_transpose_as_conv(w, stride):
+    """ConvTranspose1d(k = 2*stride, padding = stride/2) as a 3-tap stride-1 conv producing
+    ``stride`` output phases per input frame.  y[s*q + p] = sum_i x[i] * w[:, :, s*q + p + pad - s*i]
+    has exactly two non-zero taps per phase (i = q and i = q-1 or q+1); row = cout*stride + phase.
+    ``w`` is [Cin, Cout, k] (torch ConvTranspose1d layout, reference: openvoice/models.py:244-256)."""
+    cin, cout, k = w.shape
+    s = stride
+    pad = (k - s) // 2
+    assert k == 2 * s and (k - s) % 2 == 0
+    wc = torch.zeros(cout * s, cin, 3, dtype=w.dtype)
+    for p in range(s):
+        rows = torch.arange(cout) * s + p
+        wc[rows, :, 1] = w[:, :, p + pad].t()                 # x[q]
+        if p + pad < s:
+            wc[rows, :, 0] = w[:, :, p + pad + s].t()         # x[q-1]
+        else:
+            wc[rows, :, 2] = w[:, :, p + pad - s].t()         # x[q+1]
+    return wc
+
+
+def launch_conv(layer, x, x_off, x_bs, out, out_off, out_bs, B, L, epi=EPI_LINEAR, flags=0, in_slope=1.0,
+                scale=1.0, res=None, res_off=0, res_bs=0, add=None, add_bs=0, out2=None, out2_bs=0, mask=None,
+                bias_b=None, bias_b_off=0, bias_b_bs=0, split=0, phase_s=1, cin=None, rows=None):
+    """Fill ``ov_conv1d_params`` and launch on torch's current stream of ``x``'s device.
+    Offsets and batch strides are in elements."""
+    p = ConvParams()
+    p.x, p.w = _ptr(x, x_off), _ptr(layer.w)
+    p.bias = _ptr(layer.bias) if layer.has_bias else None
+    p.bias_b = _ptr(bias_b, bias_b_off) if bias_b is not None else None
+    p.out = _ptr(out, out_off)
+    p.res = _ptr(res, res_off) if res is not None else None
+    p.add = _ptr(add) if add is not None else None
+    p.out2 = _ptr(out2) if out2 is not None else None
+    p.mask = _ptr(mask) if mask is not None else None
+    p.x_bstride, p.out_bstride, p.res_bstride = x_bs, out_bs, res_bs
+    p.add_bstride, p.out2_bstride, p.bias_b_bstride = add_bs, out2_bs, bias_b_bs
+    p.B, p.Cin, p.L = B, layer.cin if cin is None else cin, L
+    p.M = layer.rows if rows is None else rows
+    p.Cout = layer.cout
+    p.K, p.dil, p.epi, p.flags, p.split, p.phase_s = layer.K, layer.dil, epi, flags, split, phase_s
+    p.in_slope, p.scale = in_slope, scale
+    stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(_lib.load().ov_conv1d_f32(ctypes.byref(p), stream), "ov_conv1d_f32")
+
+
+class _WaveNet:
+    """Packed WN stack (reference: openvoice/modules.py:133-210)."""
+
+    def __init__(self, sd, prefix, n_layers, hidden, device):
+        order = gate_row_order(hidden)
+        self.hidden, self.n_layers = hidden, n_layers
+        self.in_layers, self.rs_layers = [], []
+        for i in range(n_layers):
+            w = effective_weight(sd, f"{prefix}.in_layers.{i}")
+            self.in_layers.append(PackedConv(w[order], sd[f"{prefix}.in_layers.{i}.bias"][order], device,
+                                             K=w.shape[2], cout=hidden))
+            w = effective_weight(sd, f"{prefix}.res_skip_layers.{i}")
+            self.rs_layers.append(PackedConv(w, sd[f"{prefix}.res_skip_layers.{i}.bias"], device, K=1))
+        # cond_layer rows re-ordered per layer so its output is directly the gate's per-batch bias
+        wc = effective_weight(sd, prefix + ".cond_layer")[:, :, 0]
+        bc = sd[prefix + ".cond_layer.bias"].float()
+        full = torch.cat([order + 2 * hidden * i for i in range(n_layers)])
+        self.cond_w = wc[full].contiguous().to(device)
+        self.cond_b = bc[full].contiguous().to(device)
+
+
+class ConverterEngine:
+    """Kernel-level implementation of the converter model for one device."""
+
+    def __init__(self, state_dict, model_cfg, spec_channels, device, zero_g=False):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.OvError("ConverterEngine needs a ROCm device ('cuda:N'); there is no CPU path")
+        sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
+        cfg = dict(model_cfg.items()) if hasattr(model_cfg, "items") else dict(model_cfg)
+        self.cfg = cfg
+        self.zero_g = bool(zero_g)
+        self.inter = cfg["inter_channels"]
+        self.hidden = cfg["hidden_channels"]
+        self.gin = cfg.get("gin_channels", 256)
+        self.spec_channels = spec_channels
+        dev = self.device
+        H, C = self.hidden, self.inter
+        half = C // 2
+        # ---- posterior encoder -----------------------------------------------------------------
+        self.q_pre = PackedConv(sd["enc_q.pre.weight"], sd["enc_q.pre.bias"], dev, K=1)
+        self.q_wn = _WaveNet(sd, "enc_q.enc", ENC_Q_LAYERS, H, dev)
+        order = gate_row_order(C)
+        self.q_proj = PackedConv(sd["enc_q.proj.weight"][order], sd["enc_q.proj.bias"][order], dev, K=1, cout=C)
+        # ---- flow: Flip folded into channel order of pre (inputs) / post (outputs) ---------------
+        self.couplings = []
+        for f in range(N_FLOWS):
+            p = f"flow.flows.{2 * f}"
+            flipped = f % 2 == 1   # an odd number of Flips precedes this coupling in both directions
+            w_pre, w_post, b_post = sd[p + ".pre.weight"], sd[p + ".post.weight"], sd[p + ".post.bias"]
+            if flipped:
+                w_pre = torch.flip(w_pre, [1])
+                w_post, b_post = torch.flip(w_post, [0]), torch.flip(b_post, [0])
+            self.couplings.append(dict(
+                flipped=flipped,
+                pre=PackedConv(w_pre, sd[p + ".pre.bias"], dev, K=1),
+                wn=_WaveNet(sd, p + ".enc", FLOW_LAYERS, H, dev),
+                post=PackedConv(w_post, b_post, dev, K=1)))
+        self.half = half
+        # ---- generator -------------------------------------------------------------------------
+        self.conv_pre = PackedConv(sd["dec.conv_pre.weight"], sd["dec.conv_pre.bias"], dev, K=7)
+        self.dec_cond_w = sd["dec.cond.weight"][:, :, 0].contiguous().to(dev)
+        self.dec_cond_b = sd["dec.cond.bias"].contiguous().to(dev)
+        self.ups, self.resblocks = [], []
+        ch = cfg["upsample_initial_channel"]
+        kernels, dils = cfg["resblock_kernel_sizes"], cfg["resblock_dilation_sizes"]
+        for i, (u, k) in enumerate(zip(cfg["upsample_rates"], cfg["upsample_kernel_sizes"])):
+            w = effective_weight(sd, f"dec.ups.{i}")
+            wc = conv_transpose_as_conv(w, u)
+            bias = sd[f"dec.ups.{i}.bias"].repeat_interleave(u)
+            self.ups.append(dict(conv=PackedConv(wc, bias, dev, K=3, cout=ch // 2), stride=u))
+            ch //= 2
+            stage = []
+            for j, (rk, rd) in enumerate(zip(kernels, dils)):
+                rb = f"dec.resblocks.{i * len(kernels) + j}"
+                pairs = []
+                for n, d in enumerate(rd):
+                    c1 = PackedConv(effective_weight(sd, f"{rb}.convs1.{n}"), sd[f"{rb}.convs1.{n}.bias"], dev, K=rk, dil=d)
+                    c2 = PackedConv(effective_weight(sd, f"{rb}.convs2.{n}"), sd[f"{rb}.convs2.{n}.bias"], dev, K=rk, dil=1)
+                    pairs.append((c1, c2))
+                stage.append(pairs)
+            self.resblocks.append(stage)
+        self.final_channels = ch
+        self.post_w = sd["dec.conv_post.weight"][0].contiguous().to(dev)   # [C, 7]
+        self.total_upsample = 1
+        for u in cfg["upsample_rates"]:
+            self.total_upsample *= u
+        self._ws = {}
+        self.profile = None   # set to [] to collect per-launch HIP-event timings
+
+    # ---- launch helpers --------------------------------------------------------------------------
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _conv(self, layer, x, x_off, x_bs, out, out_off, out_bs, B, L, tag="conv", alg_flops=None, **kwargs):
+        """Launch one conv; when ``self.profile`` is a list, bracket the launch with HIP events on
+        the launch stream and record (tag, algorithmic FLOPs, start, end) for bench.py's roofline."""
+        if self.profile is None:
+            launch_conv(layer, x, x_off, x_bs, out, out_off, out_bs, B, L, **kwargs)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch_conv(layer, x, x_off, x_bs, out, out_off, out_bs, B, L, **kwargs)
+        e1.record()
+        if alg_flops is None:
+            alg_flops = 2.0 * layer.rows * (kwargs.get("cin") or layer.cin) * layer.K * L * B
+        self.profile.append((tag, alg_flops, e0, e1))
+
+    def _linear(self, x2d, w, b):
+        Bg, Kd = x2d.shape
+        M = w.shape[0]
+        y = torch.empty(Bg, M, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.ov_linear_f32(_ptr(x2d), _ptr(w), _ptr(b), _ptr(y), Bg, M, Kd, self._stream()),
+                   "ov_linear_f32")
+        return y
+
+    def _workspace(self, B, T):
+        key = (B, T)
+        ws = self._ws.get(key)
+        if ws is None:
+            self._ws.clear()   # one resident shape at a time; the decoder scratch is GBs at B=32
+            dev, H = self.device, self.hidden
+            f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+            ws = dict(mask=f(B, T), h=f(B, H, T), acts=f(B, H, T), skip=f(B, H, T))
+            ch = self.cfg["upsample_initial_channel"]
+            ws["pre"] = f(B, ch, T)
+            L, biggest = T, 0
+            for u in self.cfg["upsample_rates"]:
+                ch //= 2
+                L *= u
+                biggest = max(biggest, ch * L)
+            ws["dec"] = [f(B * biggest) for _ in range(5)]
+            self._ws[key] = ws
+        return ws
+
+    def _wavenet(self, wn, ws, B, T, cond, mask):
+        """h (in place) -> skip accumulator; reference: openvoice/modules.py:192-210.  The final
+        ``output * x_mask`` (modules.py:210) is dropped: every consumer (proj / post) is a 1x1 conv
+        whose own epilogue multiplies by the same 0/1 mask, which makes it a no-op."""
+        H = wn.hidden
+        cbs = 0 if cond.shape[0] == 1 else cond.shape[1]
+        for i in range(wn.n_layers):
+            self._conv(wn.in_layers[i], ws["h"], 0, H * T, ws["acts"], 0, H * T, B, T, epi=EPI_GATE,
+                       bias_b=cond, bias_b_off=2 * H * i, bias_b_bs=cbs, rows=2 * H, tag="wn_in")
+            last = i == wn.n_layers - 1
+            self._conv(wn.rs_layers[i], ws["acts"], 0, H * T, ws["h"], 0, H * T, B, T, epi=EPI_RESSKIP,
+                       flags=F_OUT2_INIT if i == 0 else 0, out2=ws["skip"], out2_bs=H * T, mask=mask,
+                       split=0 if last else H, tag="wn_rs")
+
+    def _flow(self, buf, ws, B, T, conds, mask, reverse):
+        C, half, H = self.inter, self.half, self.hidden
+        order = range(N_FLOWS - 1, -1, -1) if reverse else range(N_FLOWS)
+        for f in order:
+            cp = self.couplings[f]
+            x0_off = half * T if cp["flipped"] else 0
+            x1_off = 0 if cp["flipped"] else half * T
+            self._conv(cp["pre"], buf, x0_off, C * T, ws["h"], 0, H * T, B, T, flags=F_MASK_V, mask=mask, tag="cpl_pre")
+            self._wavenet(cp["wn"], ws, B, T, conds[f], mask)
+            self._conv(cp["post"], ws["skip"], 0, H * T, buf, x1_off, C * T, B, T, epi=EPI_COUPLE, mask=mask,
+                       scale=-1.0 if reverse else 1.0, tag="cpl_post")
+
+    # ---- the path ----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def voice_conversion(self, spec, spec_lengths, sid_src, sid_tgt, tau=1.0, noise=None):
+        """Same contract as the reference seam (openvoice/models.py:492-499):
+        ``(o_hat [B,1,256T], y_mask [B,1,T], (z, z_p, z_hat) [B,192,T])``.  ``noise`` [B,192,T]
+        replaces the reference's ``torch.randn_like`` draw (models.py:220); when omitted it is drawn
+        from torch's generator on the device."""
+        dev = self.device
+        spec = spec.to(dev, torch.float32).contiguous()
+        B, F, T = spec.shape
+        assert F == self.spec_channels
+        C, H = self.inter, self.hidden
+        lengths = spec_lengths.to(dev, torch.int64).contiguous()
+        g_src = sid_src.to(dev, torch.float32).reshape(sid_src.shape[0], -1).contiguous()
+        g_tgt = sid_tgt.to(dev, torch.float32).reshape(sid_tgt.shape[0], -1).contiguous()
+        if noise is None:
+            noise = torch.randn(B, C, T, dtype=torch.float32, device=dev)
+        noise = noise.to(dev, torch.float32).contiguous()
+        ws = self._workspace(B, T)
+        mask = ws["mask"]
+        st = self._stream()
+        _lib.check(self.lib.ov_sequence_mask_f32(ctypes.c_void_p(lengths.data_ptr()), _ptr(mask), B, T, st),
+                   "ov_sequence_mask_f32")
+        # conditioning GEMVs (T = 1): modules.py:189-190 for every WN, models.py:275 for the decoder
+        g_q = torch.zeros_like(g_src) if self.zero_g else g_src
+        g_d = torch.zeros_like(g_tgt) if self.zero_g else g_tgt
+        cond_q = self._linear(g_q, self.q_wn.cond_w, self.q_wn.cond_b)
+        cond_src = [self._linear(g_src, cp["wn"].cond_w, cp["wn"].cond_b) for cp in self.couplings]
+        cond_tgt = [self._linear(g_tgt, cp["wn"].cond_w, cp["wn"].cond_b) for cp in self.couplings]
+        cond_d = self._linear(g_d, self.dec_cond_w, self.dec_cond_b)
+        # ---- posterior encoder (models.py:212-221) -------------------------------------------------
+        self._conv(self.q_pre, spec, 0, F * T, ws["h"], 0, H * T, B, T, flags=F_MASK_V, mask=mask, tag="q_pre")
+        self._wavenet(self.q_wn, ws, B, T, cond_q, mask)
+        z = torch.empty(B, C, T, dtype=torch.float32, device=dev)
+        self._conv(self.q_proj, ws["skip"], 0, H * T, z, 0, C * T, B, T, epi=EPI_POSTERIOR, res=noise,
+                   res_bs=C * T, scale=float(tau), mask=mask, rows=2 * C, tag="q_proj")
+        # ---- flow forward with g_src, reverse with g_tgt (models.py:496-497) -----------------------
+        z_p = z.clone()
+        self._flow(z_p, ws, B, T, cond_src, mask, reverse=False)
+        z_hat = z_p.clone()
+        self._flow(z_hat, ws, B, T, cond_tgt, mask, reverse=True)
+        # ---- generator (models.py:272-291); z_hat * y_mask is the identity (z_hat already masked) --
+        o_hat = self.decode(z_hat, cond_d, ws)
+        return o_hat, mask.unsqueeze(1), (z, z_p, z_hat)
+
+    def decode(self, z_hat, cond_d, ws=None):
+        B, C, T = z_hat.shape
+        if ws is None:
+            ws = self._workspace(B, T)
+        cfg = self.cfg
+        ch = cfg["upsample_initial_channel"]
+        self._conv(self.conv_pre, z_hat, 0, C * T, ws["pre"], 0, ch * T, B, T, bias_b=cond_d,
+                   bias_b_bs=0 if cond_d.shape[0] == 1 else cond_d.shape[1], tag="conv_pre")
+        x, L = ws["pre"], T
+        free = list(ws["dec"])
+        nk = len(cfg["resblock_kernel_sizes"])
+        for i, up in enumerate(self.ups):
+            s = up["stride"]
+            cin, ch = ch, ch // 2
+            u = free.pop()
+            # leaky_relu(0.1) + ConvTranspose1d (models.py:278-279)
+            self._conv(up["conv"], x, 0, cin * L, u, 0, ch * L * s, B, L, epi=EPI_CONVT, in_slope=LRELU_SLOPE,
+                       phase_s=s, tag="ups", alg_flops=2.0 * cin * ch * 2 * s * L * B)
+            if i > 0:
+                free.append(x)
+            L *= s
+            t1, ra, acc = free.pop(), free.pop(), free.pop()
+            bs = ch * L
+            # MRF: mean of the 3 ResBlock1 outputs (models.py:280-286, modules.py:296-306)
+            for j, pairs in enumerate(self.resblocks[i]):
+                cur = u
+                for n, (c1, c2) in enumerate(pairs):
+                    self._conv(c1, cur, 0, bs, t1, 0, bs, B, L, in_slope=LRELU_SLOPE, tag="mrf")
+                    last = n == len(pairs) - 1
+                    dst = acc if last else ra
+                    self._conv(c2, t1, 0, bs, dst, 0, bs, B, L, in_slope=LRELU_SLOPE, res=cur, res_bs=bs,
+                               add=acc if (last and j > 0) else None, add_bs=bs,
+                               scale=1.0 / nk if (last and j == nk - 1) else 1.0, tag="mrf")
+                    cur = dst
+            free += [u, t1, ra]
+            x = acc
+        o_hat = torch.empty(B, 1, L, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.ov_conv_post_tanh_f32(_ptr(x), _ptr(self.post_w), _ptr(o_hat), B, ch, L,
+                                                  self.post_w.shape[1], FINAL_LRELU_SLOPE, self._stream()),
+                   "ov_conv_post_tanh_f32")
+        return o_hat

@@ -1,0 +1,97 @@
+"""``SynthesizerTrn`` -- the model seam of the reference API, re-hosted on the HIP engine.
+
+Keeps the constructor signature, parameter names (so released ``checkpoint.pth`` files load with
+``load_state_dict``) and the inference entry points of the reference class
+(reference: openvoice/models.py:399-499) but contains no eager PyTorch compute: ``voice_conversion``
+and ``ref_enc`` run on ``ConverterEngine`` (hand-written gfx950 kernels).  Only the converter
+variant (``n_speakers == 0``: ``enc_q``, ``flow``, ``dec``, ``ref_enc``) is in scope for this
+round; the V1 TTS variant (``enc_p``/``sdp``/``dp``) is SURVEY.md section 8(f) item 1.
+"""
+import weakref
+
+import torch
+from torch import nn
+
+from .engine import ConverterEngine
+from .params import converter_param_spec
+
+
+def _attach(root, dotted, tensor):
+    parts = dotted.split(".")
+    mod = root
+    for part in parts[:-1]:
+        if part not in mod._modules:
+            mod.add_module(part, nn.Module())
+        mod = mod._modules[part]
+    mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+class _ReferenceEncoderHandle(nn.Module):
+    """``model.ref_enc`` stays a parameter-owning, callable submodule as in the reference
+    (openvoice/models.py:301-364, called at openvoice/api.py:131); its forward runs on the engine."""
+
+    def __init__(self, root):
+        super().__init__()
+        object.__setattr__(self, "_root", weakref.ref(root))
+
+    def forward(self, inputs, mask=None):
+        return self._root().engine().reference_encoder(inputs)
+
+
+class SynthesizerTrn(nn.Module):
+    def __init__(self, n_vocab, spec_channels, inter_channels, hidden_channels, filter_channels, n_heads,
+                 n_layers, kernel_size, p_dropout, resblock, resblock_kernel_sizes, resblock_dilation_sizes,
+                 upsample_rates, upsample_initial_channel, upsample_kernel_sizes, n_speakers=256,
+                 gin_channels=256, zero_g=False, **kwargs):
+        super().__init__()
+        if n_speakers != 0:
+            raise NotImplementedError(
+                "only the tone-colour converter (n_speakers == 0) runs on the MI355X engine so far; "
+                "the V1 BaseSpeakerTTS model (enc_p/sdp/dp) is not built yet")
+        self.n_speakers = n_speakers
+        self.zero_g = zero_g
+        self.spec_channels = spec_channels
+        self.model_cfg = dict(
+            inter_channels=inter_channels, hidden_channels=hidden_channels, resblock=resblock,
+            resblock_kernel_sizes=list(resblock_kernel_sizes),
+            resblock_dilation_sizes=[list(d) for d in resblock_dilation_sizes],
+            upsample_rates=list(upsample_rates), upsample_initial_channel=upsample_initial_channel,
+            upsample_kernel_sizes=list(upsample_kernel_sizes), gin_channels=gin_channels)
+        self.ref_enc = _ReferenceEncoderHandle(self)
+        gen = torch.Generator().manual_seed(0)
+        for name, shape in converter_param_spec(spec_channels, **self.model_cfg).items():
+            if name.endswith("weight_g") or name == "ref_enc.layernorm.weight":
+                init = torch.ones(shape)
+            elif len(shape) == 1:
+                init = torch.zeros(shape)
+            else:
+                init = 0.01 * torch.randn(shape, generator=gen)   # reference: openvoice/commons.py:6-9
+            _attach(self, name, init)
+        self._engine = None
+        self._engine_key = None
+
+    # The engine snapshots (folds + packs) the parameters; rebuild it when they change or move.
+    def _apply(self, fn, *args, **kwargs):
+        self._engine = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._engine = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def engine(self):
+        dev = next(self.parameters()).device
+        key = (str(dev), bool(self.zero_g))
+        if self._engine is None or self._engine_key != key:
+            self._engine = ConverterEngine(self.state_dict(), self.model_cfg, self.spec_channels, dev,
+                                           zero_g=self.zero_g)
+            self._engine_key = key
+        return self._engine
+
+    def voice_conversion(self, y, y_lengths, sid_src, sid_tgt, tau=1.0, noise=None):
+        """reference: openvoice/models.py:492-499; ``noise`` is the explicit form of the
+        reference's ``randn_like`` draw (optional)."""
+        return self.engine().voice_conversion(y, y_lengths, sid_src, sid_tgt, tau=tau, noise=noise)
+
+    def infer(self, *args, **kwargs):
+        raise NotImplementedError("SynthesizerTrn.infer (V1 TTS path) is not built yet")

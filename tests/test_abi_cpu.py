@@ -1,0 +1,85 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol the header declares, and
+its host-side weight packer produces the documented MFMA fragment layout.  No kernel is launched."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from openvoice_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.skipif(not os.path.exists(_lib.LIB_PATH),
+                                reason="libopenvoice_amd.so not built (run __graft_entry__.build())")
+
+
+def test_every_header_symbol_is_exported_and_bound():
+    header = open(os.path.join(REPO, "include", "openvoice_amd.h")).read()
+    declared = set(re.findall(r"\b(ov_[a-z0-9_]+)\s*\(", header))
+    declared -= {"ov_conv1d_params"}
+    lib = _lib.load()
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert lib.ov_version() >= 100
+
+
+def test_conv_params_struct_matches_header_field_order():
+    header = open(os.path.join(REPO, "include", "openvoice_amd.h")).read()
+    body = header[header.index("typedef struct ov_conv1d_params {"):header.index("} ov_conv1d_params;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        first, *rest = decl.split(",")
+        names.append(re.findall(r"(\w+)$", first.strip())[0])
+        names += [r.strip() for r in rest]
+    assert names == [f[0] for f in _lib.ConvParams._fields_]
+
+
+@pytest.mark.parametrize("cout,cin,k", [(32, 32, 3), (96, 192, 1), (384, 192, 5), (192, 513, 1), (64, 64, 11)])
+def test_weight_packer_layout(cout, cin, k):
+    """Record (mt, U, g), lane l, component u holds W[32mt + (l&31)][8U + 2p + (l>>5)][tap] with
+    s = 4g + u, p = s // K, tap = s % K (DESIGN.md 'Packed weights')."""
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(cout * 1000 + cin + k)
+    w = torch.randn(cout, cin, k, generator=gen)
+    n = lib.ov_conv1d_pack_size(cout, cin, k)
+    dst = torch.full((n,), float("nan"))
+    assert lib.ov_conv1d_pack_f32(w.data_ptr(), cout, cin, k, dst.data_ptr()) == 0
+    rows = lib.ov_conv1d_pack_rows(cout)
+    assert rows % 128 == 0 and rows >= cout
+    nu = ((cin + 7) // 8 + 1) // 2 * 2
+    recs = nu * k + 1
+    assert n == rows // 32 * recs * 256
+    got = dst.numpy().reshape(rows // 32, recs, 64, 4)
+    assert not np.isnan(got).any()
+    wp = np.zeros((rows, nu * 8, k), dtype=np.float32)
+    wp[:cout, :cin] = w.numpy()
+    lane = np.arange(64)
+    for mt in range(rows // 32):
+        for U in range(nu):
+            for g in range(k):
+                for u in range(4):
+                    s = 4 * g + u
+                    p, tap = divmod(s, k)
+                    exp = wp[32 * mt + (lane & 31), 8 * U + 2 * p + (lane >> 5), tap]
+                    assert np.array_equal(got[mt, U * k + g, :, u], exp), (mt, U, g, u)
+    assert np.all(got[:, -1] == 0)    # prefetch-overrun record
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    lib = _lib.load()
+    assert lib.ov_conv1d_f32(None, None) == -1
+    p = _lib.ConvParams()
+    assert lib.ov_conv1d_f32(p, None) == -1
+    assert lib.ov_linear_f32(None, None, None, None, 1, 1, 1, None) == -1
+    assert lib.ov_conv_post_tanh_f32(None, None, None, 1, 1, 1, 7, 0.01, None) == -1
+    assert lib.ov_sequence_mask_f32(None, None, 1, 1, None) == -1
+    assert lib.ov_conv1d_pack_f32(None, 1, 1, 1, None) == -1
+    assert lib.ov_conv1d_pack_size(0, 1, 1) == 0

@@ -1,0 +1,69 @@
+"""End-to-end parity of the HIP converter path (through SynthesizerTrn / the C ABI) against
+(a) the committed reference outputs (tests/golden, produced by the unmodified reference) and
+(b) the oracle on the same seeded inputs at other shapes.  Tolerance from BASELINE.json's
+north_star: waveform within 1e-3 max-abs of the fp32 reference; latents are checked at 2e-4."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from openvoice_amd.models import SynthesizerTrn  # noqa: E402
+from openvoice_amd.utils import CONVERTER_MODEL_CONFIG  # noqa: E402
+
+DEV = "cuda:0"
+VC_CASES = ["vc_b2_t17", "vc_b3_t65_ragged_zero_g", "vc_b1_t40_tau0"]
+O_HAT_TOL = 1e-3
+LATENT_TOL = 2e-4
+
+
+def _model(sd, zero_g):
+    m = SynthesizerTrn(0, 513, n_speakers=0, zero_g=zero_g, **CONVERTER_MODEL_CONFIG)
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV).eval()
+
+
+@pytest.mark.parametrize("name", VC_CASES)
+def test_voice_conversion_matches_reference_golden(golden_dir, synth_sd, name):
+    rec = torch.load(os.path.join(golden_dir, name + ".pt"), weights_only=False)
+    case = rec["case"]
+    model = _model(synth_sd, case["zero_g"])
+    o_hat, y_mask, (z, z_p, z_hat) = model.voice_conversion(
+        rec["spec"].to(DEV), rec["lengths"].to(DEV), rec["g_src"].to(DEV), rec["g_tgt"].to(DEV),
+        tau=case["tau"], noise=rec["noise"].to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(y_mask.cpu(), rec["y_mask"])
+    errs = {k: (v.cpu() - rec[k]).abs().max().item() for k, v in
+            dict(z=z, z_p=z_p, z_hat=z_hat, o_hat=o_hat).items()}
+    print(name, errs)
+    assert errs["z"] <= LATENT_TOL and errs["z_p"] <= LATENT_TOL and errs["z_hat"] <= LATENT_TOL, errs
+    assert errs["o_hat"] <= O_HAT_TOL, errs
+    assert o_hat.shape == rec["o_hat"].shape
+
+
+@pytest.mark.parametrize("B,T,zero_g,per_item", [(1, 1, True, False), (2, 64, False, True), (3, 127, True, False),
+                                                 (1, 861, True, False)])
+def test_voice_conversion_matches_oracle(synth_sd, B, T, zero_g, per_item):
+    """Tile/halo edge shapes and the benchmark frame count (T = 861), vs the CPU oracle."""
+    from oracle import vc_oracle
+    gen = torch.Generator().manual_seed(B * 1000 + T)
+    spec = torch.rand(B, 513, T, generator=gen).abs() * torch.linspace(3, 0.05, 513)[None, :, None]
+    gshape = (B if per_item else 1, 256, 1)
+    g_src, g_tgt = 0.3 * torch.randn(gshape, generator=gen), 0.3 * torch.randn(gshape, generator=gen)
+    noise = torch.randn(B, 192, T, generator=gen)
+    lengths = torch.tensor([max(1, T - 7 * b) for b in range(B)], dtype=torch.long)
+    torch.set_num_threads(os.cpu_count() or 1)
+    with torch.no_grad():
+        o_ref, mask_ref, (z_r, zp_r, zh_r) = vc_oracle.voice_conversion(
+            synth_sd, CONVERTER_MODEL_CONFIG, spec, lengths, g_src, g_tgt, 0.3, noise, zero_g=zero_g)
+    model = _model(synth_sd, zero_g)
+    o_hat, y_mask, (z, z_p, z_hat) = model.voice_conversion(spec.to(DEV), lengths.to(DEV), g_src.to(DEV),
+                                                            g_tgt.to(DEV), tau=0.3, noise=noise.to(DEV))
+    torch.cuda.synchronize()
+    errs = dict(z=(z.cpu() - z_r).abs().max().item(), z_p=(z_p.cpu() - zp_r).abs().max().item(),
+                z_hat=(z_hat.cpu() - zh_r).abs().max().item(), o_hat=(o_hat.cpu() - o_ref).abs().max().item())
+    print((B, T), errs)
+    assert torch.equal(y_mask.cpu(), mask_ref)
+    assert max(errs["z"], errs["z_p"], errs["z_hat"]) <= LATENT_TOL, errs
+    assert errs["o_hat"] <= O_HAT_TOL, errs

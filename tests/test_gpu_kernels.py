@@ -1,0 +1,203 @@
+"""Parity of every HIP kernel against plain fp32 PyTorch on CPU (same op, same seeded inputs),
+called through the C ABI.  Run on the MI355X box: ``pytest -m gpu``.
+
+Tolerances: fp32 MFMA is an exact fmaf chain, so the only difference from the CPU reference is
+summation order; bounds below are ~1e-5 relative to the output scale (stated per test).
+"""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from openvoice_amd import _lib  # noqa: E402
+from openvoice_amd.engine import (PackedConv, conv_transpose_as_conv, gate_row_order, launch_conv,  # noqa: E402
+                                  _ptr)
+from openvoice_amd._lib import (EPI_CONVT, EPI_COUPLE, EPI_GATE, EPI_POSTERIOR, EPI_RESSKIP,  # noqa: E402
+                                F_MASK_V, F_OUT2_INIT)
+
+DEV = "cuda:0"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    gen = torch.Generator().manual_seed(seed)
+    return scale * torch.randn(*shape, generator=gen)
+
+
+def _close(got, ref, rel=2e-5, what=""):
+    err = (got.cpu() - ref).abs().max().item()
+    bound = rel * max(1.0, ref.abs().max().item())
+    assert err <= bound, f"{what}: max-abs err {err:.3e} > {bound:.3e}"
+
+
+RESBLOCK_SHAPES = [(c, k, d) for c in (32, 64, 128, 256) for k in (3, 7, 11) for d in (1, 3, 5)]
+
+
+@pytest.mark.parametrize("c,k,d", RESBLOCK_SHAPES)
+def test_resblock_conv_shapes(c, k, d):
+    """The 36 (C, k, dilation) convs of the MRF (reference: openvoice/modules.py:222-283) with the
+    fused leaky-ReLU prologue and bias + residual epilogue; L is not a multiple of any tile."""
+    B, L = 2, 1096 if c >= 128 else 2312
+    x, res = _rand(B, c, L, seed=1), _rand(B, c, L, seed=2)
+    w, bias = _rand(c, c, k, seed=3, scale=(c * k) ** -0.5), _rand(c, seed=4, scale=0.1)
+    ref = F.conv1d(F.leaky_relu(x, 0.1), w, bias, dilation=d, padding=(k - 1) * d // 2) + res
+    layer = PackedConv(w, bias, DEV, K=k, dil=d)
+    xd, rd = x.to(DEV), res.to(DEV)
+    out = torch.full((B, c, L), float("nan"), device=DEV)
+    launch_conv(layer, xd, 0, c * L, out, 0, c * L, B, L, in_slope=0.1, res=rd, res_bs=c * L)
+    _close(out, ref, what=f"C={c} k={k} d={d}")
+
+
+@pytest.mark.parametrize("cin,cout,k,L", [(513, 192, 1, 861), (192, 512, 7, 861), (96, 192, 1, 65),
+                                          (192, 96, 1, 17), (192, 384, 1, 1), (192, 512, 7, 864)])
+def test_frame_rate_convs_unaligned_and_aligned(cin, cout, k, L):
+    """1x1 / k7 convs at frame rate: T = 861 takes the 4-byte staging path, 864 the 16-byte one;
+    also tiny T (1, 17) and C_in that is not a multiple of the channel chunk (513, 96)."""
+    B = 3
+    x = _rand(B, cin, L, seed=5)
+    w, bias = _rand(cout, cin, k, seed=6, scale=(cin * k) ** -0.5), _rand(cout, seed=7, scale=0.1)
+    mask = (torch.arange(L)[None, :] < torch.tensor([L, max(1, L // 2), max(1, L // 3)])[:, None]).float()
+    ref = F.conv1d(x, w, bias, padding=(k - 1) // 2) * mask[:, None]
+    layer = PackedConv(w, bias, DEV, K=k)
+    out = torch.full((B, cout, L), float("nan"), device=DEV)
+    launch_conv(layer, x.to(DEV), 0, cin * L, out, 0, cout * L, B, L, flags=F_MASK_V, mask=mask.to(DEV))
+    _close(out, ref, what=f"{cin}->{cout} k={k} L={L}")
+
+
+def test_linear_epilogue_add_scale_and_batch_bias():
+    """conv2 of the last ResBlock pair: (conv + bias + res + running MRF sum) / 3, and conv_pre's
+    per-utterance conditioning bias (reference: openvoice/models.py:273-286)."""
+    B, C, L, k = 2, 64, 520, 3
+    x, res, add = _rand(B, C, L, seed=1), _rand(B, C, L, seed=2), _rand(B, C, L, seed=3)
+    w, bias, bb = _rand(C, C, k, seed=4, scale=0.1), _rand(C, seed=5), _rand(B, C, seed=6)
+    ref = (F.conv1d(x, w, bias, padding=1) + bb[:, :, None] + res + add) * (1.0 / 3.0)
+    layer = PackedConv(w, bias, DEV, K=k)
+    out = torch.empty(B, C, L, device=DEV)
+    bbd = torch.zeros(B, 128)
+    bbd[:, :C] = bb
+    launch_conv(layer, x.to(DEV), 0, C * L, out, 0, C * L, B, L, res=res.to(DEV), res_bs=C * L, add=add.to(DEV),
+                add_bs=C * L, scale=1.0 / 3.0, bias_b=bbd.to(DEV), bias_b_bs=128)
+    _close(out, ref, what="linear epilogue")
+
+
+@pytest.mark.parametrize("T", [1, 17, 200, 861])
+def test_wavenet_layer_gate_and_res_skip(T):
+    """One WN layer = k5 conv + conditioning + tanh*sigmoid gate, then the 1x1 res/skip conv
+    (reference: openvoice/modules.py:192-209, openvoice/commons.py:100-107)."""
+    B, H = 2, 192
+    x, g = _rand(B, H, T, seed=1), _rand(B, 2 * H, seed=2, scale=0.3)
+    w_in, b_in = _rand(2 * H, H, 5, seed=3, scale=(5 * H) ** -0.5), _rand(2 * H, seed=4, scale=0.1)
+    w_rs, b_rs = _rand(2 * H, H, 1, seed=5, scale=H ** -0.5), _rand(2 * H, seed=6, scale=0.1)
+    skip0 = _rand(B, H, T, seed=7)
+    mask = (torch.arange(T)[None, :] < torch.tensor([T, max(1, T - 5)])[:, None]).float()
+    x_in = F.conv1d(x, w_in, b_in, padding=2) + g[:, :, None]
+    acts = torch.tanh(x_in[:, :H]) * torch.sigmoid(x_in[:, H:])
+    rs = F.conv1d(acts, w_rs, b_rs)
+    x_ref = (x + rs[:, :H]) * mask[:, None]
+    skip_ref = skip0 + rs[:, H:]
+    order = gate_row_order(H)
+    l_in = PackedConv(w_in[order], b_in[order], DEV, K=5, cout=H)
+    l_rs = PackedConv(w_rs, b_rs, DEV, K=1)
+    xd, maskd = x.to(DEV), mask.to(DEV)
+    actsd = torch.full((B, H, T), float("nan"), device=DEV)
+    gd = g[:, order].contiguous().to(DEV)
+    launch_conv(l_in, xd, 0, H * T, actsd, 0, H * T, B, T, epi=EPI_GATE, bias_b=gd, bias_b_bs=2 * H, rows=2 * H)
+    _close(actsd, acts, what="gate")
+    skipd = skip0.to(DEV)
+    launch_conv(l_rs, actsd, 0, H * T, xd, 0, H * T, B, T, epi=EPI_RESSKIP, out2=skipd, out2_bs=H * T, mask=maskd,
+                split=H)
+    _close(xd, x_ref, what="residual")
+    _close(skipd, skip_ref, what="skip +=")
+    # first-layer form (skip = ...) and last-layer form (all rows are skip)
+    skipd2 = torch.full((B, H, T), float("nan"), device=DEV)
+    l_last = PackedConv(w_rs[:H], b_rs[:H], DEV, K=1)
+    launch_conv(l_last, actsd, 0, H * T, xd, 0, H * T, B, T, epi=EPI_RESSKIP, flags=F_OUT2_INIT, out2=skipd2,
+                out2_bs=H * T, mask=maskd, split=0)
+    _close(skipd2, F.conv1d(acts, w_rs[:H], b_rs[:H]), what="skip = (last layer)")
+
+
+@pytest.mark.parametrize("reverse", [False, True])
+@pytest.mark.parametrize("flipped", [False, True])
+def test_coupling_combine_with_folded_flip(reverse, flipped):
+    """post 1x1 conv + mean-only coupling update written in place into the x1 half, with the
+    Flip folded into channel order (reference: openvoice/modules.py:441-455, :374-381)."""
+    B, H, C, T = 2, 192, 192, 77
+    half = C // 2
+    h, x = _rand(B, H, T, seed=1), _rand(B, C, T, seed=2)
+    w, b = _rand(half, H, 1, seed=3, scale=H ** -0.5), _rand(half, seed=4, scale=0.1)
+    mask = (torch.arange(T)[None, :] < torch.tensor([T, 40])[:, None]).float()[:, None]
+    # logical view: when flipped, the logical tensor is the channel-reversed physical one
+    logical = torch.flip(x, [1]) if flipped else x
+    m = F.conv1d(h, w, b) * mask
+    x1 = logical[:, half:]
+    x1n = (x1 - m) * mask if reverse else m + x1 * mask
+    logical_new = torch.cat([logical[:, :half], x1n], 1)
+    ref = torch.flip(logical_new, [1]) if flipped else logical_new
+    wl, bl = (torch.flip(w, [0]), torch.flip(b, [0])) if flipped else (w, b)
+    layer = PackedConv(wl, bl, DEV, K=1)
+    xd = x.to(DEV)
+    launch_conv(layer, h.to(DEV), 0, H * T, xd, 0 if flipped else half * T, C * T, B, T, epi=EPI_COUPLE,
+                mask=mask[:, 0].contiguous().to(DEV), scale=-1.0 if reverse else 1.0)
+    _close(xd, ref, what=f"couple reverse={reverse} flipped={flipped}")
+
+
+def test_posterior_sample_epilogue():
+    """proj 1x1 conv + z = (m + noise*tau*exp(logs)) * mask (reference: openvoice/models.py:218-220)."""
+    B, H, C, T, tau = 2, 192, 192, 130, 0.3
+    h, noise = _rand(B, H, T, seed=1), _rand(B, C, T, seed=2)
+    w, b = _rand(2 * C, H, 1, seed=3, scale=H ** -0.5), _rand(2 * C, seed=4, scale=0.1)
+    mask = (torch.arange(T)[None, :] < torch.tensor([T, 64])[:, None]).float()[:, None]
+    stats = F.conv1d(h, w, b) * mask
+    ref = (stats[:, :C] + noise * tau * torch.exp(stats[:, C:])) * mask
+    order = gate_row_order(C)
+    layer = PackedConv(w[order], b[order], DEV, K=1, cout=C)
+    z = torch.full((B, C, T), float("nan"), device=DEV)
+    launch_conv(layer, h.to(DEV), 0, H * T, z, 0, C * T, B, T, epi=EPI_POSTERIOR, res=noise.to(DEV), res_bs=C * T,
+                scale=tau, mask=mask[:, 0].contiguous().to(DEV), rows=2 * C)
+    _close(z, ref, what="posterior")
+
+
+@pytest.mark.parametrize("cin,cout,s,L", [(512, 256, 8, 61), (256, 128, 8, 488), (128, 64, 2, 1000), (64, 32, 2, 2000)])
+def test_conv_transpose_as_phase_conv(cin, cout, s, L):
+    """leaky_relu(0.1) + ConvTranspose1d(k=2s, stride s, pad s/2) (reference: openvoice/models.py:278-279,
+    :244-256) as the 3-tap phase conv with the interleaving 16/8-byte store epilogue."""
+    B, k = 2, 2 * s
+    x = _rand(B, cin, L, seed=1)
+    w, b = _rand(cin, cout, k, seed=2, scale=(2 * cin) ** -0.5), _rand(cout, seed=3, scale=0.1)
+    ref = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, stride=s, padding=(k - s) // 2)
+    assert ref.shape[2] == s * L
+    layer = PackedConv(conv_transpose_as_conv(w, s), b.repeat_interleave(s), DEV, K=3, cout=cout)
+    out = torch.full((B, cout, s * L), float("nan"), device=DEV)
+    launch_conv(layer, x.to(DEV), 0, cin * L, out, 0, cout * s * L, B, L, epi=EPI_CONVT, in_slope=0.1, phase_s=s)
+    _close(out, ref, what=f"convT {cin}->{cout} s={s}")
+
+
+@pytest.mark.parametrize("L", [4352, 1001])
+def test_conv_post_tanh(L):
+    """leaky_relu(0.01) + conv k7 32->1 (no bias) + tanh (reference: openvoice/models.py:287-289)."""
+    B, C = 2, 32
+    x, w = _rand(B, C, L, seed=1), _rand(1, C, 7, seed=2, scale=0.1)
+    ref = torch.tanh(F.conv1d(F.leaky_relu(x, 0.01), w, None, padding=3))
+    lib = _lib.load()
+    out = torch.full((B, 1, L), float("nan"), device=DEV)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    xd, wd = x.to(DEV), w[0].contiguous().to(DEV)
+    assert lib.ov_conv_post_tanh_f32(_ptr(xd), _ptr(wd), _ptr(out), B, C, L, 7, 0.01, st) == 0
+    _close(out, ref, what="conv_post")
+
+
+def test_linear_and_sequence_mask():
+    lib = _lib.load()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x, w, b = _rand(3, 256, seed=1), _rand(1536, 256, seed=2, scale=1 / 16), _rand(1536, seed=3)
+    y = torch.empty(3, 1536, device=DEV)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    assert lib.ov_linear_f32(_ptr(xd), _ptr(wd), _ptr(bd), _ptr(y), 3, 1536, 256, st) == 0
+    _close(y, x @ w.t() + b, what="linear")
+    lengths = torch.tensor([5, 0, 9, 7], dtype=torch.int64, device=DEV)
+    mask = torch.empty(4, 9, device=DEV)
+    assert lib.ov_sequence_mask_f32(ctypes.c_void_p(lengths.data_ptr()), _ptr(mask), 4, 9, st) == 0
+    ref = (torch.arange(9)[None] < lengths.cpu()[:, None]).float()
+    assert torch.equal(mask.cpu(), ref)
