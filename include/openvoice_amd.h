@@ -126,6 +126,27 @@ int ov_linear_f32(const float* x, const float* w, const float* bias, float* y, i
 /* mask[b][t] = t < lengths[b] ? 1 : 0, reference openvoice/commons.py:121-125. */
 int ov_sequence_mask_f32(const int64_t* lengths, float* mask, int B, int T, ov_stream_t stream);
 
+/* ---- ReferenceEncoder (extract_se), reference openvoice/models.py:339-359 -----------------------
+ * Layout: time is the contiguous axis everywhere, [N][C][F][T]; the spectrogram [N][F][T] is the
+ * C = 1 case, and the conv-stack output [N][128][9][T'] read as [N][1152][T'] is the GRU input in
+ * the (B, C, T) layout of ov_conv1d_f32 (feature index c*9 + f, as models.py:351-354 builds it). */
+
+/* y[n][f][t] = LayerNorm over f of x[n][:, t] (nn.LayerNorm(F), reference models.py:344). */
+int ov_layernorm_freq_f32(const float* x, const float* gamma, const float* beta, float* y, int N, int F, int T,
+                          float eps, ov_stream_t stream);
+
+/* y = relu(conv2d(x, w, bias, stride 2, pad 1)), 3x3; w is the reference's [Cout][Cin][kh=time][kw=freq]
+ * (models.py:314-325, :346-349).  x [N][Cin][Fi][Ti] -> y [N][Cout][(Fi-1)/2+1][(Ti-1)/2+1].
+ * Cout must be a multiple of 16. */
+int ov_conv2d_s2_relu_f32(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Cout,
+                          int Fi, int Ti, ov_stream_t stream);
+
+/* GRU recurrence over T steps from h0 = 0, final hidden state out (nn.GRU batch_first, models.py:356-357).
+ * gi [N][3H][T] = W_ih x_t + b_ih (gate order r,z,n), whh_t = W_hh transposed to [H][3H], bhh [3H],
+ * h_out [N][H].  H must be 128. */
+int ov_gru_f32(const float* gi, const float* whh_t, const float* bhh, float* h_out, int N, int H, int T,
+               ov_stream_t stream);
+
 /* Library/ABI version (major*100 + minor). */
 int ov_version(void);
 

@@ -1,0 +1,204 @@
+"""Public API of the tone-colour converter, re-hosted on the MI355X engine.
+
+Same class names, constructor/ method signatures, attributes (``model``, ``hps``, ``device``,
+``version``, ``watermark_model``) and return types as the reference API layer
+(reference: openvoice/api.py:14-201), so the upstream notebooks run unchanged
+(``from openvoice.api import ToneColorConverter`` resolves here through the ``openvoice`` alias
+package at the repo root).  What differs, on purpose:
+
+* the model behind ``self.model`` is ``openvoice_amd.models.SynthesizerTrn`` whose
+  ``voice_conversion`` / ``ref_enc`` run hand-written gfx950 kernels -- there is no eager PyTorch
+  compute and no CPU fallback (a 'cpu' device is rejected at construction);
+* ``ToneColorConverter.__init__`` strips ``enable_watermark`` before calling the base class (the
+  reference forwards it and raises TypeError);
+* ``convert_batch`` (new) is the batched entry the benchmark configs use; ``convert`` is file I/O
+  around ``convert_batch`` with B = 1;
+* audio decode / WAV write go through ``openvoice_amd.audio_io`` (librosa/soundfile when present);
+* the watermark (third-party ``wavmark``) stays an optional post-processing hook.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import audio_io, utils
+from .mel_processing import spectrogram_torch
+from .models import SynthesizerTrn
+
+
+class OpenVoiceBaseClass(object):
+    """reference: openvoice/api.py:14-39."""
+
+    def __init__(self, config_path, device="cuda:0"):
+        if "cuda" in device:
+            assert torch.cuda.is_available()
+        else:
+            raise RuntimeError(f"device {device!r}: the MI355X engine has no CPU path; use 'cuda:N'")
+        hps = utils.get_hparams_from_file(config_path)
+        model = SynthesizerTrn(
+            len(getattr(hps, "symbols", [])),
+            hps.data.filter_length // 2 + 1,
+            n_speakers=hps.data.n_speakers,
+            **hps.model,
+        ).to(device)
+        model.eval()
+        self.model = model
+        self.hps = hps
+        self.device = device
+
+    def load_ckpt(self, ckpt_path):
+        checkpoint_dict = torch.load(ckpt_path, map_location=torch.device(self.device))
+        a, b = self.model.load_state_dict(checkpoint_dict["model"], strict=False)
+        print("Loaded checkpoint '{}'".format(ckpt_path))
+        print("missing/unexpected keys:", a, b)
+
+
+class BaseSpeakerTTS(OpenVoiceBaseClass):
+    """V1 base-speaker TTS (reference: openvoice/api.py:42-98).  The class and its static helpers
+    exist so imports and notebook cells resolve; the model behind ``tts`` (TextEncoder, duration
+    predictors, spline flows -- BASELINE.json configs[3]) is SURVEY.md section 8(f) item 1 and is
+    not built yet: constructing it raises NotImplementedError from ``SynthesizerTrn``."""
+
+    language_marks = {"english": "EN", "chinese": "ZH"}
+
+    @staticmethod
+    def audio_numpy_concat(segment_data_list, sr, speed=1.0):
+        """reference: openvoice/api.py:56-63 -- segments joined with 50 ms / speed of silence after
+        each (built with one allocation instead of a Python list of samples)."""
+        gap = np.zeros(int((sr * 0.05) / speed), dtype=np.float32)
+        parts = []
+        for segment in segment_data_list:
+            parts += [np.asarray(segment, dtype=np.float32).reshape(-1), gap]
+        return np.concatenate(parts) if parts else np.zeros(0, dtype=np.float32)
+
+    def tts(self, text, output_path, speaker, language="English", speed=1.0):
+        mark = self.language_marks.get(language.lower(), None)
+        assert mark is not None, f"language {language} is not supported"
+        raise NotImplementedError("BaseSpeakerTTS.tts: the V1 TTS model is not built on the MI355X engine yet")
+
+
+def string_to_bits(string, pad_len=8):
+    """ASCII -> [pad_len, 8] bit matrix, MSB first, short strings padded with 0b00100000 (space);
+    reference: openvoice/utils.py:46-62."""
+    codes = np.frombuffer(string.encode("latin-1", "replace")[:pad_len], dtype=np.uint8)
+    full = np.full(pad_len, 0x20, dtype=np.uint8)
+    full[:len(codes)] = codes
+    return np.unpackbits(full[:, None], axis=1).astype(np.int64)
+
+
+def bits_to_string(bits_array):
+    """reference: openvoice/utils.py:65-75."""
+    vals = np.packbits(np.asarray(bits_array).astype(np.uint8), axis=1).reshape(-1)
+    return "".join(chr(int(v)) for v in vals)
+
+
+class ToneColorConverter(OpenVoiceBaseClass):
+    """reference: openvoice/api.py:101-201."""
+
+    def __init__(self, *args, **kwargs):
+        enable_watermark = kwargs.pop("enable_watermark", True)
+        super().__init__(*args, **kwargs)
+        self.watermark_model = None
+        if enable_watermark:
+            try:
+                import wavmark   # third-party, not part of the reference tree (requirements.txt:4)
+                self.watermark_model = wavmark.load_model().to(self.device)
+            except ImportError:
+                print("wavmark is not installed: watermarking disabled")
+        self.version = getattr(self.hps, "_version_", "v1")
+
+    # ---- spectrogram helpers ---------------------------------------------------------------------
+    def _spec(self, y):
+        d = self.hps.data
+        return spectrogram_torch(y, d.filter_length, d.sampling_rate, d.hop_length, d.win_length, center=False)
+
+    def extract_se(self, ref_wav_list, se_save_path=None):
+        """Mean reference-encoder embedding over the given audio files -> ``[1, gin, 1]``
+        (reference: openvoice/api.py:114-139)."""
+        if isinstance(ref_wav_list, str):
+            ref_wav_list = [ref_wav_list]
+        gs = []
+        for fname in ref_wav_list:
+            audio_ref, _ = audio_io.load(fname, sr=self.hps.data.sampling_rate)
+            y = torch.from_numpy(np.ascontiguousarray(audio_ref, dtype=np.float32)).to(self.device).unsqueeze(0)
+            spec = self._spec(y)
+            with torch.no_grad():
+                g = self.model.ref_enc(spec.transpose(1, 2)).unsqueeze(-1)
+            gs.append(g.detach())
+        gs = torch.stack(gs).mean(0)
+        if se_save_path is not None:
+            os.makedirs(os.path.dirname(se_save_path), exist_ok=True)
+            torch.save(gs.cpu(), se_save_path)
+        return gs
+
+    @torch.no_grad()
+    def convert_batch(self, waveforms, src_se, tgt_se, tau=0.3, noise=None):
+        """Batched conversion, everything on the device.
+
+        ``waveforms``: float32 tensor ``[B, N]`` (equal lengths), or a list of 1-D tensors/arrays of
+        different lengths (each gets its own spectrogram, exactly as a per-file ``convert`` would,
+        then the batch is zero-padded in frames and masked by ``spec_lengths``).  Returns
+        ``(o_hat [B, 1, hop*T_max] on the device, lengths_in_samples [B])``.  Note the reference
+        decoder is unmasked, so for ragged batches samples within ~13 frames of an utterance's end
+        differ from a per-utterance run (hard part 6); trim with the returned
+        lengths."""
+        hop = self.hps.data.hop_length
+        if isinstance(waveforms, (list, tuple)):
+            specs = [self._spec(torch.as_tensor(w, dtype=torch.float32).to(self.device).reshape(1, -1))[0]
+                     for w in waveforms]
+            frames = [s.shape[1] for s in specs]
+            spec = torch.zeros(len(specs), specs[0].shape[0], max(frames), dtype=torch.float32, device=self.device)
+            for i, s in enumerate(specs):
+                spec[i, :, :s.shape[1]] = s
+            spec_lengths = torch.tensor(frames, dtype=torch.int64, device=self.device)
+        else:
+            y = torch.as_tensor(waveforms, dtype=torch.float32).to(self.device)
+            spec = self._spec(y)
+            spec_lengths = torch.full((spec.shape[0],), spec.shape[2], dtype=torch.int64, device=self.device)
+        o_hat = self.model.voice_conversion(spec, spec_lengths, sid_src=src_se, sid_tgt=tgt_se, tau=tau,
+                                            noise=noise)[0]
+        return o_hat, spec_lengths * hop
+
+    def convert(self, audio_src_path, src_se, tgt_se, output_path=None, tau=0.3, message="default"):
+        """reference: openvoice/api.py:141-160."""
+        hps = self.hps
+        audio, _ = audio_io.load(audio_src_path, sr=hps.data.sampling_rate)
+        y = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32)).unsqueeze(0)
+        o_hat, _ = self.convert_batch(y, src_se, tgt_se, tau=tau)
+        audio = o_hat[0, 0].data.cpu().float().numpy()
+        audio = self.add_watermark(audio, message)
+        if output_path is None:
+            return audio
+        audio_io.write(output_path, audio, hps.data.sampling_rate)
+
+    # ---- optional watermark hook (third-party model; reference: openvoice/api.py:162-201) ----------
+    def add_watermark(self, audio, message):
+        if self.watermark_model is None:
+            return audio
+        bits = string_to_bits(message).reshape(-1)
+        n_repeat = len(bits) // 32
+        K, coeff = 16000, 2
+        for n in range(n_repeat):
+            trunck = audio[(coeff * n) * K: (coeff * n + 1) * K]
+            if len(trunck) != K:
+                print("Audio too short, fail to add watermark")
+                break
+            with torch.no_grad():
+                signal = torch.FloatTensor(trunck).to(self.device)[None]
+                msg = torch.FloatTensor(bits[n * 32: (n + 1) * 32]).to(self.device)[None]
+                audio[(coeff * n) * K: (coeff * n + 1) * K] = \
+                    self.watermark_model.encode(signal, msg).detach().cpu().squeeze()
+        return audio
+
+    def detect_watermark(self, audio, n_repeat):
+        bits = []
+        K, coeff = 16000, 2
+        for n in range(n_repeat):
+            trunck = audio[(coeff * n) * K: (coeff * n + 1) * K]
+            if len(trunck) != K:
+                print("Audio too short, fail to detect watermark")
+                return "Fail"
+            with torch.no_grad():
+                signal = torch.FloatTensor(trunck).to(self.device).unsqueeze(0)
+                bits.append((self.watermark_model.decode(signal) >= 0.5).int().detach().cpu().numpy().squeeze())
+        return bits_to_string(np.stack(bits).reshape(-1, 8))

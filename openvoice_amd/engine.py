@@ -17,7 +17,7 @@ import torch
 from . import _lib
 from ._lib import (ConvParams, EPI_CONVT, EPI_COUPLE, EPI_GATE, EPI_LINEAR, EPI_POSTERIOR, EPI_RESSKIP,
                    F_MASK_V, F_OUT2_INIT)
-from .params import ENC_Q_LAYERS, FLOW_LAYERS, N_FLOWS, effective_weight
+from .params import ENC_Q_LAYERS, FLOW_LAYERS, N_FLOWS, REF_ENC_FILTERS, REF_ENC_GRU, effective_weight
 
 LRELU_SLOPE = 0.1       # reference: openvoice/modules.py:14
 FINAL_LRELU_SLOPE = 0.01  # F.leaky_relu default at openvoice/models.py:287
@@ -193,6 +193,21 @@ class ConverterEngine:
         self.total_upsample = 1
         for u in cfg["upsample_rates"]:
             self.total_upsample *= u
+        # ---- reference encoder (extract_se): present in converter checkpoints only -------------------
+        self.ref_enc = None
+        if "ref_enc.gru.weight_ih_l0" in sd:
+            convs = [(effective_weight(sd, f"ref_enc.convs.{i}").contiguous().to(dev),
+                      sd[f"ref_enc.convs.{i}.bias"].contiguous().to(dev)) for i in range(len(REF_ENC_FILTERS))]
+            w_ih = sd["ref_enc.gru.weight_ih_l0"]
+            self.ref_enc = dict(
+                ln_w=sd["ref_enc.layernorm.weight"].contiguous().to(dev),
+                ln_b=sd["ref_enc.layernorm.bias"].contiguous().to(dev),
+                convs=convs,
+                gru_in=PackedConv(w_ih.unsqueeze(-1), sd["ref_enc.gru.bias_ih_l0"], dev, K=1),
+                whh_t=sd["ref_enc.gru.weight_hh_l0"].t().contiguous().to(dev),
+                bhh=sd["ref_enc.gru.bias_hh_l0"].contiguous().to(dev),
+                proj_w=sd["ref_enc.proj.weight"].contiguous().to(dev),
+                proj_b=sd["ref_enc.proj.bias"].contiguous().to(dev))
         self._ws = {}
         self.profile = None   # set to [] to collect per-launch HIP-event timings
 
@@ -353,3 +368,36 @@ class ConverterEngine:
                                                   self.post_w.shape[1], FINAL_LRELU_SLOPE, self._stream()),
                    "ov_conv_post_tanh_f32")
         return o_hat
+
+    # ---- extract_se path -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def reference_encoder(self, spec_t):
+        """``spec_t`` [N, Ty, n_freq] (the transposed spectrogram the reference API passes,
+        openvoice/api.py:131) -> [N, gin]; reference: openvoice/models.py:339-359.  Internally every
+        tensor is [N][C][F][T] (time contiguous), i.e. the un-transposed spectrogram: when the caller
+        passes ``spec.transpose(1, 2)`` the transpose back is a view and nothing is copied."""
+        re = self.ref_enc
+        if re is None:
+            raise _lib.OvError("this checkpoint has no ref_enc.* weights")
+        dev, st, lib = self.device, self._stream(), self.lib
+        x = spec_t.to(dev, torch.float32).transpose(1, 2).contiguous()     # [N, F, T]
+        N, F, T = x.shape
+        assert F == self.spec_channels
+        cur = torch.empty_like(x)
+        _lib.check(lib.ov_layernorm_freq_f32(_ptr(x), _ptr(re["ln_w"]), _ptr(re["ln_b"]), _ptr(cur), N, F, T,
+                                             1e-5, st), "ov_layernorm_freq_f32")
+        cin = 1
+        for w, b in re["convs"]:
+            cout = w.shape[0]
+            Fo, To = (F - 1) // 2 + 1, (T - 1) // 2 + 1
+            nxt = torch.empty(N, cout, Fo, To, dtype=torch.float32, device=dev)
+            _lib.check(lib.ov_conv2d_s2_relu_f32(_ptr(cur), _ptr(w), _ptr(b), _ptr(nxt), N, cin, cout, F, T, st),
+                       "ov_conv2d_s2_relu_f32")
+            cur, cin, F, T = nxt, cout, Fo, To
+        feat = cin * F                                                        # 128 * 9 = 1152
+        H = REF_ENC_GRU
+        gi = torch.empty(N, 3 * H, T, dtype=torch.float32, device=dev)
+        self._conv(re["gru_in"], cur, 0, feat * T, gi, 0, 3 * H * T, N, T, tag="gru_in")
+        h = torch.empty(N, H, dtype=torch.float32, device=dev)
+        _lib.check(lib.ov_gru_f32(_ptr(gi), _ptr(re["whh_t"]), _ptr(re["bhh"]), _ptr(h), N, H, T, st), "ov_gru_f32")
+        return self._linear(h, re["proj_w"], re["proj_b"])

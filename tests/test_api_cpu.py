@@ -1,0 +1,125 @@
+"""Host-side logic of the API boundary that needs no GPU: config loader, audio file I/O stand-ins,
+watermark bit codec, the alias package, and the fail-loudly behaviour without a ROCm device."""
+import json
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from openvoice_amd import api, audio_io, utils
+from openvoice_amd.utils import default_converter_hparams
+
+
+def _config(tmp_path, version="v2"):
+    hps = default_converter_hparams(version)
+    cfg = {"data": dict(hps.data.items()), "model": dict(hps.model.items())}
+    if version == "v2":
+        cfg["_version_"] = "v2"
+    path = tmp_path / "config.json"
+    path.write_text(json.dumps(cfg))
+    return str(path)
+
+
+def test_hparams_round_trip(tmp_path):
+    hps = utils.get_hparams_from_file(_config(tmp_path))
+    assert hps.data.sampling_rate == 22050 and hps["data"]["hop_length"] == 256
+    assert hps.model.zero_g is True and getattr(hps, "_version_") == "v2"
+    kwargs = dict(**hps.model)
+    assert kwargs["upsample_rates"] == [8, 8, 2, 2] and "model" in hps and len(hps.data) == 5
+
+
+def test_no_cpu_path(tmp_path):
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        api.ToneColorConverter(_config(tmp_path), device="cpu", enable_watermark=False)
+    if not torch.cuda.is_available():
+        with pytest.raises(AssertionError):          # reference: openvoice/api.py:18-19
+            api.ToneColorConverter(_config(tmp_path), device="cuda:0", enable_watermark=False)
+
+
+def test_engine_rejects_cpu_device(synth_sd):
+    from openvoice_amd._lib import OvError
+    from openvoice_amd.engine import ConverterEngine
+    with pytest.raises(OvError):
+        ConverterEngine(synth_sd, utils.CONVERTER_MODEL_CONFIG, 513, "cpu")
+
+
+def test_v1_tts_model_is_reported_as_not_built(tmp_path):
+    from openvoice_amd.models import SynthesizerTrn
+    with pytest.raises(NotImplementedError):
+        SynthesizerTrn(68, 513, n_speakers=10, **utils.CONVERTER_MODEL_CONFIG)
+
+
+def test_state_dict_round_trip_strict(synth_sd):
+    from openvoice_amd.models import SynthesizerTrn
+    model = SynthesizerTrn(0, 513, n_speakers=0, **utils.CONVERTER_MODEL_CONFIG)
+    missing, unexpected = model.load_state_dict(synth_sd, strict=True)
+    assert not missing and not unexpected
+    back = model.state_dict()
+    assert set(back) == set(synth_sd)
+    assert all(torch.equal(back[k], synth_sd[k]) for k in back)
+
+
+def test_wav_write_read_round_trip(tmp_path):
+    sr = 22050
+    t = np.arange(sr // 2, dtype=np.float32) / sr
+    x = (0.5 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
+    path = str(tmp_path / "a.wav")
+    audio_io.write(path, x, sr)
+    y, sr2 = audio_io.load(path, sr)
+    assert sr2 == sr and y.dtype == np.float32 and y.shape == x.shape
+    assert np.abs(y - x).max() <= 1.0 / 32768 + 1e-7
+
+
+def test_wav_reader_formats_and_resample(tmp_path):
+    sr = 44100
+    t = np.arange(sr // 4) / sr
+    x = 0.25 * np.sin(2 * np.pi * 300 * t)
+    stereo = np.stack([x, x], 1).astype("<f4")
+    body = stereo.tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(body)) + b"WAVE" + b"fmt " + struct.pack(
+        "<IHHIIHH", 16, 3, 2, sr, sr * 8, 8, 32) + b"data" + struct.pack("<I", len(body))
+    path = tmp_path / "f32_stereo.wav"
+    path.write_bytes(hdr + body)
+    y, out_sr = audio_io.load(str(path), 22050)
+    assert out_sr == 22050 and abs(len(y) - len(x) // 2) <= 1
+    ref = 0.25 * np.sin(2 * np.pi * 300 * np.arange(len(y)) / 22050)
+    assert np.abs(y[200:-200] - ref[200:-200]).max() < 2e-3     # polyphase resampler, edges excluded
+    with pytest.raises(ValueError):
+        bad = tmp_path / "x.mp3"
+        bad.write_bytes(b"ID3\x00" * 10)
+        audio_io._read_wav(str(bad))
+
+
+def test_watermark_bit_codec_matches_reference_convention():
+    # reference: openvoice/utils.py:46-75 -- MSB-first ASCII, padded to 8 rows of 0b00100000
+    bits = api.string_to_bits("@MyShell")
+    assert bits.shape == (8, 8) and bits[0].tolist() == [0, 1, 0, 0, 0, 0, 0, 0]
+    assert api.bits_to_string(bits) == "@MyShell"
+    short = api.string_to_bits("ab")
+    assert short[2:].tolist() == [[0, 0, 1, 0, 0, 0, 0, 0]] * 6
+    assert api.bits_to_string(short) == "ab" + " " * 6
+    assert api.string_to_bits("0123456789").shape == (8, 8)
+
+
+def test_audio_numpy_concat():
+    segs = [np.ones(10, dtype=np.float32), 2 * np.ones((1, 5), dtype=np.float32)]
+    out = api.BaseSpeakerTTS.audio_numpy_concat(segs, sr=1000, speed=2.0)
+    gap = int(1000 * 0.05 / 2.0)
+    assert out.dtype == np.float32 and len(out) == 15 + 2 * gap
+    assert out[:10].tolist() == [1.0] * 10 and out[10:10 + gap].sum() == 0 and out[10 + gap] == 2.0
+
+
+def test_alias_package_exposes_reference_import_paths():
+    from openvoice import se_extractor
+    from openvoice.api import BaseSpeakerTTS, ToneColorConverter
+    assert ToneColorConverter is api.ToneColorConverter and BaseSpeakerTTS is api.BaseSpeakerTTS
+    assert callable(se_extractor.get_se)
+
+
+def test_spectrogram_front_end_matches_oracle(golden_dir):
+    import os
+    from openvoice_amd.mel_processing import spectrogram_torch
+    rec = torch.load(os.path.join(golden_dir, "vc_b2_t17.pt"), weights_only=False)
+    spec = spectrogram_torch(rec["wave"], 1024, 22050, 256, 1024, center=False)
+    assert (spec - rec["spec"]).abs().max().item() <= 1e-4 * rec["spec"].abs().max().item()

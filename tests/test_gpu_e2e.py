@@ -67,3 +67,32 @@ def test_voice_conversion_matches_oracle(synth_sd, B, T, zero_g, per_item):
     assert torch.equal(y_mask.cpu(), mask_ref)
     assert max(errs["z"], errs["z_p"], errs["z_hat"]) <= LATENT_TOL, errs
     assert errs["o_hat"] <= O_HAT_TOL, errs
+
+
+@pytest.mark.parametrize("name", VC_CASES + ["ref_enc_b2_t200"])
+def test_reference_encoder_matches_reference_golden(golden_dir, synth_sd, name):
+    """extract_se's model half: model.ref_enc(spec.transpose(1, 2)) as openvoice/api.py:131 calls it,
+    against the unmodified reference's output.  Tolerance 1e-4 max-abs on |se| ~ 0.1-0.3."""
+    rec = torch.load(os.path.join(golden_dir, name + ".pt"), weights_only=False)
+    model = _model(synth_sd, False)
+    se = model.ref_enc(rec["spec"].to(DEV).transpose(1, 2))
+    torch.cuda.synchronize()
+    assert se.shape == rec["ref_enc"].shape
+    err = (se.cpu() - rec["ref_enc"]).abs().max().item()
+    print(name, "ref_enc err", err, "scale", rec["ref_enc"].abs().max().item())
+    assert err <= 1e-4, err
+
+
+def test_reference_encoder_matches_oracle_at_benchmark_length(synth_sd):
+    """T = 861 frames (10 s): 14 GRU steps, all six conv2d layers with odd sizes."""
+    from oracle import vc_oracle
+    gen = torch.Generator().manual_seed(5)
+    spec = torch.rand(3, 513, 861, generator=gen) * torch.linspace(3, 0.05, 513)[None, :, None]
+    with torch.no_grad():
+        ref = vc_oracle.reference_encoder(synth_sd, spec.transpose(1, 2))
+    model = _model(synth_sd, False)
+    se = model.ref_enc(spec.to(DEV).transpose(1, 2))
+    torch.cuda.synchronize()
+    err = (se.cpu() - ref).abs().max().item()
+    print("ref_enc T=861 err", err)
+    assert err <= 1e-4, err
