@@ -46,7 +46,8 @@ def cpu_baseline(sd, cfg, seconds, budget_s=20.0):
     """The oracle (CPU restatement of the reference path, 'port') on this box's host cores:
     B = 1 utterances of the same length, repeated until ~budget_s of CPU work."""
     from oracle import vc_oracle
-    cores = os.cpu_count() or 1
+    from openvoice_amd.hostinfo import usable_cpus
+    cores = usable_cpus(32)
     torch.set_num_threads(cores)
     samples = int(seconds * SAMPLE_RATE)
     wave = synth_wave(1, samples, 7, "cpu")

@@ -70,7 +70,7 @@ enum {
 typedef struct ov_conv1d_params {
   const float* x;        /* [B][>=Cin][L]; channel offset already applied to the pointer        */
   const float* w;        /* packed weights from ov_conv1d_pack_f32                              */
-  const float* bias;     /* [M] in packed row order, or NULL                                    */
+  const float* bias;     /* [M rounded up to 128] in packed row order; required (zeros if none) */
   const float* bias_b;   /* per-batch bias [B or 1][M] in packed row order, or NULL             */
   float* out;            /* primary output, indexed [b][row][t] with out_bstride                */
   const float* res;      /* LINEAR: residual; POSTERIOR: noise; indexed like out; or NULL       */
@@ -88,6 +88,7 @@ typedef struct ov_conv1d_params {
   int32_t Cout;          /* rows >= Cout (LINEAR/COUPLE/RESSKIP) are padding and never stored    */
   int32_t K, dil;        /* taps, dilation; padding is (K-1)*dil/2                               */
   int32_t epi, flags, split, phase_s;
+  int32_t tiles_per_wg;  /* consecutive time tiles walked by one workgroup; 0 = chosen by the launcher */
   float in_slope;        /* leaky-ReLU slope applied to x while staging (1.0f = identity)        */
   float scale;
 } ov_conv1d_params;

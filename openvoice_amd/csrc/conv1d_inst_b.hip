@@ -1,27 +1,29 @@
-// Tile 64x256 (1x4 waves, 64x64 per wave): 64-row convs (ResBlock stage 2, ups.3).
+// Tile 64x256 (1x4 matrix waves, 64x64 per wave): 64-row convs (ResBlock stage 2, ups.3).
 #include "conv1d_mfma.h"
 namespace ovk {
 // explicit kernel instantiations (both host and device passes see these)
-template __global__ void conv1d_mfma_kernel<3, 1, 2, 2, 1, 4, true>(const ov_conv1d_params);
-template __global__ void conv1d_mfma_kernel<3, 3, 2, 2, 1, 4, true>(const ov_conv1d_params);
-template __global__ void conv1d_mfma_kernel<3, 5, 2, 2, 1, 4, true>(const ov_conv1d_params);
-template __global__ void conv1d_mfma_kernel<7, 1, 2, 2, 1, 4, true>(const ov_conv1d_params);
-template __global__ void conv1d_mfma_kernel<7, 3, 2, 2, 1, 4, true>(const ov_conv1d_params);
-template __global__ void conv1d_mfma_kernel<7, 5, 2, 2, 1, 4, true>(const ov_conv1d_params);
-template __global__ void conv1d_mfma_kernel<11, 1, 2, 2, 1, 4, true>(const ov_conv1d_params);
-template __global__ void conv1d_mfma_kernel<11, 3, 2, 2, 1, 4, true>(const ov_conv1d_params);
-template __global__ void conv1d_mfma_kernel<11, 5, 2, 2, 1, 4, true>(const ov_conv1d_params);
+template __global__ void conv1d_mfma_kernel<3, 1, 2, 2, 1, 4, 16, true, OV_EPI_LINEAR>(const ov_conv1d_params, const int);
+template __global__ void conv1d_mfma_kernel<3, 3, 2, 2, 1, 4, 16, true, OV_EPI_LINEAR>(const ov_conv1d_params, const int);
+template __global__ void conv1d_mfma_kernel<3, 5, 2, 2, 1, 4, 16, true, OV_EPI_LINEAR>(const ov_conv1d_params, const int);
+template __global__ void conv1d_mfma_kernel<7, 1, 2, 2, 1, 4, 16, true, OV_EPI_LINEAR>(const ov_conv1d_params, const int);
+template __global__ void conv1d_mfma_kernel<7, 3, 2, 2, 1, 4, 16, true, OV_EPI_LINEAR>(const ov_conv1d_params, const int);
+template __global__ void conv1d_mfma_kernel<7, 5, 2, 2, 1, 4, 16, true, OV_EPI_LINEAR>(const ov_conv1d_params, const int);
+template __global__ void conv1d_mfma_kernel<11, 1, 2, 2, 1, 4, 16, true, OV_EPI_LINEAR>(const ov_conv1d_params, const int);
+template __global__ void conv1d_mfma_kernel<11, 3, 2, 2, 1, 4, 16, true, OV_EPI_LINEAR>(const ov_conv1d_params, const int);
+template __global__ void conv1d_mfma_kernel<11, 5, 2, 2, 1, 4, 16, true, OV_EPI_LINEAR>(const ov_conv1d_params, const int);
+template __global__ void conv1d_mfma_kernel<3, 1, 2, 2, 1, 4, 16, true, OV_EPI_CONVT>(const ov_conv1d_params, const int);
 #if !defined(__HIP_DEVICE_COMPILE__)
 const ConvVariant kVariantsB[] = {
-    {3, 1, TILE_64x256, 1, conv1d_launch<3, 1, 2, 2, 1, 4, true>},
-    {3, 3, TILE_64x256, 1, conv1d_launch<3, 3, 2, 2, 1, 4, true>},
-    {3, 5, TILE_64x256, 1, conv1d_launch<3, 5, 2, 2, 1, 4, true>},
-    {7, 1, TILE_64x256, 1, conv1d_launch<7, 1, 2, 2, 1, 4, true>},
-    {7, 3, TILE_64x256, 1, conv1d_launch<7, 3, 2, 2, 1, 4, true>},
-    {7, 5, TILE_64x256, 1, conv1d_launch<7, 5, 2, 2, 1, 4, true>},
-    {11, 1, TILE_64x256, 1, conv1d_launch<11, 1, 2, 2, 1, 4, true>},
-    {11, 3, TILE_64x256, 1, conv1d_launch<11, 3, 2, 2, 1, 4, true>},
-    {11, 5, TILE_64x256, 1, conv1d_launch<11, 5, 2, 2, 1, 4, true>},
+    {3, 1, TILE_64x256, 1, OV_EPI_LINEAR, conv1d_launch<3, 1, 2, 2, 1, 4, 16, true, OV_EPI_LINEAR>},
+    {3, 3, TILE_64x256, 1, OV_EPI_LINEAR, conv1d_launch<3, 3, 2, 2, 1, 4, 16, true, OV_EPI_LINEAR>},
+    {3, 5, TILE_64x256, 1, OV_EPI_LINEAR, conv1d_launch<3, 5, 2, 2, 1, 4, 16, true, OV_EPI_LINEAR>},
+    {7, 1, TILE_64x256, 1, OV_EPI_LINEAR, conv1d_launch<7, 1, 2, 2, 1, 4, 16, true, OV_EPI_LINEAR>},
+    {7, 3, TILE_64x256, 1, OV_EPI_LINEAR, conv1d_launch<7, 3, 2, 2, 1, 4, 16, true, OV_EPI_LINEAR>},
+    {7, 5, TILE_64x256, 1, OV_EPI_LINEAR, conv1d_launch<7, 5, 2, 2, 1, 4, 16, true, OV_EPI_LINEAR>},
+    {11, 1, TILE_64x256, 1, OV_EPI_LINEAR, conv1d_launch<11, 1, 2, 2, 1, 4, 16, true, OV_EPI_LINEAR>},
+    {11, 3, TILE_64x256, 1, OV_EPI_LINEAR, conv1d_launch<11, 3, 2, 2, 1, 4, 16, true, OV_EPI_LINEAR>},
+    {11, 5, TILE_64x256, 1, OV_EPI_LINEAR, conv1d_launch<11, 5, 2, 2, 1, 4, 16, true, OV_EPI_LINEAR>},
+    {3, 1, TILE_64x256, 1, OV_EPI_CONVT, conv1d_launch<3, 1, 2, 2, 1, 4, 16, true, OV_EPI_CONVT>},
 };
 const int kNumVariantsB = sizeof(kVariantsB) / sizeof(kVariantsB[0]);
 #endif

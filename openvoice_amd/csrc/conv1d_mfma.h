@@ -1,17 +1,27 @@
-// Implicit-GEMM Conv1d on the gfx950 fp32 matrix pipe (v_mfma_f32_32x32x2_f32).
+// Implicit-GEMM Conv1d on the gfx950 fp32 matrix pipe (v_mfma_f32_32x32x2_f32), wave-specialised.
 //
 // GEMM view of y[b][co][t] = sum_{ci,j} W[co][ci][j] * act(x[b][ci][t + j*DIL - PAD]):
 //   M = output rows (co), N = time, K_gemm = (ci, tap).
-// One 256-thread workgroup (4 wave64, one per SIMD) owns an M_BLK x N_BLK output tile of one
-// utterance.  Input channels are walked in chunks of CI_CHUNK: the chunk's rows, with the
-// (K-1)*DIL receptive-field halo, are staged ONCE into LDS (leaky-ReLU applied on the way in, so
-// the activation costs one VALU op per staged element instead of one per tap), and every tap of
-// every MFMA B operand is then a conflict-free ds_read_b32 at a compile-time offset.  The A
-// operand (weights) never touches LDS: weights are pre-packed at load time into MFMA fragment
-// order, so a wave fetches the fragments of 4 consecutive k-steps with one coalesced 1 KiB
-// global_load_dwordx4 (L2-resident), prefetched one group ahead in registers.  The staging loads
-// of chunk c+1 are issued before the MFMA loop of chunk c and written to LDS after it
-// (issue-early / write-late), so HBM latency hides under the matrix work.
+//
+// One workgroup = 5 wave64: four MATRIX waves (one per SIMD) that own an M_BLK x N_BLK output tile
+// of one utterance, and one LOADER wave.  Input channels are walked in chunks of CHUNK rows; the
+// loader brings chunk c+1 -- rows with their (K-1)*DIL receptive-field halo, leaky-ReLU applied on
+// the way in, zero-filled outside [0, L) -- from HBM through registers into one half of a
+// double-buffered LDS tile while the matrix waves run the MFMAs of chunk c out of the other half;
+// one s_barrier per chunk hands a buffer over.  Every tap of every MFMA B operand is then a
+// conflict-free ds_read_b32 at a compile-time offset.
+//
+// Why a separate loader wave: the A operand (weights) never touches LDS -- weights are pre-packed at
+// load time into MFMA fragment order, so a wave fetches the fragments of 4 consecutive k-steps with
+// one coalesced 1 KiB global_load_dwordx4 (L2-resident), prefetched one group ahead.  s_waitcnt
+// vmcnt retires loads IN ORDER, so if the same wave also had the HBM staging loads in flight, every
+// wait for an (L2-fast) weight fragment would drain the (HBM-slow) staging loads issued before it
+// and expose the full HBM latency once per chunk; measured on MI355X that cost 25-60 % of the matrix
+// pipe on the k=3 convs.  With the roles split, the matrix waves' vmcnt queue holds weight
+// fragments only.
+//
+// A workgroup walks `tiles_per_wg` consecutive time tiles; the loader runs one chunk ahead across
+// tile boundaries, so only the first tile of a workgroup pays an exposed HBM round trip.
 //
 // fp32 MFMA is bit-exact fmaf-chain arithmetic (no TF32-style truncation on gfx950), so parity
 // with the fp32 reference is limited only by summation order.
@@ -26,270 +36,352 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int CI_CHUNK = 16;         // input channels staged per LDS fill
-constexpr int UNIT = 8;              // input channels per unrolled unit (4 ci-pairs x K taps)
-constexpr int UPC = CI_CHUNK / UNIT; // units per chunk
-constexpr int REC = 256;             // floats per packed-weight record (64 lanes x 4 k-steps)
+constexpr int UNIT = 8;    // input channels per unrolled unit (4 ci-pairs x K taps)
+constexpr int REC = 256;   // floats per packed-weight record (64 lanes x 4 k-steps)
+constexpr int LB = 12;     // loader: 16-byte (or 4-byte) loads kept in flight per lane
 
-__host__ __device__ inline int packed_units(int cin) { return ((cin + UNIT - 1) / UNIT + UPC - 1) / UPC * UPC; }
+// units are padded to a multiple of 4 (the largest units-per-chunk of any kernel variant)
+__host__ __device__ inline int packed_units(int cin) { return ((cin + UNIT - 1) / UNIT + 3) / 4 * 4; }
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
-__device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + __expf(-v)); }
 
-// K taps, dilation DIL; wave tile = (32*WM) x (32*WN); WVM x WVN waves per workgroup;
-// VEC: 16-byte staging loads (needs L % 4 == 0 and 16-byte aligned rows).
-template <int K, int DIL, int WM, int WN, int WVM, int WVN, bool VEC>
-__global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ov_conv1d_params p) {
-  static_assert(WVM * WVN == 4, "4 waves per workgroup");
-  constexpr int N_BLK = 32 * WN * WVN;
-  constexpr int PAD = (K - 1) * DIL / 2;
-  constexpr int PADA = (PAD + 3) / 4 * 4;
-  constexpr int XS = N_BLK + 2 * PADA;  // LDS row stride (floats), multiple of 4
-  constexpr int XS4 = XS / 4;
-  constexpr int NITEM = VEC ? CI_CHUNK * XS4 : CI_CHUNK * XS;
-  constexpr int NV = (NITEM + 255) / 256;
-
-  __shared__ __attribute__((aligned(16))) float xs[CI_CHUNK * XS];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WVN, wn = wave % WVN;
-  const int b = blockIdx.z;
-  const int t0 = blockIdx.x * N_BLK;
-  const int L = p.L, Cin = p.Cin;
-  const float* __restrict__ xb = p.x + (int64_t)b * p.x_bstride;
-  const float slope = p.in_slope;
-
-  const int nunits = packed_units(Cin);
-  const int nchunks = nunits / UPC;
-  const int recs_per_mtile = nunits * K + 1;
-  const int mtile0 = (blockIdx.y * WVM + wm) * WM;
-
-  const f32x4* __restrict__ wq[WM];
-#pragma unroll
-  for (int i = 0; i < WM; ++i)
-    wq[i] = reinterpret_cast<const f32x4*>(p.w) + (int64_t)(mtile0 + i) * recs_per_mtile * 64 + lane;
-
-  f32x16 acc[WM][WN];
-#pragma unroll
-  for (int i = 0; i < WM; ++i)
-#pragma unroll
-    for (int j = 0; j < WN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // ---- staging: global -> registers (early) -> LDS (late) -----------------------------------
-  f32x4 stg4[VEC ? NV : 1];
-  float stg1[VEC ? 1 : NV];
-  auto stage_load = [&](int chunk) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int idx = tid + 256 * i;
-      if constexpr (VEC) {
-        const int row = idx / XS4, c4 = idx - row * XS4;
-        const int ci = chunk * CI_CHUNK + row;
-        const int t = t0 - PADA + 4 * c4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (idx < NITEM && ci < Cin && t >= 0 && t < L)
-          v = *reinterpret_cast<const f32x4*>(xb + (int64_t)ci * L + t);
-        stg4[i] = v;
-      } else {
-        const int row = idx / XS, c = idx - row * XS;
-        const int ci = chunk * CI_CHUNK + row;
-        const int t = t0 - PADA + c;
-        float v = 0.f;
-        if (idx < NITEM && ci < Cin && t >= 0 && t < L) v = xb[(int64_t)ci * L + t];
-        stg1[i] = v;
-      }
-    }
-  };
-  auto stage_write = [&]() {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int idx = tid + 256 * i;
-      if (idx < NITEM) {
-        if constexpr (VEC) {
-          f32x4 v = stg4[i];
-          v[0] = lrelu(v[0], slope); v[1] = lrelu(v[1], slope);
-          v[2] = lrelu(v[2], slope); v[3] = lrelu(v[3], slope);
-          *reinterpret_cast<f32x4*>(xs + 4 * idx) = v;  // row*XS + 4*c4 == 4*idx
-        } else {
-          xs[idx] = lrelu(stg1[i], slope);
-        }
-      }
-    }
-  };
-
-  // per-lane LDS base of the B operand: row (lane>>5) of a ci pair, column n of this wave
-  const float* xl = xs + (lane >> 5) * XS + wn * (32 * WN) + (lane & 31) + (PADA - PAD);
-
-  f32x4 a_cur[WM], a_nxt[WM];
-#pragma unroll
-  for (int i = 0; i < WM; ++i) a_cur[i] = wq[i][0];
-  int rec = 0;
-
-  stage_load(0);
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    __syncthreads();  // every wave finished reading the previous chunk
-    stage_write();
-    __syncthreads();
-    if (chunk + 1 < nchunks) stage_load(chunk + 1);
-#pragma unroll
-    for (int uu = 0; uu < UPC; ++uu) {
-      const float* xu = xl + uu * UNIT * XS;
-#pragma unroll
-      for (int g = 0; g < K; ++g) {
-        ++rec;  // the record after the last real one is zero padding written by the packer
-#pragma unroll
-        for (int i = 0; i < WM; ++i) a_nxt[i] = wq[i][(int64_t)rec * 64];
-        // Pin the prefetch here: without this hipcc sinks the loads next to their first use and
-        // every group starts with an L2-latency stall.
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int s = 4 * g + u;
-          const int pp = s / K, tap = s - pp * K;
-          float bv[WN];
-#pragma unroll
-          for (int j = 0; j < WN; ++j) bv[j] = xu[(2 * pp) * XS + 32 * j + tap * DIL];
-#pragma unroll
-          for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][u], bv[j], acc[i][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < WM; ++i) a_cur[i] = a_nxt[i];
-      }
-    }
-  }
-
-  // ---- epilogue ---------------------------------------------------------------------------
-  // C/D fragment: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-  const int half = lane >> 5;
-  const int epi = p.epi;
+// ---- epilogue: accumulators -> global, shared by every tile shape --------------------------------
+// C/D fragment: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+// Addressing: 64-bit per-utterance base pointers stay scalar; a lane carries ONE 32-bit offset
+// (its column + its half's row offset) and the 16 per-register row offsets are scalar multiples of
+// L, so loads/stores take the saddr + voffset form and nothing 64-bit lives in VGPRs.  The epilogue
+// kind is a template parameter and every optional operand is tested once per 32x32 fragment, never
+// per element, so the element loops are straight-line code with 16 loads in flight.
+template <int EPI, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 (&acc)[WM][WN], int b, int tcol0,
+                                              int mtile0, int q, int lane) {
+  const uint32_t L = (uint32_t)p.L;
+  const uint32_t half = (uint32_t)lane >> 5;
+  const uint32_t Cout = (uint32_t)p.Cout;
   const float scale = p.scale;
   const float* mrow = p.mask ? p.mask + (int64_t)b * L : nullptr;
-  const float* bias = p.bias;
-  const float* bias_b = p.bias_b ? p.bias_b + (int64_t)b * p.bias_b_bstride : nullptr;
+  const float* __restrict__ bias = p.bias;
+  const float* __restrict__ bias_b = p.bias_b ? p.bias_b + (int64_t)b * p.bias_b_bstride : nullptr;
+  float* outb = p.out + (int64_t)b * p.out_bstride;
+  const uint32_t col0 = (uint32_t)tcol0 + ((uint32_t)lane & 31u);
 
-  if (epi == OV_EPI_GATE || epi == OV_EPI_POSTERIOR) {
-    if constexpr (WM == 2) {
-      const int q = blockIdx.y * WVM + wm;  // pair index: packed tiles 2q (tanh | m), 2q+1 (sigmoid | logs)
+  if constexpr (EPI == OV_EPI_GATE || EPI == OV_EPI_POSTERIOR) {
+    static_assert(WM == 2, "gate/posterior pair two 32-row tiles per wave");
+    // q = pair index: packed tiles 2q (tanh | m), 2q+1 (sigmoid | logs)
+    if ((uint32_t)q * 32u >= Cout) return;
+    const float* resb = p.res ? p.res + (int64_t)b * p.res_bstride : nullptr;
 #pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        const int col = t0 + wn * (32 * WN) + 32 * j + (lane & 31);
-        const bool colok = col < L;
-        const float mk = (mrow && colok) ? mrow[col] : 1.f;
+    for (int j = 0; j < WN; ++j) {
+      const uint32_t col = col0 + 32u * j;
+      if (col >= L) continue;
+      const float mk = mrow ? mrow[col] : 1.f;
+      const uint32_t voff = ((uint32_t)q * 32u + 4u * half) * L + col;
+      const uint32_t rbase = (uint32_t)q * 64u + 4u * half;
+      f32x16 v0 = acc[0][j], v1 = acc[1][j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t rr = (r & 3) + 8 * (r >> 2);
+        v0[r] += bias[rbase + rr];
+        v1[r] += bias[rbase + rr + 32u];
+      }
+      if (bias_b) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int rit = (r & 3) + 8 * (r >> 2) + 4 * half;
-          const int ch = q * 32 + rit;
-          const int row0 = q * 64 + rit, row1 = row0 + 32;
-          float v0 = acc[0][j][r], v1 = acc[1][j][r];
-          if (bias) { v0 += bias[row0]; v1 += bias[row1]; }
-          if (bias_b) { v0 += bias_b[row0]; v1 += bias_b[row1]; }
-          if (colok && ch < p.Cout) {
-            const int64_t o = (int64_t)b * p.out_bstride + (int64_t)ch * L + col;
-            if (epi == OV_EPI_GATE) {
-              p.out[o] = tanhf(v0) * (1.f / (1.f + expf(-v1)));
-            } else {
-              const float nz = p.res[(int64_t)b * p.res_bstride + (int64_t)ch * L + col];
-              p.out[o] = (v0 * mk + nz * scale * expf(v1 * mk)) * mk;
-            }
-          }
+          const uint32_t rr = (r & 3) + 8 * (r >> 2);
+          v0[r] += bias_b[rbase + rr];
+          v1[r] += bias_b[rbase + rr + 32u];
+        }
+      }
+      if constexpr (EPI == OV_EPI_GATE) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t rr = (r & 3) + 8 * (r >> 2);
+          (outb + (size_t)rr * L)[voff] = tanhf(v0[r]) * (1.f / (1.f + expf(-v1[r])));
+        }
+      } else {
+        f32x16 nz;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nz[r] = (resb + (size_t)((r & 3) + 8 * (r >> 2)) * L)[voff];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t rr = (r & 3) + 8 * (r >> 2);
+          (outb + (size_t)rr * L)[voff] = (v0[r] * mk + nz[r] * scale * expf(v1[r] * mk)) * mk;
         }
       }
     }
     return;
-  }
-
+  } else {
 #pragma unroll
-  for (int i = 0; i < WM; ++i) {
-    const int mt = mtile0 + i;
+    for (int i = 0; i < WM; ++i) {
+      const uint32_t mt = (uint32_t)(mtile0 + i);
+      // rows are stored in whole 32-row fragments (the dispatcher checks Cout*phase_s % 32 == 0)
+      if (mt * 32u >= (EPI == OV_EPI_CONVT ? Cout * (uint32_t)p.phase_s : Cout)) continue;
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      const int col = t0 + wn * (32 * WN) + 32 * j + (lane & 31);
-      const bool colok = col < L;
-      const float mk = (mrow && colok) ? mrow[col] : 1.f;
-      f32x16 v = acc[i][j];
+      for (int j = 0; j < WN; ++j) {
+        const uint32_t col = col0 + 32u * j;
+        if (col >= L) continue;
+        const float mk = mrow ? mrow[col] : 1.f;
+        const uint32_t rbase = mt * 32u + 4u * half;
+        f32x16 v = acc[i][j];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (bias) v[r] += bias[row];
-        if (bias_b) v[r] += bias_b[row];
-      }
-      if (epi == OV_EPI_CONVT) {
-        const int s = p.phase_s;
-        float* ob = p.out + (int64_t)b * p.out_bstride;
-        const int64_t Lout = (int64_t)L * s;
-        if (s == 8) {
+        for (int r = 0; r < 16; ++r) v[r] += bias[rbase + (r & 3) + 8 * (r >> 2)];
+        if (bias_b) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int co = mt * 4 + c;
-            if (colok && co < p.Cout) {
+          for (int r = 0; r < 16; ++r) v[r] += bias_b[rbase + (r & 3) + 8 * (r >> 2)];
+        }
+        if constexpr (EPI == OV_EPI_CONVT) {
+          const uint32_t s = (uint32_t)p.phase_s;
+          const uint32_t Lout = L * s;
+          if (s == 8) {          // row = co*8 + phase: r&3 walks 4 consecutive output samples
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
               f32x4 o = {v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
-              *reinterpret_cast<f32x4*>(ob + co * Lout + 8 * (int64_t)col + 4 * half) = o;
+              *reinterpret_cast<f32x4*>(outb + (size_t)(mt * 4u + c) * Lout + (8u * col + 4u * half)) = o;
             }
-          }
-        } else if (s == 2) {
+          } else if (s == 2) {   // row = co*2 + phase
 #pragma unroll
-          for (int jj = 0; jj < 8; ++jj) {
-            const int r = 2 * jj;
-            const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int co = row >> 1;
-            if (colok && co < p.Cout) {
+            for (int jj = 0; jj < 8; ++jj) {
+              const int r = 2 * jj;
+              const uint32_t co = (rbase + (r & 3) + 8 * (r >> 2)) >> 1;
               f32x2 o = {v[r], v[r + 1]};
-              *reinterpret_cast<f32x2*>(ob + co * Lout + 2 * (int64_t)col) = o;
+              *reinterpret_cast<f32x2*>(outb + (co * Lout + 2u * col)) = o;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const uint32_t row = rbase + (r & 3) + 8 * (r >> 2);
+              const uint32_t co = row / s, ph = row - co * s;
+              outb[co * Lout + s * col + ph] = v[r];
             }
           }
         } else {
+          const uint32_t voff = rbase * L + col;   // the lane's only per-element offset
+          if constexpr (EPI == OV_EPI_LINEAR) {
+            const float* resb = p.res ? p.res + (int64_t)b * p.res_bstride : nullptr;
+            const float* addb = p.add ? p.add + (int64_t)b * p.add_bstride : nullptr;
+            const float mkv = (p.flags & OV_F_MASK_V) ? mk : 1.f;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int co = row / s, ph = row - co * s;
-            if (colok && co < p.Cout) ob[co * Lout + (int64_t)s * col + ph] = v[r];
-          }
-        }
-        continue;
-      }
+            for (int r = 0; r < 16; ++r) v[r] *= mkv;
+            if (resb) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (!colok || row >= p.Cout) continue;
-        const int64_t o = (int64_t)b * p.out_bstride + (int64_t)row * L + col;
-        float val = v[r];
-        if (epi == OV_EPI_LINEAR) {
-          if (p.flags & OV_F_MASK_V) val *= mk;
-          if (p.res) val += p.res[(int64_t)b * p.res_bstride + (int64_t)row * L + col];
-          if (p.add) val += p.add[(int64_t)b * p.add_bstride + (int64_t)row * L + col];
-          p.out[o] = val * scale;
-        } else if (epi == OV_EPI_RESSKIP) {
-          if (row < p.split) {
-            p.out[o] = (p.out[o] + val) * mk;
-          } else {
-            const int64_t o2 = (int64_t)b * p.out2_bstride + (int64_t)(row - p.split) * L + col;
-            p.out2[o2] = (p.flags & OV_F_OUT2_INIT) ? val : p.out2[o2] + val;
+              for (int r = 0; r < 16; ++r) v[r] += (resb + (size_t)((r & 3) + 8 * (r >> 2)) * L)[voff];
+            }
+            if (addb) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) v[r] += (addb + (size_t)((r & 3) + 8 * (r >> 2)) * L)[voff];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) (outb + (size_t)((r & 3) + 8 * (r >> 2)) * L)[voff] = v[r] * scale;
+          } else if constexpr (EPI == OV_EPI_RESSKIP) {
+            if (mt * 32u < (uint32_t)p.split) {        // residual rows: h = (h + v) * mask, in place
+#pragma unroll
+              for (int r = 0; r < 16; ++r) v[r] += (outb + (size_t)((r & 3) + 8 * (r >> 2)) * L)[voff];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) (outb + (size_t)((r & 3) + 8 * (r >> 2)) * L)[voff] = v[r] * mk;
+            } else {                                   // skip rows: accumulate (or initialise)
+              float* o2 = p.out2 + (int64_t)b * p.out2_bstride;
+              const uint32_t voff2 = voff - (uint32_t)p.split * L;
+              if (!(p.flags & OV_F_OUT2_INIT)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += (o2 + (size_t)((r & 3) + 8 * (r >> 2)) * L)[voff2];
+              }
+#pragma unroll
+              for (int r = 0; r < 16; ++r) (o2 + (size_t)((r & 3) + 8 * (r >> 2)) * L)[voff2] = v[r];
+            }
+          } else {  // OV_EPI_COUPLE: out is x1, in place
+            f32x16 x1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x1[r] = (outb + (size_t)((r & 3) + 8 * (r >> 2)) * L)[voff];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float m = v[r] * mk;
+              (outb + (size_t)((r & 3) + 8 * (r >> 2)) * L)[voff] = scale > 0.f ? m + x1[r] * mk : (x1[r] - m) * mk;
+            }
           }
-        } else {  // OV_EPI_COUPLE
-          const float m = val * mk;
-          const float x1 = p.out[o];
-          p.out[o] = scale > 0.f ? m + x1 * mk : (x1 - m) * mk;
         }
       }
     }
   }
 }
 
+// K taps, dilation DIL; wave tile = (32*WM) x (32*WN); WVM x WVN matrix waves per workgroup;
+// CHUNK input channels per LDS fill; VEC: 16-byte staging loads (needs L % 4 == 0 and 16-byte
+// aligned rows); EPI: epilogue kind (OV_EPI_*).
+template <int K, int DIL, int WM, int WN, int WVM, int WVN, int CHUNK, bool VEC, int EPI>
+__global__ __launch_bounds__(320) void conv1d_mfma_kernel(const ov_conv1d_params p, const int tiles_per_wg) {
+  static_assert(WVM * WVN == 4, "4 matrix waves per workgroup");
+  static_assert(CHUNK % UNIT == 0 && (CHUNK / UNIT == 2 || CHUNK / UNIT == 4), "chunk = 2 or 4 units");
+  constexpr int UPC = CHUNK / UNIT;
+  constexpr int N_BLK = 32 * WN * WVN;
+  constexpr int PAD = (K - 1) * DIL / 2;
+  constexpr int PADA = (PAD + 3) / 4 * 4;
+  constexpr int XS = N_BLK + 2 * PADA;  // LDS row stride (floats), multiple of 4
+  constexpr int XS4 = XS / 4;
+  constexpr int BUF = CHUNK * XS;       // floats per LDS buffer
+  constexpr int NITEM = VEC ? CHUNK * XS4 : CHUNK * XS;
+  constexpr int NBATCH = (NITEM + 64 * LB - 1) / (64 * LB);
+
+  __shared__ __attribute__((aligned(16))) float xs[2 * BUF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z;
+  const int L = p.L, Cin = p.Cin;
+  const int nunits = packed_units(Cin);
+  const int nchunks = nunits / UPC;
+  const int ntiles = (L + N_BLK - 1) / N_BLK;
+  const int tile_begin = blockIdx.x * tiles_per_wg;
+  const int tile_end = min(ntiles, tile_begin + tiles_per_wg);
+
+  if (wave == 4) {
+    // ================================ loader wave ================================================
+    const float* __restrict__ xb = p.x + (int64_t)b * p.x_bstride;
+    const float slope = p.in_slope;
+    int it = 0;
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+      const int t0 = tile * N_BLK;
+      for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
+        float* dst = xs + (it & 1) * BUF;
+#pragma unroll
+        for (int bt = 0; bt < NBATCH; ++bt) {
+          if constexpr (VEC) {
+            f32x4 stg[LB];
+#pragma unroll
+            for (int i = 0; i < LB; ++i) {
+              const int idx = (bt * LB + i) * 64 + lane;
+              const int row = idx / XS4, c4 = idx - row * XS4;
+              const int ci = chunk * CHUNK + row;
+              const int t = t0 - PADA + 4 * c4;
+              const bool ok = idx < NITEM && ci < Cin && t >= 0 && t < L;
+              const uint32_t goff = ok ? (uint32_t)ci * (uint32_t)L + (uint32_t)t : 0u;   // always valid
+              f32x4 v = *reinterpret_cast<const f32x4*>(xb + goff);
+              if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+              stg[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < LB; ++i) {
+              const int idx = (bt * LB + i) * 64 + lane;
+              if (idx < NITEM) {
+                f32x4 v = stg[i];
+                v[0] = lrelu(v[0], slope); v[1] = lrelu(v[1], slope);
+                v[2] = lrelu(v[2], slope); v[3] = lrelu(v[3], slope);
+                *reinterpret_cast<f32x4*>(dst + 4 * idx) = v;  // row*XS + 4*c4 == 4*idx
+              }
+            }
+          } else {
+            float stg[LB];
+#pragma unroll
+            for (int i = 0; i < LB; ++i) {
+              const int idx = (bt * LB + i) * 64 + lane;
+              const int row = idx / XS, c = idx - row * XS;
+              const int ci = chunk * CHUNK + row;
+              const int t = t0 - PADA + c;
+              const bool ok = idx < NITEM && ci < Cin && t >= 0 && t < L;
+              const uint32_t goff = ok ? (uint32_t)ci * (uint32_t)L + (uint32_t)t : 0u;
+              const float v = xb[goff];
+              stg[i] = ok ? v : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < LB; ++i) {
+              const int idx = (bt * LB + i) * 64 + lane;
+              if (idx < NITEM) dst[idx] = lrelu(stg[i], slope);
+            }
+          }
+        }
+        __syncthreads();  // hand buffer (it & 1) to the matrix waves
+      }
+    }
+    return;
+  }
+
+  // ================================== matrix waves ================================================
+  const int wm = wave / WVN, wn = wave % WVN;
+  const int recs_per_mtile = nunits * K + 1;
+  const int mtile0 = (blockIdx.y * WVM + wm) * WM;
+
+  // weight fragments: scalar base + per-lane 32-bit index (in 16-byte units), record stride 64
+  const f32x4* __restrict__ wbase = reinterpret_cast<const f32x4*>(p.w);
+  uint32_t widx[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) widx[i] = (uint32_t)(mtile0 + i) * (uint32_t)recs_per_mtile * 64u + (uint32_t)lane;
+
+  // per-lane LDS offset of the B operand: row (lane>>5) of a ci pair, column n of this wave
+  const int xl_off = (lane >> 5) * XS + wn * (32 * WN) + (lane & 31) + (PADA - PAD);
+
+  f32x4 a_cur[WM], a_nxt[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) a_cur[i] = wbase[widx[i]];
+
+  int it = 0;
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int rec = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
+      __syncthreads();  // loader finished buffer (it & 1); we finished reading the other one
+      const float* xl = xs + (it & 1) * BUF + xl_off;
+#pragma unroll
+      for (int uu = 0; uu < UPC; ++uu) {
+        const float* xu = xl + uu * UNIT * XS;
+#pragma unroll
+        for (int g = 0; g < K; ++g) {
+          ++rec;  // the record after the last real one is zero padding written by the packer
+#pragma unroll
+          for (int i = 0; i < WM; ++i) a_nxt[i] = (wbase + (size_t)rec * 64)[widx[i]];
+          // Pin the prefetch here: without this hipcc sinks the loads next to their first use and
+          // every group starts with an L2-latency stall.
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int s = 4 * g + u;
+            const int pp = s / K, tap = s - pp * K;
+            float bv[WN];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bv[j] = xu[(2 * pp) * XS + 32 * j + tap * DIL];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+              for (int j = 0; j < WN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][u], bv[j], acc[i][j], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < WM; ++i) a_cur[i] = a_nxt[i];
+        }
+      }
+    }
+    // first weight record of the next tile: in flight while the epilogue runs
+    if (tile + 1 < tile_end) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a_cur[i] = wbase[widx[i]];
+    }
+    conv_epilogue<EPI, WM, WN>(p, acc, b, tile * N_BLK + wn * (32 * WN), mtile0, blockIdx.y * WVM + wm, lane);
+  }
+}
+
 typedef int (*conv_launch_fn)(const ov_conv1d_params*, hipStream_t);
 
-template <int K, int DIL, int WM, int WN, int WVM, int WVN, bool VEC>
+template <int K, int DIL, int WM, int WN, int WVM, int WVN, int CHUNK, bool VEC, int EPI>
 int conv1d_launch(const ov_conv1d_params* p, hipStream_t stream) {
   constexpr int M_BLK = 32 * WM * WVM, N_BLK = 32 * WN * WVN;
-  dim3 grid((p->L + N_BLK - 1) / N_BLK, (p->M + M_BLK - 1) / M_BLK, p->B);
-  hipLaunchKernelGGL((conv1d_mfma_kernel<K, DIL, WM, WN, WVM, WVN, VEC>), grid, dim3(256), 0, stream, *p);
+  const int ntiles = (p->L + N_BLK - 1) / N_BLK;
+  const int mblocks = (p->M + M_BLK - 1) / M_BLK;
+  // Keep >= ~8 workgroups per CU-slot in the grid before giving a workgroup several time tiles.
+  const long total = (long)ntiles * mblocks * p->B;
+  int tpw = 1;
+  if (p->tiles_per_wg > 0) tpw = p->tiles_per_wg;
+  else if (total >= 16384) tpw = 4;
+  else if (total >= 8192) tpw = 2;
+  dim3 grid((ntiles + tpw - 1) / tpw, mblocks, p->B);
+  hipLaunchKernelGGL((conv1d_mfma_kernel<K, DIL, WM, WN, WVM, WVN, CHUNK, VEC, EPI>), grid, dim3(320), 0, stream, *p,
+                     tpw);
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
 }
 
@@ -297,7 +389,7 @@ int conv1d_launch(const ov_conv1d_params* p, hipStream_t stream) {
 enum { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x512 = 2 };
 
 struct ConvVariant {
-  int K, dil, tile, vec;
+  int K, dil, tile, vec, epi;
   conv_launch_fn fn;
 };
 
@@ -310,5 +402,7 @@ extern const ConvVariant kVariantsC[];
 extern const int kNumVariantsC;
 extern const ConvVariant kVariantsS[];
 extern const int kNumVariantsS;
+extern const ConvVariant kVariantsW[];
+extern const int kNumVariantsW;
 
 }  // namespace ovk

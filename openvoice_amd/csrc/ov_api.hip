@@ -3,9 +3,11 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include "conv1d_mfma.h"
+#include "conv1d_mfma_v1.h"
 #include "openvoice_amd.h"
 
 namespace ovk {
@@ -96,13 +98,32 @@ __global__ void sequence_mask_kernel(const int64_t* __restrict__ lengths, float*
   if (t < T) mask[(int64_t)b * T + t] = t < lengths[b] ? 1.f : 0.f;
 }
 
-static const ConvVariant* find_variant(int K, int dil, int tile, int vec) {
-  const ConvVariant* tabs[4] = {kVariantsA, kVariantsB, kVariantsC, kVariantsS};
-  const int ns[4] = {kNumVariantsA, kNumVariantsB, kNumVariantsC, kNumVariantsS};
-  for (int t = 0; t < 4; ++t)
+// OV_CONV_IMPL=v1 selects the round-1 single-role kernel for A/B measurements (tools/ only).
+static bool use_v1() {
+  static const int flag = [] {
+    const char* e = std::getenv("OV_CONV_IMPL");
+    return (e && e[0] == 'v' && e[1] == '1') ? 1 : 0;
+  }();
+  return flag != 0;
+}
+
+static conv_launch_fn find_variant(int K, int dil, int tile, int vec, int epi) {
+  if (use_v1()) {
+    const v1::ConvVariant* tabs[4] = {v1::kV1VariantsA, v1::kV1VariantsB, v1::kV1VariantsC, v1::kV1VariantsS};
+    const int ns[4] = {v1::kV1NumVariantsA, v1::kV1NumVariantsB, v1::kV1NumVariantsC, v1::kV1NumVariantsS};
+    for (int t = 0; t < 4; ++t)
+      for (int i = 0; i < ns[t]; ++i) {
+        const v1::ConvVariant& v = tabs[t][i];
+        if (v.K == K && v.dil == dil && v.tile == tile && v.vec == vec) return v.fn;
+      }
+    return nullptr;
+  }
+  const ConvVariant* tabs[5] = {kVariantsA, kVariantsB, kVariantsC, kVariantsS, kVariantsW};
+  const int ns[5] = {kNumVariantsA, kNumVariantsB, kNumVariantsC, kNumVariantsS, kNumVariantsW};
+  for (int t = 0; t < 5; ++t)
     for (int i = 0; i < ns[t]; ++i) {
       const ConvVariant& v = tabs[t][i];
-      if (v.K == K && v.dil == dil && v.tile == tile && v.vec == vec) return &v;
+      if (v.K == K && v.dil == dil && v.tile == tile && v.vec == vec && v.epi == epi) return v.fn;
     }
   return nullptr;
 }
@@ -154,6 +175,11 @@ int ov_conv1d_f32(const ov_conv1d_params* p, ov_stream_t stream) {
   if ((epi == OV_EPI_GATE || epi == OV_EPI_POSTERIOR) && (p->M % 64 != 0)) return OV_E_BADARG;
   if (epi == OV_EPI_POSTERIOR && !p->res) return OV_E_BADARG;
   if (epi == OV_EPI_RESSKIP && (!p->out2 || p->split % 32 != 0)) return OV_E_BADARG;
+  if (!p->bias) return OV_E_BADARG;   // layers without a bias pass a zero vector (M floats)
+  if (epi != OV_EPI_GATE && epi != OV_EPI_POSTERIOR &&
+      ((int64_t)p->Cout * (epi == OV_EPI_CONVT ? p->phase_s : 1)) % 32 != 0)
+    return OV_E_UNSUPPORTED;          // rows are stored in whole 32-row fragments
+  if ((epi == OV_EPI_GATE || epi == OV_EPI_POSTERIOR) && p->Cout % 32 != 0) return OV_E_UNSUPPORTED;
   if (epi == OV_EPI_CONVT) {
     if (p->phase_s <= 0 || 32 % p->phase_s != 0) return OV_E_BADARG;
     if ((reinterpret_cast<uintptr_t>(p->out) & 15) || (p->out_bstride & 3)) return OV_E_ALIGN;
@@ -163,12 +189,12 @@ int ov_conv1d_f32(const ov_conv1d_params* p, ov_stream_t stream) {
   if (p->M <= 32 && epi != OV_EPI_GATE && epi != OV_EPI_POSTERIOR) tile = TILE_32x512;
   else if (p->M <= 64) tile = TILE_64x256;
   const bool can_vec = (p->L % 4 == 0) && !(reinterpret_cast<uintptr_t>(p->x) & 15) && (p->x_bstride % 4 == 0);
-  const ConvVariant* v = nullptr;
-  if (can_vec) v = find_variant(p->K, p->dil, tile, 1);
-  if (!v && can_vec && tile != TILE_128x128) v = find_variant(p->K, p->dil, TILE_128x128, 1);
-  if (!v) v = find_variant(p->K, p->dil, TILE_128x128, 0);
-  if (!v) return OV_E_UNSUPPORTED;
-  return v->fn(p, static_cast<hipStream_t>(stream));
+  conv_launch_fn fn = nullptr;
+  if (can_vec) fn = find_variant(p->K, p->dil, tile, 1, epi);
+  if (!fn && can_vec && tile != TILE_128x128) fn = find_variant(p->K, p->dil, TILE_128x128, 1, epi);
+  if (!fn) fn = find_variant(p->K, p->dil, TILE_128x128, 0, epi);
+  if (!fn) return OV_E_UNSUPPORTED;
+  return fn(p, static_cast<hipStream_t>(stream));
 }
 
 int ov_conv_post_tanh_f32(const float* x, const float* w, float* out, int B, int C, int L, int K,

@@ -5,12 +5,13 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu_info.txt
-echo "== kernel tests" ; timeout 400 python -m pytest tests/test_gpu_kernels.py -q -m gpu -x --timeout 120 2>&1 | tail -25 | tee gpurun_out/test_kernels.log
-echo "== e2e tests" ; timeout 400 python -m pytest tests/test_gpu_e2e.py -q -m gpu -s --timeout 300 2>&1 | tail -25 | tee gpurun_out/test_e2e.log
-echo "== bench" ; timeout 300 python bench.py --steps 3 --warmup 1 2>&1 | tail -5 | tee gpurun_out/bench.log
+(nproc; python -c "import os; print('cpu_count', os.cpu_count(), 'affinity', len(os.sched_getaffinity(0)))"; cat /sys/fs/cgroup/cpu.max 2>/dev/null; lscpu | grep -E "Model name|^CPU\(s\)|Socket") > gpurun_out/host_info.txt 2>&1
+echo "== kernel tests" ; timeout 300 python -m pytest tests/test_gpu_kernels.py -q -m gpu -x --timeout 120 2>&1 | tail -15 | tee gpurun_out/test_kernels.log
+echo "== e2e tests" ; timeout 300 python -m pytest tests/test_gpu_e2e.py -q -m gpu -s --timeout 200 2>&1 | tail -25 | tee gpurun_out/test_e2e.log
+echo "== conv microbench v2" ; timeout 200 python tools/bench_convs.py --tpw 0 1 4 --reps 3 2>&1 | tee gpurun_out/convs_v2.log | tail -3
+echo "== conv microbench v1" ; OV_CONV_IMPL=v1 timeout 200 python tools/bench_convs.py --reps 3 2>&1 | tee gpurun_out/convs_v1.log | tail -3
+echo "== bench" ; timeout 300 python bench.py --steps 3 --warmup 1 --cpu-budget 12 2>&1 | tail -5 | tee gpurun_out/bench.log
 echo "== rocprof" ; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o r1 --output-format csv -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OLDPWD/gpurun_out/rocprof.log" 2>&1)
-tail -3 gpurun_out/rocprof.log
-find gpurun_out/prof -name '*stats*' | head; f=$(find gpurun_out/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -30 "$f"
-# keep the merged-back payload small: the per-dispatch trace can be tens of MB
+grep '"metric"' gpurun_out/rocprof.log | cut -c1-400
+f=$(find gpurun_out/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -12 "$f"
 find gpurun_out/prof -name '*kernel_trace.csv' -size +20M -delete

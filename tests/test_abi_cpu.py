@@ -54,7 +54,7 @@ def test_weight_packer_layout(cout, cin, k):
     assert lib.ov_conv1d_pack_f32(w.data_ptr(), cout, cin, k, dst.data_ptr()) == 0
     rows = lib.ov_conv1d_pack_rows(cout)
     assert rows % 128 == 0 and rows >= cout
-    nu = ((cin + 7) // 8 + 1) // 2 * 2
+    nu = ((cin + 7) // 8 + 3) // 4 * 4       # units padded to the largest units-per-chunk
     recs = nu * k + 1
     assert n == rows // 32 * recs * 256
     got = dst.numpy().reshape(rows // 32, recs, 64, 4)

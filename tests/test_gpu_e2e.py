@@ -9,6 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from openvoice_amd.hostinfo import usable_cpus  # noqa: E402
 from openvoice_amd.models import SynthesizerTrn  # noqa: E402
 from openvoice_amd.utils import CONVERTER_MODEL_CONFIG  # noqa: E402
 
@@ -53,7 +54,7 @@ def test_voice_conversion_matches_oracle(synth_sd, B, T, zero_g, per_item):
     g_src, g_tgt = 0.3 * torch.randn(gshape, generator=gen), 0.3 * torch.randn(gshape, generator=gen)
     noise = torch.randn(B, 192, T, generator=gen)
     lengths = torch.tensor([max(1, T - 7 * b) for b in range(B)], dtype=torch.long)
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(usable_cpus(32))
     with torch.no_grad():
         o_ref, mask_ref, (z_r, zp_r, zh_r) = vc_oracle.voice_conversion(
             synth_sd, CONVERTER_MODEL_CONFIG, spec, lengths, g_src, g_tgt, 0.3, noise, zero_g=zero_g)

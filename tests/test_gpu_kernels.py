@@ -50,6 +50,37 @@ def test_resblock_conv_shapes(c, k, d):
     _close(out, ref, what=f"C={c} k={k} d={d}")
 
 
+@pytest.mark.parametrize("c,k,d,L,tpw", [(32, 3, 1, 2312, 2), (32, 11, 5, 2312, 4), (64, 7, 3, 2056, 3),
+                                         (128, 3, 5, 1096, 4), (256, 11, 1, 520, 2), (128, 7, 1, 1096, 16)])
+def test_resblock_conv_several_tiles_per_workgroup(c, k, d, L, tpw):
+    """The loader wave runs one chunk ahead across time-tile boundaries when a workgroup walks
+    several tiles (the launcher does this by itself only for grids of >= 8192 tiles): tile counts
+    that do not divide evenly, last tile ragged, more tiles per workgroup than exist."""
+    B = 2
+    x, res, add = _rand(B, c, L, seed=1), _rand(B, c, L, seed=2), _rand(B, c, L, seed=9)
+    w, bias = _rand(c, c, k, seed=3, scale=(c * k) ** -0.5), _rand(c, seed=4, scale=0.1)
+    ref = (F.conv1d(F.leaky_relu(x, 0.1), w, bias, dilation=d, padding=(k - 1) * d // 2) + res + add) / 3.0
+    layer = PackedConv(w, bias, DEV, K=k, dil=d)
+    out = torch.full((B, c, L), float("nan"), device=DEV)
+    launch_conv(layer, x.to(DEV), 0, c * L, out, 0, c * L, B, L, in_slope=0.1, res=res.to(DEV), res_bs=c * L,
+                add=add.to(DEV), add_bs=c * L, scale=1.0 / 3.0, tiles_per_wg=tpw)
+    _close(out, ref, what=f"C={c} k={k} d={d} tpw={tpw}")
+
+
+def test_wavenet_gate_several_tiles_per_workgroup():
+    B, H, T = 2, 192, 700
+    x, g = _rand(B, H, T, seed=1), _rand(B, 2 * H, seed=2, scale=0.3)
+    w_in, b_in = _rand(2 * H, H, 5, seed=3, scale=(5 * H) ** -0.5), _rand(2 * H, seed=4, scale=0.1)
+    x_in = F.conv1d(x, w_in, b_in, padding=2) + g[:, :, None]
+    acts = torch.tanh(x_in[:, :H]) * torch.sigmoid(x_in[:, H:])
+    order = gate_row_order(H)
+    l_in = PackedConv(w_in[order], b_in[order], DEV, K=5, cout=H)
+    actsd = torch.full((B, H, T), float("nan"), device=DEV)
+    launch_conv(l_in, x.to(DEV), 0, H * T, actsd, 0, H * T, B, T, epi=EPI_GATE, bias_b=g[:, order].contiguous().to(DEV),
+                bias_b_bs=2 * H, rows=2 * H, tiles_per_wg=3)
+    _close(actsd, acts, what="gate tpw=3")
+
+
 @pytest.mark.parametrize("cin,cout,k,L", [(513, 192, 1, 861), (192, 512, 7, 861), (96, 192, 1, 65),
                                           (192, 96, 1, 17), (192, 384, 1, 1), (192, 512, 7, 864)])
 def test_frame_rate_convs_unaligned_and_aligned(cin, cout, k, L):
