@@ -15,3 +15,7 @@ echo "== rocprof" ; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d 
 grep '"metric"' gpurun_out/rocprof.log | cut -c1-400
 f=$(find gpurun_out/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -12 "$f"
 find gpurun_out/prof -name '*kernel_trace.csv' -size +20M -delete
+echo "== pmc fetch" ; (cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OLDPWD/gpurun_out/pmc_fetch" -o r1 --output-format csv -- python "$OLDPWD/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$OLDPWD/gpurun_out/pmc_fetch.log" 2>&1)
+echo "== pmc write" ; (cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OLDPWD/gpurun_out/pmc_write" -o r1 --output-format csv -- python "$OLDPWD/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$OLDPWD/gpurun_out/pmc_write.log" 2>&1)
+python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write > gpurun_out/pmc_summary.txt 2>&1; tail -30 gpurun_out/pmc_summary.txt
+find gpurun_out -name '*kernel_trace.csv' -size +20M -delete
