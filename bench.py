@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0, help="utterance length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--pmc-calibration", action="store_true",
+                    help="after the timed region, run three 1 GiB device-to-device copies (a known byte count) "
+                         "so a rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass can be calibrated")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -161,6 +164,14 @@ def main():
     achieved = f_mrf / t_mrf / 1e12
     all_flops = sum(r[1] for r in by_tag.values())
     all_conv_s = sum(r[2] for r in by_tag.values())
+
+    if args.pmc_calibration:
+        src = torch.zeros(1 << 28, dtype=torch.float32, device=dev)   # 1 GiB
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        del src, dst
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3

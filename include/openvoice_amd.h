@@ -66,7 +66,10 @@ enum {
 };
 
 /* One Conv1d launch.  Input length == output length L ('same' padding, stride 1), as every conv
- * on the converter path (reference: openvoice/modules.py:163-171, :228-283, models.py:238,266). */
+ * on the converter path (reference: openvoice/modules.py:163-171, :228-283, models.py:238,266).
+ * Rows may be padded: x rows are x_ld floats apart, out/res/add/out2 rows out_ld floats apart (both
+ * >= L; columns >= L are never read as data and never written).  16-byte staging loads are used
+ * when x, x_bstride and x_ld are 16-byte aligned -- L itself may be ragged. */
 typedef struct ov_conv1d_params {
   const float* x;        /* [B][>=Cin][L]; channel offset already applied to the pointer        */
   const float* w;        /* packed weights from ov_conv1d_pack_f32                              */
@@ -76,19 +79,25 @@ typedef struct ov_conv1d_params {
   const float* res;      /* LINEAR: residual; POSTERIOR: noise; indexed like out; or NULL       */
   const float* add;      /* LINEAR: second addend (MRF running sum), indexed like out; or NULL  */
   float* out2;           /* RESSKIP: skip accumulator [b][row-split][t]                         */
-  const float* mask;     /* [B][L] sequence mask (1/0), or NULL                                 */
+  const float* mask;     /* [B][>=L] sequence mask (1/0), rows mask_bstride apart, or NULL      */
   int64_t x_bstride;     /* elements between consecutive batches of x                           */
   int64_t out_bstride;
   int64_t res_bstride;
   int64_t add_bstride;
   int64_t out2_bstride;
   int64_t bias_b_bstride;/* 0 broadcasts one row to every batch item                            */
+  int64_t mask_bstride;  /* 0 = L                                                               */
   int32_t B, Cin, L;
+  int32_t x_ld;          /* row stride of x in floats; 0 = L                                    */
+  int32_t out_ld;        /* row stride of out/res/add/out2; 0 = L (CONVT: L * phase_s)          */
   int32_t M;             /* packed rows = 32 * m_tiles, as passed to ov_conv1d_pack_f32          */
   int32_t Cout;          /* rows >= Cout (LINEAR/COUPLE/RESSKIP) are padding and never stored    */
   int32_t K, dil;        /* taps, dilation; padding is (K-1)*dil/2                               */
   int32_t epi, flags, split, phase_s;
-  int32_t tiles_per_wg;  /* consecutive time tiles walked by one workgroup; 0 = chosen by the launcher */
+  int32_t tiles_per_wg;  /* consecutive time tiles walked by one workgroup; 0 = 1                */
+  int32_t tile;          /* 0 = chosen by the dispatcher; else 1 + tile id (128x128, 64x256,
+                          * 32x512, 32x256) -- tuning / measurement knob                         */
+  int32_t loaders;       /* loader waves per workgroup: 0 = chosen by the dispatcher, else 1/2/4 */
   float in_slope;        /* leaky-ReLU slope applied to x while staging (1.0f = identity)        */
   float scale;
 } ov_conv1d_params;
@@ -124,8 +133,9 @@ int ov_conv_post_tanh_f32(const float* x, const float* w, float* out, int B, int
 int ov_linear_f32(const float* x, const float* w, const float* bias, float* y, int B, int M, int Kdim,
                   ov_stream_t stream);
 
-/* mask[b][t] = t < lengths[b] ? 1 : 0, reference openvoice/commons.py:121-125. */
-int ov_sequence_mask_f32(const int64_t* lengths, float* mask, int B, int T, ov_stream_t stream);
+/* mask[b][t] = t < lengths[b] ? 1 : 0 for t < T, reference openvoice/commons.py:121-125.
+ * Rows of mask are ld floats apart (0 = T); columns >= T are not written. */
+int ov_sequence_mask_f32(const int64_t* lengths, float* mask, int B, int T, int ld, ov_stream_t stream);
 
 /* ---- ReferenceEncoder (extract_se), reference openvoice/models.py:339-359 -----------------------
  * Layout: time is the contiguous axis everywhere, [N][C][F][T]; the spectrogram [N][F][T] is the

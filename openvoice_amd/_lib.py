@@ -27,10 +27,12 @@ class ConvParams(ctypes.Structure):
         ("add", _fp), ("out2", _fp), ("mask", _fp),
         ("x_bstride", ctypes.c_int64), ("out_bstride", ctypes.c_int64), ("res_bstride", ctypes.c_int64),
         ("add_bstride", ctypes.c_int64), ("out2_bstride", ctypes.c_int64), ("bias_b_bstride", ctypes.c_int64),
-        ("B", ctypes.c_int32), ("Cin", ctypes.c_int32), ("L", ctypes.c_int32), ("M", ctypes.c_int32),
+        ("mask_bstride", ctypes.c_int64),
+        ("B", ctypes.c_int32), ("Cin", ctypes.c_int32), ("L", ctypes.c_int32),
+        ("x_ld", ctypes.c_int32), ("out_ld", ctypes.c_int32), ("M", ctypes.c_int32),
         ("Cout", ctypes.c_int32), ("K", ctypes.c_int32), ("dil", ctypes.c_int32), ("epi", ctypes.c_int32),
         ("flags", ctypes.c_int32), ("split", ctypes.c_int32), ("phase_s", ctypes.c_int32),
-        ("tiles_per_wg", ctypes.c_int32),
+        ("tiles_per_wg", ctypes.c_int32), ("tile", ctypes.c_int32), ("loaders", ctypes.c_int32),
         ("in_slope", ctypes.c_float), ("scale", ctypes.c_float),
     ]
 
@@ -45,7 +47,7 @@ SIGNATURES = {
     "ov_conv_post_tanh_f32": (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_float, _fp]),
     "ov_linear_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
-    "ov_sequence_mask_f32": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, _fp]),
+    "ov_sequence_mask_f32": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
     "ov_layernorm_freq_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_float, _fp]),
     "ov_conv2d_s2_relu_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -1,0 +1,15 @@
+// Tile 32x512: MRF stage 3 (C = 32); 4 loader waves.
+#include "conv1d_mfma.h"
+namespace ovk {
+#define LIST(X) \
+  X(3, 1, 32x512, 16, 1, OV_EPI_LINEAR, 4) \
+  X(3, 3, 32x512, 16, 1, OV_EPI_LINEAR, 4) \
+  X(3, 5, 32x512, 16, 1, OV_EPI_LINEAR, 4) \
+  X(7, 1, 32x512, 16, 1, OV_EPI_LINEAR, 4) \
+  X(7, 3, 32x512, 16, 1, OV_EPI_LINEAR, 4) \
+  X(7, 5, 32x512, 16, 1, OV_EPI_LINEAR, 4) \
+  X(11, 1, 32x512, 16, 1, OV_EPI_LINEAR, 4) \
+  X(11, 3, 32x512, 16, 1, OV_EPI_LINEAR, 4) \
+  X(11, 5, 32x512, 16, 1, OV_EPI_LINEAR, 4)
+OV_DEFINE_VARIANTS(kVariantsC2, LIST)
+}  // namespace ovk

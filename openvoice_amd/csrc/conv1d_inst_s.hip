@@ -1,21 +1,18 @@
-// Tile 128x128, 4-byte staging for rows that are not 16-byte aligned (frame-rate tensors with
-// T % 4 != 0: 1x1 convs, conv_pre k7, ups.0 as a 3-tap conv).
+// Frame-rate and upsampling layers: 1x1 / k3 / k5 / k7 LINEAR and the 3-tap phase form of
+// ConvTranspose1d (CONVT), 16-byte staging and the 4-byte fallback for unaligned rows.
 #include "conv1d_mfma.h"
 namespace ovk {
-// explicit kernel instantiations (both host and device passes see these)
-template __global__ void conv1d_mfma_kernel<1, 1, 2, 2, 2, 2, 32, false, OV_EPI_LINEAR>(const ov_conv1d_params, const int);
-template __global__ void conv1d_mfma_kernel<3, 1, 2, 2, 2, 2, 16, false, OV_EPI_LINEAR>(const ov_conv1d_params, const int);
-template __global__ void conv1d_mfma_kernel<5, 1, 2, 2, 2, 2, 16, false, OV_EPI_LINEAR>(const ov_conv1d_params, const int);
-template __global__ void conv1d_mfma_kernel<7, 1, 2, 2, 2, 2, 16, false, OV_EPI_LINEAR>(const ov_conv1d_params, const int);
-template __global__ void conv1d_mfma_kernel<3, 1, 2, 2, 2, 2, 16, false, OV_EPI_CONVT>(const ov_conv1d_params, const int);
-#if !defined(__HIP_DEVICE_COMPILE__)
-const ConvVariant kVariantsS[] = {
-    {1, 1, TILE_128x128, 0, OV_EPI_LINEAR, conv1d_launch<1, 1, 2, 2, 2, 2, 32, false, OV_EPI_LINEAR>},
-    {3, 1, TILE_128x128, 0, OV_EPI_LINEAR, conv1d_launch<3, 1, 2, 2, 2, 2, 16, false, OV_EPI_LINEAR>},
-    {5, 1, TILE_128x128, 0, OV_EPI_LINEAR, conv1d_launch<5, 1, 2, 2, 2, 2, 16, false, OV_EPI_LINEAR>},
-    {7, 1, TILE_128x128, 0, OV_EPI_LINEAR, conv1d_launch<7, 1, 2, 2, 2, 2, 16, false, OV_EPI_LINEAR>},
-    {3, 1, TILE_128x128, 0, OV_EPI_CONVT, conv1d_launch<3, 1, 2, 2, 2, 2, 16, false, OV_EPI_CONVT>},
-};
-const int kNumVariantsS = sizeof(kVariantsS) / sizeof(kVariantsS[0]);
-#endif
+#define LIST(X) \
+  X(1, 1, 128x128, 32, 1, OV_EPI_LINEAR, 2) \
+  X(1, 1, 128x128, 32, 1, OV_EPI_LINEAR, 4) \
+  X(5, 1, 128x128, 16, 1, OV_EPI_LINEAR, 2) \
+  X(3, 1, 128x128, 16, 1, OV_EPI_CONVT, 2) \
+  X(1, 1, 128x128, 32, 0, OV_EPI_LINEAR, 2) \
+  X(1, 1, 128x128, 32, 0, OV_EPI_LINEAR, 4) \
+  X(3, 1, 128x128, 16, 0, OV_EPI_LINEAR, 2) \
+  X(5, 1, 128x128, 16, 0, OV_EPI_LINEAR, 2) \
+  X(7, 1, 128x128, 16, 0, OV_EPI_LINEAR, 2) \
+  X(3, 1, 128x128, 16, 0, OV_EPI_CONVT, 2) \
+  X(3, 1, 64x256, 16, 1, OV_EPI_CONVT, 2)
+OV_DEFINE_VARIANTS(kVariantsS, LIST)
 }  // namespace ovk

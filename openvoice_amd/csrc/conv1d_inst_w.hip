@@ -1,26 +1,24 @@
 // Tile 128x128, WaveNet / coupling / posterior epilogues (16-byte and 4-byte staging).
 #include "conv1d_mfma.h"
 namespace ovk {
-// explicit kernel instantiations (both host and device passes see these)
-template __global__ void conv1d_mfma_kernel<5, 1, 2, 2, 2, 2, 16, true, OV_EPI_GATE>(const ov_conv1d_params, const int);
-template __global__ void conv1d_mfma_kernel<5, 1, 2, 2, 2, 2, 16, false, OV_EPI_GATE>(const ov_conv1d_params, const int);
-template __global__ void conv1d_mfma_kernel<1, 1, 2, 2, 2, 2, 32, true, OV_EPI_RESSKIP>(const ov_conv1d_params, const int);
-template __global__ void conv1d_mfma_kernel<1, 1, 2, 2, 2, 2, 32, false, OV_EPI_RESSKIP>(const ov_conv1d_params, const int);
-template __global__ void conv1d_mfma_kernel<1, 1, 2, 2, 2, 2, 32, true, OV_EPI_COUPLE>(const ov_conv1d_params, const int);
-template __global__ void conv1d_mfma_kernel<1, 1, 2, 2, 2, 2, 32, false, OV_EPI_COUPLE>(const ov_conv1d_params, const int);
-template __global__ void conv1d_mfma_kernel<1, 1, 2, 2, 2, 2, 32, true, OV_EPI_POSTERIOR>(const ov_conv1d_params, const int);
-template __global__ void conv1d_mfma_kernel<1, 1, 2, 2, 2, 2, 32, false, OV_EPI_POSTERIOR>(const ov_conv1d_params, const int);
-#if !defined(__HIP_DEVICE_COMPILE__)
-const ConvVariant kVariantsW[] = {
-    {5, 1, TILE_128x128, 1, OV_EPI_GATE, conv1d_launch<5, 1, 2, 2, 2, 2, 16, true, OV_EPI_GATE>},
-    {5, 1, TILE_128x128, 0, OV_EPI_GATE, conv1d_launch<5, 1, 2, 2, 2, 2, 16, false, OV_EPI_GATE>},
-    {1, 1, TILE_128x128, 1, OV_EPI_RESSKIP, conv1d_launch<1, 1, 2, 2, 2, 2, 32, true, OV_EPI_RESSKIP>},
-    {1, 1, TILE_128x128, 0, OV_EPI_RESSKIP, conv1d_launch<1, 1, 2, 2, 2, 2, 32, false, OV_EPI_RESSKIP>},
-    {1, 1, TILE_128x128, 1, OV_EPI_COUPLE, conv1d_launch<1, 1, 2, 2, 2, 2, 32, true, OV_EPI_COUPLE>},
-    {1, 1, TILE_128x128, 0, OV_EPI_COUPLE, conv1d_launch<1, 1, 2, 2, 2, 2, 32, false, OV_EPI_COUPLE>},
-    {1, 1, TILE_128x128, 1, OV_EPI_POSTERIOR, conv1d_launch<1, 1, 2, 2, 2, 2, 32, true, OV_EPI_POSTERIOR>},
-    {1, 1, TILE_128x128, 0, OV_EPI_POSTERIOR, conv1d_launch<1, 1, 2, 2, 2, 2, 32, false, OV_EPI_POSTERIOR>},
-};
-const int kNumVariantsW = sizeof(kVariantsW) / sizeof(kVariantsW[0]);
-#endif
+#define LIST(X) \
+  X(5, 1, 128x128, 16, 1, OV_EPI_GATE, 1) \
+  X(5, 1, 128x128, 16, 1, OV_EPI_GATE, 2) \
+  X(5, 1, 128x128, 16, 1, OV_EPI_GATE, 4) \
+  X(1, 1, 128x128, 32, 1, OV_EPI_RESSKIP, 2) \
+  X(1, 1, 128x128, 32, 1, OV_EPI_RESSKIP, 4) \
+  X(1, 1, 128x128, 32, 1, OV_EPI_COUPLE, 2) \
+  X(1, 1, 128x128, 32, 1, OV_EPI_COUPLE, 4) \
+  X(1, 1, 128x128, 32, 1, OV_EPI_POSTERIOR, 2) \
+  X(1, 1, 128x128, 32, 1, OV_EPI_POSTERIOR, 4) \
+  X(5, 1, 128x128, 16, 0, OV_EPI_GATE, 1) \
+  X(5, 1, 128x128, 16, 0, OV_EPI_GATE, 2) \
+  X(5, 1, 128x128, 16, 0, OV_EPI_GATE, 4) \
+  X(1, 1, 128x128, 32, 0, OV_EPI_RESSKIP, 2) \
+  X(1, 1, 128x128, 32, 0, OV_EPI_RESSKIP, 4) \
+  X(1, 1, 128x128, 32, 0, OV_EPI_COUPLE, 2) \
+  X(1, 1, 128x128, 32, 0, OV_EPI_COUPLE, 4) \
+  X(1, 1, 128x128, 32, 0, OV_EPI_POSTERIOR, 2) \
+  X(1, 1, 128x128, 32, 0, OV_EPI_POSTERIOR, 4)
+OV_DEFINE_VARIANTS(kVariantsW, LIST)
 }  // namespace ovk

@@ -55,11 +55,12 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? 
 template <int EPI, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 (&acc)[WM][WN], int b, int tcol0,
                                               int mtile0, int q, int lane) {
-  const uint32_t L = (uint32_t)p.L;
+  const uint32_t L = (uint32_t)p.L;        // valid columns
+  const uint32_t LD = (uint32_t)p.out_ld;  // row stride of out / res / add / out2
   const uint32_t half = (uint32_t)lane >> 5;
   const uint32_t Cout = (uint32_t)p.Cout;
   const float scale = p.scale;
-  const float* mrow = p.mask ? p.mask + (int64_t)b * L : nullptr;
+  const float* mrow = p.mask ? p.mask + (int64_t)b * p.mask_bstride : nullptr;
   const float* __restrict__ bias = p.bias;
   const float* __restrict__ bias_b = p.bias_b ? p.bias_b + (int64_t)b * p.bias_b_bstride : nullptr;
   float* outb = p.out + (int64_t)b * p.out_bstride;
@@ -75,7 +76,7 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
       const uint32_t col = col0 + 32u * j;
       if (col >= L) continue;
       const float mk = mrow ? mrow[col] : 1.f;
-      const uint32_t voff = ((uint32_t)q * 32u + 4u * half) * L + col;
+      const uint32_t voff = ((uint32_t)q * 32u + 4u * half) * LD + col;
       const uint32_t rbase = (uint32_t)q * 64u + 4u * half;
       f32x16 v0 = acc[0][j], v1 = acc[1][j];
 #pragma unroll
@@ -96,16 +97,16 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const uint32_t rr = (r & 3) + 8 * (r >> 2);
-          (outb + (size_t)rr * L)[voff] = tanhf(v0[r]) * (1.f / (1.f + expf(-v1[r])));
+          (outb + (size_t)rr * LD)[voff] = tanhf(v0[r]) * (1.f / (1.f + expf(-v1[r])));
         }
       } else {
         f32x16 nz;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) nz[r] = (resb + (size_t)((r & 3) + 8 * (r >> 2)) * L)[voff];
+        for (int r = 0; r < 16; ++r) nz[r] = (resb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const uint32_t rr = (r & 3) + 8 * (r >> 2);
-          (outb + (size_t)rr * L)[voff] = (v0[r] * mk + nz[r] * scale * expf(v1[r] * mk)) * mk;
+          (outb + (size_t)rr * LD)[voff] = (v0[r] * mk + nz[r] * scale * expf(v1[r] * mk)) * mk;
         }
       }
     }
@@ -131,7 +132,7 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
         }
         if constexpr (EPI == OV_EPI_CONVT) {
           const uint32_t s = (uint32_t)p.phase_s;
-          const uint32_t Lout = L * s;
+          const uint32_t Lout = LD;   // row stride of the upsampled output (>= L * s)
           if (s == 8) {          // row = co*8 + phase: r&3 walks 4 consecutive output samples
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -155,7 +156,7 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
             }
           }
         } else {
-          const uint32_t voff = rbase * L + col;   // the lane's only per-element offset
+          const uint32_t voff = rbase * LD + col;   // the lane's only per-element offset
           if constexpr (EPI == OV_EPI_LINEAR) {
             const float* resb = p.res ? p.res + (int64_t)b * p.res_bstride : nullptr;
             const float* addb = p.add ? p.add + (int64_t)b * p.add_bstride : nullptr;
@@ -164,38 +165,38 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
             for (int r = 0; r < 16; ++r) v[r] *= mkv;
             if (resb) {
 #pragma unroll
-              for (int r = 0; r < 16; ++r) v[r] += (resb + (size_t)((r & 3) + 8 * (r >> 2)) * L)[voff];
+              for (int r = 0; r < 16; ++r) v[r] += (resb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff];
             }
             if (addb) {
 #pragma unroll
-              for (int r = 0; r < 16; ++r) v[r] += (addb + (size_t)((r & 3) + 8 * (r >> 2)) * L)[voff];
+              for (int r = 0; r < 16; ++r) v[r] += (addb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff];
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) (outb + (size_t)((r & 3) + 8 * (r >> 2)) * L)[voff] = v[r] * scale;
+            for (int r = 0; r < 16; ++r) (outb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff] = v[r] * scale;
           } else if constexpr (EPI == OV_EPI_RESSKIP) {
             if (mt * 32u < (uint32_t)p.split) {        // residual rows: h = (h + v) * mask, in place
 #pragma unroll
-              for (int r = 0; r < 16; ++r) v[r] += (outb + (size_t)((r & 3) + 8 * (r >> 2)) * L)[voff];
+              for (int r = 0; r < 16; ++r) v[r] += (outb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff];
 #pragma unroll
-              for (int r = 0; r < 16; ++r) (outb + (size_t)((r & 3) + 8 * (r >> 2)) * L)[voff] = v[r] * mk;
+              for (int r = 0; r < 16; ++r) (outb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff] = v[r] * mk;
             } else {                                   // skip rows: accumulate (or initialise)
               float* o2 = p.out2 + (int64_t)b * p.out2_bstride;
-              const uint32_t voff2 = voff - (uint32_t)p.split * L;
+              const uint32_t voff2 = voff - (uint32_t)p.split * LD;
               if (!(p.flags & OV_F_OUT2_INIT)) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] += (o2 + (size_t)((r & 3) + 8 * (r >> 2)) * L)[voff2];
+                for (int r = 0; r < 16; ++r) v[r] += (o2 + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff2];
               }
 #pragma unroll
-              for (int r = 0; r < 16; ++r) (o2 + (size_t)((r & 3) + 8 * (r >> 2)) * L)[voff2] = v[r];
+              for (int r = 0; r < 16; ++r) (o2 + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff2] = v[r];
             }
           } else {  // OV_EPI_COUPLE: out is x1, in place
             f32x16 x1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) x1[r] = (outb + (size_t)((r & 3) + 8 * (r >> 2)) * L)[voff];
+            for (int r = 0; r < 16; ++r) x1[r] = (outb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const float m = v[r] * mk;
-              (outb + (size_t)((r & 3) + 8 * (r >> 2)) * L)[voff] = scale > 0.f ? m + x1[r] * mk : (x1[r] - m) * mk;
+              (outb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff] = scale > 0.f ? m + x1[r] * mk : (x1[r] - m) * mk;
             }
           }
         }
@@ -205,10 +206,12 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
 }
 
 // K taps, dilation DIL; wave tile = (32*WM) x (32*WN); WVM x WVN matrix waves per workgroup;
-// CHUNK input channels per LDS fill; VEC: 16-byte staging loads (needs L % 4 == 0 and 16-byte
-// aligned rows); EPI: epilogue kind (OV_EPI_*).
-template <int K, int DIL, int WM, int WN, int WVM, int WVN, int CHUNK, bool VEC, int EPI>
-__global__ __launch_bounds__(320) void conv1d_mfma_kernel(const ov_conv1d_params p, const int tiles_per_wg) {
+// CHUNK input channels per LDS fill; VEC: 16-byte staging loads (needs x_ld % 4 == 0 and 16-byte
+// aligned rows; L itself may be ragged); EPI: epilogue kind (OV_EPI_*); NLD: loader waves (the
+// staging items of a chunk are dealt round-robin to them, so NLD x LB x 64 loads are in flight).
+template <int K, int DIL, int WM, int WN, int WVM, int WVN, int CHUNK, bool VEC, int EPI, int NLD>
+__global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_mfma_kernel(const ov_conv1d_params p,
+                                                                     const int tiles_per_wg) {
   static_assert(WVM * WVN == 4, "4 matrix waves per workgroup");
   static_assert(CHUNK % UNIT == 0 && (CHUNK / UNIT == 2 || CHUNK / UNIT == 4), "chunk = 2 or 4 units");
   constexpr int UPC = CHUNK / UNIT;
@@ -219,7 +222,8 @@ __global__ __launch_bounds__(320) void conv1d_mfma_kernel(const ov_conv1d_params
   constexpr int XS4 = XS / 4;
   constexpr int BUF = CHUNK * XS;       // floats per LDS buffer
   constexpr int NITEM = VEC ? CHUNK * XS4 : CHUNK * XS;
-  constexpr int NBATCH = (NITEM + 64 * LB - 1) / (64 * LB);
+  constexpr int NBATCH = (NITEM + 64 * NLD * LB - 1) / (64 * NLD * LB);
+  static_assert(NLD == 1 || NLD == 2 || NLD == 4, "1, 2 or 4 loader waves");
 
   __shared__ __attribute__((aligned(16))) float xs[2 * BUF];
 
@@ -234,58 +238,65 @@ __global__ __launch_bounds__(320) void conv1d_mfma_kernel(const ov_conv1d_params
   const int tile_begin = blockIdx.x * tiles_per_wg;
   const int tile_end = min(ntiles, tile_begin + tiles_per_wg);
 
-  if (wave == 4) {
-    // ================================ loader wave ================================================
+  if (wave >= 4) {
+    // ================================ loader waves ===============================================
     const float* __restrict__ xb = p.x + (int64_t)b * p.x_bstride;
     const float slope = p.in_slope;
+    const uint32_t ldx = (uint32_t)p.x_ld;
+    const int llane = (wave - 4) * 64 + lane;   // position among the NLD * 64 loader lanes
     int it = 0;
     for (int tile = tile_begin; tile < tile_end; ++tile) {
       const int t0 = tile * N_BLK;
       for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
         float* dst = xs + (it & 1) * BUF;
-#pragma unroll
+#pragma unroll 1   // one batch of LB loads per lane in flight at a time: bounds the loader's VGPRs
         for (int bt = 0; bt < NBATCH; ++bt) {
           if constexpr (VEC) {
             f32x4 stg[LB];
+            int nval[LB];   // valid leading elements of each vector (0 = zero fill); a VGPR count,
+                            // not lane masks, so nothing mask-shaped stays live across the loads
 #pragma unroll
             for (int i = 0; i < LB; ++i) {
-              const int idx = (bt * LB + i) * 64 + lane;
+              const int idx = (bt * LB + i) * (64 * NLD) + llane;
               const int row = idx / XS4, c4 = idx - row * XS4;
               const int ci = chunk * CHUNK + row;
-              const int t = t0 - PADA + 4 * c4;
+              const int t = t0 - PADA + 4 * c4;     // multiple of 4: a vector is wholly < 0 or >= 0
               const bool ok = idx < NITEM && ci < Cin && t >= 0 && t < L;
-              const uint32_t goff = ok ? (uint32_t)ci * (uint32_t)L + (uint32_t)t : 0u;   // always valid
-              f32x4 v = *reinterpret_cast<const f32x4*>(xb + goff);
-              if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-              stg[i] = v;
+              const uint32_t goff = ok ? (uint32_t)ci * ldx + (uint32_t)t : 0u;   // always valid
+              nval[i] = ok ? min(L - t, 4) : 0;     // ragged L: a vector may straddle the row end
+              stg[i] = *reinterpret_cast<const f32x4*>(xb + goff);
             }
 #pragma unroll
             for (int i = 0; i < LB; ++i) {
-              const int idx = (bt * LB + i) * 64 + lane;
+              const int idx = (bt * LB + i) * (64 * NLD) + llane;
               if (idx < NITEM) {
                 f32x4 v = stg[i];
-                v[0] = lrelu(v[0], slope); v[1] = lrelu(v[1], slope);
-                v[2] = lrelu(v[2], slope); v[3] = lrelu(v[3], slope);
+                const int n = nval[i];
+                v[0] = n > 0 ? lrelu(v[0], slope) : 0.f;
+                v[1] = n > 1 ? lrelu(v[1], slope) : 0.f;
+                v[2] = n > 2 ? lrelu(v[2], slope) : 0.f;
+                v[3] = n > 3 ? lrelu(v[3], slope) : 0.f;
                 *reinterpret_cast<f32x4*>(dst + 4 * idx) = v;  // row*XS + 4*c4 == 4*idx
               }
             }
           } else {
             float stg[LB];
+            int nval[LB];
 #pragma unroll
             for (int i = 0; i < LB; ++i) {
-              const int idx = (bt * LB + i) * 64 + lane;
+              const int idx = (bt * LB + i) * (64 * NLD) + llane;
               const int row = idx / XS, c = idx - row * XS;
               const int ci = chunk * CHUNK + row;
               const int t = t0 - PADA + c;
               const bool ok = idx < NITEM && ci < Cin && t >= 0 && t < L;
-              const uint32_t goff = ok ? (uint32_t)ci * (uint32_t)L + (uint32_t)t : 0u;
-              const float v = xb[goff];
-              stg[i] = ok ? v : 0.f;
+              const uint32_t goff = ok ? (uint32_t)ci * ldx + (uint32_t)t : 0u;
+              nval[i] = ok ? 1 : 0;
+              stg[i] = xb[goff];
             }
 #pragma unroll
             for (int i = 0; i < LB; ++i) {
-              const int idx = (bt * LB + i) * 64 + lane;
-              if (idx < NITEM) dst[idx] = lrelu(stg[i], slope);
+              const int idx = (bt * LB + i) * (64 * NLD) + llane;
+              if (idx < NITEM) dst[idx] = nval[i] ? lrelu(stg[i], slope) : 0.f;
             }
           }
         }
@@ -368,41 +379,63 @@ __global__ __launch_bounds__(320) void conv1d_mfma_kernel(const ov_conv1d_params
 
 typedef int (*conv_launch_fn)(const ov_conv1d_params*, hipStream_t);
 
-template <int K, int DIL, int WM, int WN, int WVM, int WVN, int CHUNK, bool VEC, int EPI>
+template <int K, int DIL, int WM, int WN, int WVM, int WVN, int CHUNK, bool VEC, int EPI, int NLD>
 int conv1d_launch(const ov_conv1d_params* p, hipStream_t stream) {
   constexpr int M_BLK = 32 * WM * WVM, N_BLK = 32 * WN * WVN;
   const int ntiles = (p->L + N_BLK - 1) / N_BLK;
   const int mblocks = (p->M + M_BLK - 1) / M_BLK;
-  // Keep >= ~8 workgroups per CU-slot in the grid before giving a workgroup several time tiles.
-  const long total = (long)ntiles * mblocks * p->B;
-  int tpw = 1;
-  if (p->tiles_per_wg > 0) tpw = p->tiles_per_wg;
-  else if (total >= 16384) tpw = 4;
-  else if (total >= 8192) tpw = 2;
+  // One time tile per workgroup unless the caller asks otherwise: measured on MI355X, walking 2-4
+  // tiles per workgroup was never better than 1 by more than 2 % and usually worse (coarser tail).
+  const int tpw = p->tiles_per_wg > 0 ? p->tiles_per_wg : 1;
   dim3 grid((ntiles + tpw - 1) / tpw, mblocks, p->B);
-  hipLaunchKernelGGL((conv1d_mfma_kernel<K, DIL, WM, WN, WVM, WVN, CHUNK, VEC, EPI>), grid, dim3(320), 0, stream, *p,
-                     tpw);
+  hipLaunchKernelGGL((conv1d_mfma_kernel<K, DIL, WM, WN, WVM, WVN, CHUNK, VEC, EPI, NLD>), grid,
+                     dim3(64 * (4 + NLD)), 0, stream, *p, tpw);
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
 }
 
-// Tile ids used by the dispatcher.
-enum { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x512 = 2 };
+// Tile ids used by the dispatcher (ov_conv1d_params.tile = id + 1 forces one).
+enum { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x512 = 2, TILE_32x256 = 3 };
 
 struct ConvVariant {
-  int K, dil, tile, vec, epi;
+  int K, dil, tile, vec, epi, nld;
   conv_launch_fn fn;
 };
 
+// Wave-tile template arguments <WM, WN, WVM, WVN> of each tile id.
+#define OV_TILE_128x128 2, 2, 2, 2
+#define OV_TILE_64x256 2, 2, 1, 4
+#define OV_TILE_32x512 1, 4, 1, 4
+#define OV_TILE_32x256 1, 2, 1, 4
+
+// An instantiation list is a macro LIST(X) expanding to X(K, DIL, TILE, CHUNK, VEC, EPI, NLD) items;
+// OV_DEFINE_VARIANTS(table, LIST) emits the explicit kernel instantiations (seen by the host and the
+// device pass) and the host-side dispatch table `table` / `table##Count`.
+#define OV_X_INST(K, DIL, TILE, CHUNK, VEC, EPI, NLD)                                                        \
+  template __global__ void conv1d_mfma_kernel<K, DIL, OV_TILE_##TILE, CHUNK, (VEC) != 0, EPI, NLD>(           \
+      const ov_conv1d_params, const int);
+#define OV_X_ROW(K, DIL, TILE, CHUNK, VEC, EPI, NLD)                                                         \
+  {K, DIL, TILE_##TILE, VEC, EPI, NLD, conv1d_launch<K, DIL, OV_TILE_##TILE, CHUNK, (VEC) != 0, EPI, NLD>},
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OV_DEFINE_VARIANTS(table, LIST) LIST(OV_X_INST)
+#else
+#define OV_DEFINE_VARIANTS(table, LIST)                   \
+  LIST(OV_X_INST)                                         \
+  const ConvVariant table[] = {LIST(OV_X_ROW)};           \
+  const int table##Count = sizeof(table) / sizeof(table[0]);
+#endif
+
 // Each conv1d_inst_*.hip translation unit exports one table.
-extern const ConvVariant kVariantsA[];
-extern const int kNumVariantsA;
-extern const ConvVariant kVariantsB[];
-extern const int kNumVariantsB;
-extern const ConvVariant kVariantsC[];
-extern const int kNumVariantsC;
-extern const ConvVariant kVariantsS[];
-extern const int kNumVariantsS;
-extern const ConvVariant kVariantsW[];
-extern const int kNumVariantsW;
+#define OV_DECLARE_VARIANTS(table)  \
+  extern const ConvVariant table[]; \
+  extern const int table##Count;
+OV_DECLARE_VARIANTS(kVariantsA1)
+OV_DECLARE_VARIANTS(kVariantsA2)
+OV_DECLARE_VARIANTS(kVariantsB1)
+OV_DECLARE_VARIANTS(kVariantsB2)
+OV_DECLARE_VARIANTS(kVariantsC1)
+OV_DECLARE_VARIANTS(kVariantsC2)
+OV_DECLARE_VARIANTS(kVariantsD)
+OV_DECLARE_VARIANTS(kVariantsS)
+OV_DECLARE_VARIANTS(kVariantsW)
 
 }  // namespace ovk

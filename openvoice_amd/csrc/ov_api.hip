@@ -7,7 +7,6 @@
 #include <cstring>
 
 #include "conv1d_mfma.h"
-#include "conv1d_mfma_v1.h"
 #include "openvoice_amd.h"
 
 namespace ovk {
@@ -92,40 +91,32 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
   if (lane == 0) y[(int64_t)b * M + m] = acc + (bias ? bias[m] : 0.f);
 }
 
-__global__ void sequence_mask_kernel(const int64_t* __restrict__ lengths, float* __restrict__ mask, int T) {
+__global__ void sequence_mask_kernel(const int64_t* __restrict__ lengths, float* __restrict__ mask, int T,
+                                     int ld) {
   const int b = blockIdx.y;
   const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t < T) mask[(int64_t)b * T + t] = t < lengths[b] ? 1.f : 0.f;
+  if (t < T) mask[(int64_t)b * ld + t] = t < lengths[b] ? 1.f : 0.f;
 }
 
-// OV_CONV_IMPL=v1 selects the round-1 single-role kernel for A/B measurements (tools/ only).
-static bool use_v1() {
-  static const int flag = [] {
-    const char* e = std::getenv("OV_CONV_IMPL");
-    return (e && e[0] == 'v' && e[1] == '1') ? 1 : 0;
-  }();
-  return flag != 0;
-}
-
-static conv_launch_fn find_variant(int K, int dil, int tile, int vec, int epi) {
-  if (use_v1()) {
-    const v1::ConvVariant* tabs[4] = {v1::kV1VariantsA, v1::kV1VariantsB, v1::kV1VariantsC, v1::kV1VariantsS};
-    const int ns[4] = {v1::kV1NumVariantsA, v1::kV1NumVariantsB, v1::kV1NumVariantsC, v1::kV1NumVariantsS};
-    for (int t = 0; t < 4; ++t)
-      for (int i = 0; i < ns[t]; ++i) {
-        const v1::ConvVariant& v = tabs[t][i];
-        if (v.K == K && v.dil == dil && v.tile == tile && v.vec == vec) return v.fn;
-      }
-    return nullptr;
-  }
-  const ConvVariant* tabs[5] = {kVariantsA, kVariantsB, kVariantsC, kVariantsS, kVariantsW};
-  const int ns[5] = {kNumVariantsA, kNumVariantsB, kNumVariantsC, kNumVariantsS, kNumVariantsW};
-  for (int t = 0; t < 5; ++t)
+static conv_launch_fn find_variant(int K, int dil, int tile, int vec, int epi, int nld) {
+  const ConvVariant* tabs[] = {kVariantsA1, kVariantsA2, kVariantsB1, kVariantsB2, kVariantsC1,
+                               kVariantsC2, kVariantsD,  kVariantsS,  kVariantsW};
+  const int ns[] = {kVariantsA1Count, kVariantsA2Count, kVariantsB1Count, kVariantsB2Count, kVariantsC1Count,
+                    kVariantsC2Count, kVariantsDCount,  kVariantsSCount,  kVariantsWCount};
+  for (unsigned t = 0; t < sizeof(ns) / sizeof(ns[0]); ++t)
     for (int i = 0; i < ns[t]; ++i) {
       const ConvVariant& v = tabs[t][i];
-      if (v.K == K && v.dil == dil && v.tile == tile && v.vec == vec && v.epi == epi) return v.fn;
+      if (v.K == K && v.dil == dil && v.tile == tile && v.vec == vec && v.epi == epi && v.nld == nld) return v.fn;
     }
   return nullptr;
+}
+
+// Loader-wave preference order for a (tile, K) class; the first instantiated one wins.  Chosen from
+// the per-shape measurements in profiles/ (tools/bench_convs.py --loaders ...).
+static void loader_preference(int tile, int K, int out[3]) {
+  if (K == 1) { out[0] = 4; out[1] = 2; out[2] = 1; return; }
+  if (tile == TILE_128x128) { out[0] = 2; out[1] = 1; out[2] = 4; return; }
+  out[0] = 4; out[1] = 2; out[2] = 1;
 }
 
 }  // namespace ovk
@@ -134,7 +125,7 @@ using namespace ovk;
 
 extern "C" {
 
-int ov_version(void) { return 100; }
+int ov_version(void) { return 101; }
 
 int ov_conv1d_pack_rows(int Cout) { return (Cout + 127) / 128 * 128; }
 
@@ -165,8 +156,10 @@ int ov_conv1d_pack_f32(const float* w, int Cout, int Cin, int K, float* dst) {
   return OV_OK;
 }
 
-int ov_conv1d_f32(const ov_conv1d_params* p, ov_stream_t stream) {
-  if (!p || !p->x || !p->w || !p->out) return OV_E_BADARG;
+int ov_conv1d_f32(const ov_conv1d_params* pin, ov_stream_t stream) {
+  if (!pin || !pin->x || !pin->w || !pin->out) return OV_E_BADARG;
+  ov_conv1d_params q = *pin;   // defaults filled in below; the kernels see the normalised copy
+  ov_conv1d_params* p = &q;
   if (p->B <= 0 || p->Cin <= 0 || p->L <= 0 || p->M <= 0 || p->Cout <= 0 || p->K <= 0 || p->dil <= 0)
     return OV_E_BADARG;
   if (p->B > 65535) return OV_E_BADARG;
@@ -180,19 +173,39 @@ int ov_conv1d_f32(const ov_conv1d_params* p, ov_stream_t stream) {
       ((int64_t)p->Cout * (epi == OV_EPI_CONVT ? p->phase_s : 1)) % 32 != 0)
     return OV_E_UNSUPPORTED;          // rows are stored in whole 32-row fragments
   if ((epi == OV_EPI_GATE || epi == OV_EPI_POSTERIOR) && p->Cout % 32 != 0) return OV_E_UNSUPPORTED;
+  if (epi == OV_EPI_CONVT && (p->phase_s <= 0 || 32 % p->phase_s != 0)) return OV_E_BADARG;
+  const int64_t lout = (int64_t)p->L * (epi == OV_EPI_CONVT ? p->phase_s : 1);
+  if (lout > INT32_MAX) return OV_E_BADARG;
+  if (p->x_ld == 0) p->x_ld = p->L;
+  if (p->out_ld == 0) p->out_ld = (int32_t)lout;
+  if (p->mask_bstride == 0) p->mask_bstride = p->L;
+  if (p->x_ld < p->L || p->out_ld < lout || (p->mask && p->mask_bstride < p->L)) return OV_E_BADARG;
+  // per-utterance offsets are 32-bit inside the kernels
+  if ((int64_t)p->Cin * p->x_ld > UINT32_MAX || (int64_t)(p->M + 32) * p->out_ld > UINT32_MAX) return OV_E_BADARG;
   if (epi == OV_EPI_CONVT) {
-    if (p->phase_s <= 0 || 32 % p->phase_s != 0) return OV_E_BADARG;
-    if ((reinterpret_cast<uintptr_t>(p->out) & 15) || (p->out_bstride & 3)) return OV_E_ALIGN;
+    const int need = p->phase_s == 8 ? 4 : (p->phase_s == 2 ? 2 : 1);   // 16- / 8-byte interleaving stores
+    if ((reinterpret_cast<uintptr_t>(p->out) & (4 * need - 1)) || (p->out_bstride % need) || (p->out_ld % need))
+      return OV_E_ALIGN;
   }
   if ((reinterpret_cast<uintptr_t>(p->w) & 15)) return OV_E_ALIGN;
+  if (p->tile < 0 || p->tile > 4 || (p->loaders != 0 && p->loaders != 1 && p->loaders != 2 && p->loaders != 4))
+    return OV_E_BADARG;
   int tile = TILE_128x128;
-  if (p->M <= 32 && epi != OV_EPI_GATE && epi != OV_EPI_POSTERIOR) tile = TILE_32x512;
+  if (p->tile > 0) tile = p->tile - 1;
+  else if (p->M <= 32 && epi != OV_EPI_GATE && epi != OV_EPI_POSTERIOR) tile = TILE_32x512;
   else if (p->M <= 64) tile = TILE_64x256;
-  const bool can_vec = (p->L % 4 == 0) && !(reinterpret_cast<uintptr_t>(p->x) & 15) && (p->x_bstride % 4 == 0);
+  const bool can_vec = (p->x_ld % 4 == 0) && !(reinterpret_cast<uintptr_t>(p->x) & 15) && (p->x_bstride % 4 == 0);
+  int pref[3];
   conv_launch_fn fn = nullptr;
-  if (can_vec) fn = find_variant(p->K, p->dil, tile, 1, epi);
-  if (!fn && can_vec && tile != TILE_128x128) fn = find_variant(p->K, p->dil, TILE_128x128, 1, epi);
-  if (!fn) fn = find_variant(p->K, p->dil, TILE_128x128, 0, epi);
+  // forced tile / loader count: exact match or OV_E_UNSUPPORTED (measurement knobs must not silently
+  // fall back); otherwise the preferred tile, then 128x128, 16-byte staging before 4-byte.
+  const int tiles_try[2] = {tile, p->tile > 0 ? tile : (int)TILE_128x128};
+  for (int ti = 0; ti < 2 && !fn; ++ti) {
+    if (p->loaders) { pref[0] = pref[1] = pref[2] = p->loaders; }
+    else loader_preference(tiles_try[ti], p->K, pref);
+    for (int vec = can_vec ? 1 : 0; vec >= 0 && !fn; --vec)
+      for (int li = 0; li < 3 && !fn; ++li) fn = find_variant(p->K, p->dil, tiles_try[ti], vec, epi, pref[li]);
+  }
   if (!fn) return OV_E_UNSUPPORTED;
   return fn(p, static_cast<hipStream_t>(stream));
 }
@@ -222,10 +235,11 @@ int ov_linear_f32(const float* x, const float* w, const float* bias, float* y, i
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
 }
 
-int ov_sequence_mask_f32(const int64_t* lengths, float* mask, int B, int T, ov_stream_t stream) {
-  if (!lengths || !mask || B <= 0 || T <= 0 || B > 65535) return OV_E_BADARG;
+int ov_sequence_mask_f32(const int64_t* lengths, float* mask, int B, int T, int ld, ov_stream_t stream) {
+  if (!lengths || !mask || B <= 0 || T <= 0 || B > 65535 || (ld != 0 && ld < T)) return OV_E_BADARG;
   dim3 grid((T + 255) / 256, B);
-  hipLaunchKernelGGL(sequence_mask_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), lengths, mask, T);
+  hipLaunchKernelGGL(sequence_mask_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), lengths, mask, T,
+                     ld ? ld : T);
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
 }
 

@@ -50,6 +50,12 @@ class PackedConv:
         self.bias = b.to(device)
 
 
+def padded_frames(T):
+    """Row stride of the frame-rate tensors inside the engine: T rounded up to 4 floats so that every
+    row starts 16-byte aligned and the conv kernels take their 16-byte staging path for any T."""
+    return (T + 3) // 4 * 4
+
+
 def gate_row_order(hidden):
     """Packed row order pairing row c (tanh | m) with row c+hidden (sigmoid | logs) in adjacent
     32-row MFMA tiles, so both halves of a gate land in the same lane of one wave."""
@@ -82,9 +88,10 @@ def conv_transpose_as_conv(w, stride):
 
 def launch_conv(layer, x, x_off, x_bs, out, out_off, out_bs, B, L, epi=EPI_LINEAR, flags=0, in_slope=1.0,
                 scale=1.0, res=None, res_off=0, res_bs=0, add=None, add_bs=0, out2=None, out2_bs=0, mask=None,
-                bias_b=None, bias_b_off=0, bias_b_bs=0, split=0, phase_s=1, cin=None, rows=None, tiles_per_wg=0):
+                bias_b=None, bias_b_off=0, bias_b_bs=0, split=0, phase_s=1, cin=None, rows=None, tiles_per_wg=0,
+                x_ld=0, out_ld=0, mask_bs=0, tile=0, loaders=0):
     """Fill ``ov_conv1d_params`` and launch on torch's current stream of ``x``'s device.
-    Offsets and batch strides are in elements."""
+    Offsets, row strides (``*_ld``, 0 = dense) and batch strides are in elements."""
     p = ConvParams()
     p.x, p.w = _ptr(x, x_off), _ptr(layer.w)
     p.bias = _ptr(layer.bias)        # zeros when the layer has no bias (the kernel always adds it)
@@ -101,7 +108,8 @@ def launch_conv(layer, x, x_off, x_bs, out, out_off, out_bs, B, L, epi=EPI_LINEA
     p.Cout = layer.cout
     p.K, p.dil, p.epi, p.flags, p.split, p.phase_s = layer.K, layer.dil, epi, flags, split, phase_s
     p.in_slope, p.scale = in_slope, scale
-    p.tiles_per_wg = tiles_per_wg
+    p.tiles_per_wg, p.tile, p.loaders = tiles_per_wg, tile, loaders
+    p.x_ld, p.out_ld, p.mask_bstride = x_ld, out_ld, mask_bs
     stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(_lib.load().ov_conv1d_f32(ctypes.byref(p), stream), "ov_conv1d_f32")
 
@@ -243,11 +251,15 @@ class ConverterEngine:
         ws = self._ws.get(key)
         if ws is None:
             self._ws.clear()   # one resident shape at a time; the decoder scratch is GBs at B=32
-            dev, H = self.device, self.hidden
-            f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
-            ws = dict(mask=f(B, T), h=f(B, H, T), acts=f(B, H, T), skip=f(B, H, T))
+            dev, H, C = self.device, self.hidden, self.inter
+            Tp = padded_frames(T)
+            # zero-filled once: the pad columns [T, Tp) are never written by a kernel and never read as data
+            f = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+            ws = dict(Tp=Tp, mask=f(B, Tp), h=f(B, H, Tp), acts=f(B, H, Tp), skip=f(B, H, Tp), noise=f(B, C, Tp),
+                      z=f(B, C, Tp), z_p=f(B, C, Tp), z_hat=f(B, C, Tp))
             ch = self.cfg["upsample_initial_channel"]
-            ws["pre"] = f(B, ch, T)
+            ws["pre"] = f(B, ch, Tp)
+            f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
             L, biggest = T, 0
             for u in self.cfg["upsample_rates"]:
                 ch //= 2
@@ -261,27 +273,28 @@ class ConverterEngine:
         """h (in place) -> skip accumulator; reference: openvoice/modules.py:192-210.  The final
         ``output * x_mask`` (modules.py:210) is dropped: every consumer (proj / post) is a 1x1 conv
         whose own epilogue multiplies by the same 0/1 mask, which makes it a no-op."""
-        H = wn.hidden
+        H, Tp = wn.hidden, ws["Tp"]
         cbs = 0 if cond.shape[0] == 1 else cond.shape[1]
         for i in range(wn.n_layers):
-            self._conv(wn.in_layers[i], ws["h"], 0, H * T, ws["acts"], 0, H * T, B, T, epi=EPI_GATE,
-                       bias_b=cond, bias_b_off=2 * H * i, bias_b_bs=cbs, rows=2 * H, tag="wn_in")
+            self._conv(wn.in_layers[i], ws["h"], 0, H * Tp, ws["acts"], 0, H * Tp, B, T, epi=EPI_GATE,
+                       bias_b=cond, bias_b_off=2 * H * i, bias_b_bs=cbs, rows=2 * H, x_ld=Tp, out_ld=Tp, tag="wn_in")
             last = i == wn.n_layers - 1
-            self._conv(wn.rs_layers[i], ws["acts"], 0, H * T, ws["h"], 0, H * T, B, T, epi=EPI_RESSKIP,
-                       flags=F_OUT2_INIT if i == 0 else 0, out2=ws["skip"], out2_bs=H * T, mask=mask,
-                       split=0 if last else H, tag="wn_rs")
+            self._conv(wn.rs_layers[i], ws["acts"], 0, H * Tp, ws["h"], 0, H * Tp, B, T, epi=EPI_RESSKIP,
+                       flags=F_OUT2_INIT if i == 0 else 0, out2=ws["skip"], out2_bs=H * Tp, mask=mask, mask_bs=Tp,
+                       split=0 if last else H, x_ld=Tp, out_ld=Tp, tag="wn_rs")
 
     def _flow(self, buf, ws, B, T, conds, mask, reverse):
-        C, half, H = self.inter, self.half, self.hidden
+        C, half, H, Tp = self.inter, self.half, self.hidden, ws["Tp"]
         order = range(N_FLOWS - 1, -1, -1) if reverse else range(N_FLOWS)
         for f in order:
             cp = self.couplings[f]
-            x0_off = half * T if cp["flipped"] else 0
-            x1_off = 0 if cp["flipped"] else half * T
-            self._conv(cp["pre"], buf, x0_off, C * T, ws["h"], 0, H * T, B, T, flags=F_MASK_V, mask=mask, tag="cpl_pre")
+            x0_off = half * Tp if cp["flipped"] else 0
+            x1_off = 0 if cp["flipped"] else half * Tp
+            self._conv(cp["pre"], buf, x0_off, C * Tp, ws["h"], 0, H * Tp, B, T, flags=F_MASK_V, mask=mask,
+                       mask_bs=Tp, x_ld=Tp, out_ld=Tp, tag="cpl_pre")
             self._wavenet(cp["wn"], ws, B, T, conds[f], mask)
-            self._conv(cp["post"], ws["skip"], 0, H * T, buf, x1_off, C * T, B, T, epi=EPI_COUPLE, mask=mask,
-                       scale=-1.0 if reverse else 1.0, tag="cpl_post")
+            self._conv(cp["post"], ws["skip"], 0, H * Tp, buf, x1_off, C * Tp, B, T, epi=EPI_COUPLE, mask=mask,
+                       mask_bs=Tp, x_ld=Tp, out_ld=Tp, scale=-1.0 if reverse else 1.0, tag="cpl_post")
 
     # ---- the path ----------------------------------------------------------------------------------
     @torch.no_grad()
@@ -300,11 +313,11 @@ class ConverterEngine:
         g_tgt = sid_tgt.to(dev, torch.float32).reshape(sid_tgt.shape[0], -1).contiguous()
         if noise is None:
             noise = torch.randn(B, C, T, dtype=torch.float32, device=dev)
-        noise = noise.to(dev, torch.float32).contiguous()
         ws = self._workspace(B, T)
-        mask = ws["mask"]
+        Tp, mask = ws["Tp"], ws["mask"]
+        ws["noise"][:, :, :T].copy_(noise.to(dev, torch.float32))     # into the padded-row layout
         st = self._stream()
-        _lib.check(self.lib.ov_sequence_mask_f32(ctypes.c_void_p(lengths.data_ptr()), _ptr(mask), B, T, st),
+        _lib.check(self.lib.ov_sequence_mask_f32(ctypes.c_void_p(lengths.data_ptr()), _ptr(mask), B, T, Tp, st),
                    "ov_sequence_mask_f32")
         # conditioning GEMVs (T = 1): modules.py:189-190 for every WN, models.py:275 for the decoder
         g_q = torch.zeros_like(g_src) if self.zero_g else g_src
@@ -314,29 +327,36 @@ class ConverterEngine:
         cond_tgt = [self._linear(g_tgt, cp["wn"].cond_w, cp["wn"].cond_b) for cp in self.couplings]
         cond_d = self._linear(g_d, self.dec_cond_w, self.dec_cond_b)
         # ---- posterior encoder (models.py:212-221) -------------------------------------------------
-        self._conv(self.q_pre, spec, 0, F * T, ws["h"], 0, H * T, B, T, flags=F_MASK_V, mask=mask, tag="q_pre")
+        self._conv(self.q_pre, spec, 0, F * T, ws["h"], 0, H * Tp, B, T, flags=F_MASK_V, mask=mask, mask_bs=Tp,
+                   out_ld=Tp, tag="q_pre")
         self._wavenet(self.q_wn, ws, B, T, cond_q, mask)
-        z = torch.empty(B, C, T, dtype=torch.float32, device=dev)
-        self._conv(self.q_proj, ws["skip"], 0, H * T, z, 0, C * T, B, T, epi=EPI_POSTERIOR, res=noise,
-                   res_bs=C * T, scale=float(tau), mask=mask, rows=2 * C, tag="q_proj")
+        z, z_p, z_hat = ws["z"], ws["z_p"], ws["z_hat"]
+        self._conv(self.q_proj, ws["skip"], 0, H * Tp, z, 0, C * Tp, B, T, epi=EPI_POSTERIOR, res=ws["noise"],
+                   res_bs=C * Tp, scale=float(tau), mask=mask, mask_bs=Tp, rows=2 * C, x_ld=Tp, out_ld=Tp, tag="q_proj")
         # ---- flow forward with g_src, reverse with g_tgt (models.py:496-497) -----------------------
-        z_p = z.clone()
+        z_p.copy_(z)
         self._flow(z_p, ws, B, T, cond_src, mask, reverse=False)
-        z_hat = z_p.clone()
+        z_hat.copy_(z_p)
         self._flow(z_hat, ws, B, T, cond_tgt, mask, reverse=True)
         # ---- generator (models.py:272-291); z_hat * y_mask is the identity (z_hat already masked) --
-        o_hat = self.decode(z_hat, cond_d, ws)
-        return o_hat, mask.unsqueeze(1), (z, z_p, z_hat)
+        o_hat = self.decode(z_hat, cond_d, ws, T=T)
+        # fresh dense tensors for the caller (the workspace is reused by the next call)
+        outs = tuple(t[:, :, :T].contiguous() for t in (z, z_p, z_hat))
+        return o_hat, mask[:, :T].unsqueeze(1).contiguous(), outs
 
-    def decode(self, z_hat, cond_d, ws=None):
-        B, C, T = z_hat.shape
+    def decode(self, z_hat, cond_d, ws=None, T=None):
+        """Generator (models.py:272-291).  ``z_hat`` is [B, C, ld] with ``T`` valid frames per row
+        (``T`` defaults to the full row, i.e. a dense tensor)."""
+        B, C, ld = z_hat.shape
+        T = ld if T is None else T
         if ws is None:
             ws = self._workspace(B, T)
+        Tp = ws["Tp"]
         cfg = self.cfg
         ch = cfg["upsample_initial_channel"]
-        self._conv(self.conv_pre, z_hat, 0, C * T, ws["pre"], 0, ch * T, B, T, bias_b=cond_d,
-                   bias_b_bs=0 if cond_d.shape[0] == 1 else cond_d.shape[1], tag="conv_pre")
-        x, L = ws["pre"], T
+        self._conv(self.conv_pre, z_hat, 0, C * ld, ws["pre"], 0, ch * Tp, B, T, bias_b=cond_d,
+                   bias_b_bs=0 if cond_d.shape[0] == 1 else cond_d.shape[1], x_ld=ld, out_ld=Tp, tag="conv_pre")
+        x, L, x_ld = ws["pre"], T, Tp
         free = list(ws["dec"])
         nk = len(cfg["resblock_kernel_sizes"])
         for i, up in enumerate(self.ups):
@@ -344,11 +364,12 @@ class ConverterEngine:
             cin, ch = ch, ch // 2
             u = free.pop()
             # leaky_relu(0.1) + ConvTranspose1d (models.py:278-279)
-            self._conv(up["conv"], x, 0, cin * L, u, 0, ch * L * s, B, L, epi=EPI_CONVT, in_slope=LRELU_SLOPE,
-                       phase_s=s, tag="ups", alg_flops=2.0 * cin * ch * 2 * s * L * B)
+            self._conv(up["conv"], x, 0, cin * x_ld, u, 0, ch * L * s, B, L, epi=EPI_CONVT, in_slope=LRELU_SLOPE,
+                       phase_s=s, x_ld=x_ld, tag="ups", alg_flops=2.0 * cin * ch * 2 * s * L * B)
             if i > 0:
                 free.append(x)
             L *= s
+            x_ld = L
             t1, ra, acc = free.pop(), free.pop(), free.pop()
             bs = ch * L
             # MRF: mean of the 3 ResBlock1 outputs (models.py:280-286, modules.py:296-306)

@@ -80,6 +80,6 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.ov_conv1d_f32(p, None) == -1
     assert lib.ov_linear_f32(None, None, None, None, 1, 1, 1, None) == -1
     assert lib.ov_conv_post_tanh_f32(None, None, None, 1, 1, 1, 7, 0.01, None) == -1
-    assert lib.ov_sequence_mask_f32(None, None, 1, 1, None) == -1
+    assert lib.ov_sequence_mask_f32(None, None, 1, 1, 0, None) == -1
     assert lib.ov_conv1d_pack_f32(None, 1, 1, 1, None) == -1
     assert lib.ov_conv1d_pack_size(0, 1, 1) == 0

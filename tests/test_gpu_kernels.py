@@ -229,6 +229,97 @@ def test_linear_and_sequence_mask():
     _close(y, x @ w.t() + b, what="linear")
     lengths = torch.tensor([5, 0, 9, 7], dtype=torch.int64, device=DEV)
     mask = torch.empty(4, 9, device=DEV)
-    assert lib.ov_sequence_mask_f32(ctypes.c_void_p(lengths.data_ptr()), _ptr(mask), 4, 9, st) == 0
+    assert lib.ov_sequence_mask_f32(ctypes.c_void_p(lengths.data_ptr()), _ptr(mask), 4, 9, 0, st) == 0
     ref = (torch.arange(9)[None] < lengths.cpu()[:, None]).float()
     assert torch.equal(mask.cpu(), ref)
+
+
+def _pad_rows(t, ld, fill=float("nan")):
+    """[B, C, L] -> [B, C, ld] with the pad columns poisoned: a kernel that reads them as data or
+    writes them fails the comparison."""
+    B, C, L = t.shape
+    out = torch.full((B, C, ld), fill)
+    out[:, :, :L] = t
+    return out
+
+
+@pytest.mark.parametrize("L", [861, 862, 863, 17, 1])
+def test_padded_rows_ragged_length_16_byte_staging(L):
+    """Frame-rate tensors live in rows padded to a multiple of 4 floats (engine.padded_frames) so the
+    16-byte staging path is taken for any T; the valid length stays ragged.  One WN layer + the k7
+    conv_pre shape, pad columns poisoned with NaN on the way in and checked untouched on the way out."""
+    B, H, ld = 2, 192, (L + 3) // 4 * 4 + 4
+    x, g = _rand(B, H, L, seed=1), _rand(B, 2 * H, seed=2, scale=0.3)
+    w_in, b_in = _rand(2 * H, H, 5, seed=3, scale=(5 * H) ** -0.5), _rand(2 * H, seed=4, scale=0.1)
+    w_rs, b_rs = _rand(2 * H, H, 1, seed=5, scale=H ** -0.5), _rand(2 * H, seed=6, scale=0.1)
+    skip0 = _rand(B, H, L, seed=7)
+    lens = torch.tensor([L, max(1, L - 5)])
+    mask = (torch.arange(L)[None, :] < lens[:, None]).float()
+    x_in = F.conv1d(x, w_in, b_in, padding=2) + g[:, :, None]
+    acts = torch.tanh(x_in[:, :H]) * torch.sigmoid(x_in[:, H:])
+    rs = F.conv1d(acts, w_rs, b_rs)
+    x_ref, skip_ref = (x + rs[:, :H]) * mask[:, None], skip0 + rs[:, H:]
+    order = gate_row_order(H)
+    l_in = PackedConv(w_in[order], b_in[order], DEV, K=5, cout=H)
+    l_rs = PackedConv(w_rs, b_rs, DEV, K=1)
+    xd = _pad_rows(x, ld).to(DEV)
+    maskd = _pad_rows(mask[:, None], ld)[:, 0].contiguous().to(DEV)
+    actsd = torch.full((B, H, ld), float("nan"), device=DEV)
+    gd = g[:, order].contiguous().to(DEV)
+    launch_conv(l_in, xd, 0, H * ld, actsd, 0, H * ld, B, L, epi=EPI_GATE, bias_b=gd, bias_b_bs=2 * H, rows=2 * H,
+                x_ld=ld, out_ld=ld)
+    _close(actsd[:, :, :L], acts, what="gate (padded rows)")
+    assert torch.isnan(actsd[:, :, L:]).all(), "gate wrote into the pad columns"
+    skipd = _pad_rows(skip0, ld).to(DEV)
+    launch_conv(l_rs, actsd, 0, H * ld, xd, 0, H * ld, B, L, epi=EPI_RESSKIP, out2=skipd, out2_bs=H * ld, mask=maskd,
+                mask_bs=ld, split=H, x_ld=ld, out_ld=ld)
+    _close(xd[:, :, :L], x_ref, what="residual (padded rows)")
+    _close(skipd[:, :, :L], skip_ref, what="skip (padded rows)")
+    assert torch.isnan(xd[:, :, L:]).all() and torch.isnan(skipd[:, :, L:]).all()
+    # conv_pre shape: k7 192 -> 512 with a per-utterance bias, padded in, padded out
+    w7, b7 = _rand(512, H, 7, seed=8, scale=(7 * H) ** -0.5), _rand(512, seed=9, scale=0.1)
+    l7 = PackedConv(w7, b7, DEV, K=7)
+    out = torch.full((B, 512, ld), float("nan"), device=DEV)
+    launch_conv(l7, _pad_rows(x, ld).to(DEV), 0, H * ld, out, 0, 512 * ld, B, L, x_ld=ld, out_ld=ld)
+    _close(out[:, :, :L], F.conv1d(x, w7, b7, padding=3), what="k7 (padded rows)")
+    assert torch.isnan(out[:, :, L:]).all()
+
+
+@pytest.mark.parametrize("s,cin,cout,L", [(8, 512, 256, 61), (2, 128, 64, 999)])
+def test_conv_transpose_from_padded_rows(s, cin, cout, L):
+    """ups.0 reads the padded frame-rate rows (x_ld > L) and writes dense upsampled rows."""
+    B, k, ld = 2, 2 * s, (L + 3) // 4 * 4
+    x = _rand(B, cin, L, seed=1)
+    w, b = _rand(cin, cout, k, seed=2, scale=(2 * cin) ** -0.5), _rand(cout, seed=3, scale=0.1)
+    ref = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, stride=s, padding=(k - s) // 2)
+    layer = PackedConv(conv_transpose_as_conv(w, s), b.repeat_interleave(s), DEV, K=3, cout=cout)
+    out = torch.full((B, cout, s * L), float("nan"), device=DEV)
+    launch_conv(layer, _pad_rows(x, ld).to(DEV), 0, cin * ld, out, 0, cout * s * L, B, L, epi=EPI_CONVT,
+                in_slope=0.1, phase_s=s, x_ld=ld)
+    _close(out, ref, what=f"convT from padded rows s={s}")
+
+
+@pytest.mark.parametrize("c,tile,loaders", [(32, 3, 1), (32, 3, 2), (32, 3, 4), (32, 4, 2), (32, 4, 4),
+                                            (64, 2, 1), (64, 2, 2), (64, 2, 4), (128, 1, 1), (128, 1, 2),
+                                            (32, 1, 2), (64, 1, 1)])
+@pytest.mark.parametrize("k,d", [(3, 1), (7, 3), (11, 5)])
+def test_every_tile_and_loader_count(c, tile, loaders, k, d):
+    """All (tile, loader-wave count) instantiations of the MRF convs give the same answer: tile ids
+    1..4 = 128x128, 64x256, 32x512, 32x256; forcing one must not fall back silently."""
+    B, L = 2, 2312
+    x, res = _rand(B, c, L, seed=1), _rand(B, c, L, seed=2)
+    w, bias = _rand(c, c, k, seed=3, scale=(c * k) ** -0.5), _rand(c, seed=4, scale=0.1)
+    ref = F.conv1d(F.leaky_relu(x, 0.1), w, bias, dilation=d, padding=(k - 1) * d // 2) + res
+    layer = PackedConv(w, bias, DEV, K=k, dil=d)
+    out = torch.full((B, c, L), float("nan"), device=DEV)
+    launch_conv(layer, x.to(DEV), 0, c * L, out, 0, c * L, B, L, in_slope=0.1, res=res.to(DEV), res_bs=c * L,
+                tile=tile, loaders=loaders)
+    _close(out, ref, what=f"C={c} k={k} d={d} tile={tile} loaders={loaders}")
+
+
+def test_forced_variant_that_does_not_exist_is_an_error():
+    c, k, L, B = 32, 5, 256, 1
+    layer = PackedConv(_rand(c, c, k, seed=1), None, DEV, K=k)
+    x, out = torch.zeros(B, c, L, device=DEV), torch.zeros(B, c, L, device=DEV)
+    with pytest.raises(_lib.OvError, match="OV_E_UNSUPPORTED"):
+        launch_conv(layer, x, 0, c * L, out, 0, c * L, B, L, tile=3)   # no k=5 32x512 instantiation

@@ -2,8 +2,10 @@
 """Per-shape timing of the MFMA conv kernel on the MRF (ResBlock) shapes of the benchmark batch
 (B = 32, 10 s utterances).  Measurement tool, not part of the product path.
 
-    python tools/bench_convs.py [--tpw 0 1 2 4] [--reps 5]
-    OV_CONV_IMPL=v1 python tools/bench_convs.py      # round-1 single-role kernel, for A/B
+    python tools/bench_convs.py [--tpw 0 2] [--loaders 0 1 2 4] [--tiles 0 3 4] [--reps 5]
+
+tile ids: 0 = dispatcher's choice, 1..4 = 128x128, 64x256, 32x512, 32x256; a (tile, loaders)
+combination that is not instantiated for a shape is skipped.
 """
 import argparse
 import os
@@ -20,16 +22,23 @@ PEAK = 157.3
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tpw", type=int, nargs="+", default=[0])
+    ap.add_argument("--loaders", type=int, nargs="+", default=[0])
+    ap.add_argument("--tiles", type=int, nargs="+", default=[0])
+    ap.add_argument("--channels", type=int, nargs="+", default=[256, 128, 64, 32])
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--kernels", type=int, nargs="+", default=[3, 7, 11])
+    ap.add_argument("--wn", action="store_true", help="also time the WaveNet k5 gate conv and the 1x1 res/skip conv")
     args = ap.parse_args()
     dev = "cuda:0"
     B = args.batch
     stages = [(256, 6888), (128, 55104), (64, 110208), (32, 220416)]
-    print(f"impl={os.environ.get('OV_CONV_IMPL', 'v2')} B={B}")
-    print(f"{'C':>4} {'L':>7} {'k':>2} {'d':>1} {'epi':>8} {'tpw':>3} {'ms':>8} {'TF/s':>7} {'%peak':>6}")
+    from openvoice_amd._lib import OvError
+    print(f"B={B}")
+    print(f"{'C':>4} {'L':>7} {'k':>2} {'d':>1} {'epi':>8} {'tile':>4} {'nld':>3} {'tpw':>3} {'ms':>8} {'TF/s':>7} {'%peak':>6}")
     for c, L in stages:
+        if c not in args.channels:
+            continue
         x = torch.randn(B, c, L, device=dev)
         res = torch.randn(B, c, L, device=dev)
         add = torch.randn(B, c, L, device=dev)
@@ -38,14 +47,15 @@ def main():
             for d, mode in ((1, "plain"), (5, "plain"), (1, "res+add")):
                 w = torch.randn(c, c, k) * (c * k) ** -0.5
                 layer = PackedConv(w, torch.zeros(c), dev, K=k, dil=d)
-                for tpw in args.tpw:
-                    if tpw and os.environ.get("OV_CONV_IMPL") == "v1":
-                        continue
-                    kw = dict(in_slope=0.1, tiles_per_wg=tpw)
+                for tile, nld, tpw in [(t, n, w_) for t in args.tiles for n in args.loaders for w_ in args.tpw]:
+                    kw = dict(in_slope=0.1, tiles_per_wg=tpw, tile=tile, loaders=nld)
                     if mode != "plain":
                         kw.update(res=res, res_bs=c * L, add=add, add_bs=c * L, scale=1.0 / 3.0)
-                    for _ in range(2):
-                        launch_conv(layer, x, 0, c * L, out, 0, c * L, B, L, **kw)
+                    try:
+                        for _ in range(2):
+                            launch_conv(layer, x, 0, c * L, out, 0, c * L, B, L, **kw)
+                    except OvError:
+                        continue
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     for _ in range(args.reps):
@@ -54,8 +64,45 @@ def main():
                     torch.cuda.synchronize()
                     ms = e0.elapsed_time(e1) / args.reps
                     tf = 2.0 * c * c * k * L * B / ms / 1e9
-                    print(f"{c:>4} {L:>7} {k:>2} {d:>1} {mode:>8} {tpw:>3} {ms:8.3f} {tf:7.1f} {100 * tf / PEAK:6.1f}")
+                    print(f"{c:>4} {L:>7} {k:>2} {d:>1} {mode:>8} {tile:>4} {nld:>3} {tpw:>3} {ms:8.3f} {tf:7.1f} "
+                          f"{100 * tf / PEAK:6.1f}", flush=True)
         del x, res, add, out
+    if args.wn:
+        from openvoice_amd._lib import EPI_GATE, EPI_RESSKIP
+        from openvoice_amd.engine import gate_row_order, padded_frames
+        H, T = 192, 861
+        for ld in (T, padded_frames(T)):
+            x = torch.randn(B, H, ld, device=dev)
+            acts = torch.empty(B, H, ld, device=dev)
+            skip = torch.zeros(B, H, ld, device=dev)
+            mask = torch.ones(B, ld, device=dev)
+            cond = torch.randn(B, 2 * H, device=dev)
+            order = gate_row_order(H)
+            l_in = PackedConv((torch.randn(2 * H, H, 5) * (5 * H) ** -0.5)[order], torch.zeros(2 * H), dev, K=5, cout=H)
+            l_rs = PackedConv(torch.randn(2 * H, H, 1) * H ** -0.5, torch.zeros(2 * H), dev, K=1)
+            for name, fl, fn in (
+                    ("wn_in k5 gate", 2.0 * 2 * H * H * 5 * T * B,
+                     lambda n: launch_conv(l_in, x, 0, H * ld, acts, 0, H * ld, B, T, epi=EPI_GATE, bias_b=cond,
+                                           bias_b_bs=2 * H, rows=2 * H, x_ld=ld, out_ld=ld, loaders=n)),
+                    ("wn_rs 1x1", 2.0 * 2 * H * H * T * B,
+                     lambda n: launch_conv(l_rs, acts, 0, H * ld, x, 0, H * ld, B, T, epi=EPI_RESSKIP, out2=skip,
+                                           out2_bs=H * ld, mask=mask, mask_bs=ld, split=H, x_ld=ld, out_ld=ld,
+                                           loaders=n))):
+                for nld in args.loaders:
+                    try:
+                        for _ in range(2):
+                            fn(nld)
+                    except OvError:
+                        continue
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(10):
+                        fn(nld)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1) / 10
+                    print(f"{name:>14} ld={ld} nld={nld} {ms:8.4f} ms {fl / ms / 1e9:7.1f} TF/s "
+                          f"{100 * fl / ms / 1e9 / PEAK:6.1f} %", flush=True)
     print("done")
 
 
