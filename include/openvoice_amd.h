@@ -98,6 +98,7 @@ typedef struct ov_conv1d_params {
   int32_t tile;          /* 0 = chosen by the dispatcher; else 1 + tile id (128x128, 64x256,
                           * 32x512, 32x256) -- tuning / measurement knob                         */
   int32_t loaders;       /* loader waves per workgroup: 0 = chosen by the dispatcher, else 1/2/4 */
+  int32_t chunk;         /* input channels per LDS fill: 0 = default (32 for 1x1, else 16), or 16/32 */
   float in_slope;        /* leaky-ReLU slope applied to x while staging (1.0f = identity)        */
   float scale;
 } ov_conv1d_params;

@@ -33,6 +33,7 @@ class ConvParams(ctypes.Structure):
         ("Cout", ctypes.c_int32), ("K", ctypes.c_int32), ("dil", ctypes.c_int32), ("epi", ctypes.c_int32),
         ("flags", ctypes.c_int32), ("split", ctypes.c_int32), ("phase_s", ctypes.c_int32),
         ("tiles_per_wg", ctypes.c_int32), ("tile", ctypes.c_int32), ("loaders", ctypes.c_int32),
+        ("chunk", ctypes.c_int32),
         ("in_slope", ctypes.c_float), ("scale", ctypes.c_float),
     ]
 

@@ -38,7 +38,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int UNIT = 8;    // input channels per unrolled unit (4 ci-pairs x K taps)
 constexpr int REC = 256;   // floats per packed-weight record (64 lanes x 4 k-steps)
-constexpr int LB = 12;     // loader: 16-byte (or 4-byte) loads kept in flight per lane
+constexpr int LB_MAX = 12;  // loader: at most this many 16-byte (or 4-byte) loads in flight per lane
 
 // units are padded to a multiple of 4 (the largest units-per-chunk of any kernel variant)
 __host__ __device__ inline int packed_units(int cin) { return ((cin + UNIT - 1) / UNIT + 3) / 4 * 4; }
@@ -209,8 +209,10 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
 // CHUNK input channels per LDS fill; VEC: 16-byte staging loads (needs x_ld % 4 == 0 and 16-byte
 // aligned rows; L itself may be ragged); EPI: epilogue kind (OV_EPI_*); NLD: loader waves (the
 // staging items of a chunk are dealt round-robin to them, so NLD x LB x 64 loads are in flight).
+// The gate epilogue lands at 130 VGPRs on its own; it is held to 128 (4 waves per SIMD, 1-2 VGPRs
+// spilled in the epilogue) because the third workgroup per CU is worth more than the spill costs.
 template <int K, int DIL, int WM, int WN, int WVM, int WVN, int CHUNK, bool VEC, int EPI, int NLD>
-__global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_mfma_kernel(const ov_conv1d_params p,
+__global__ __launch_bounds__(64 * (4 + NLD), EPI == OV_EPI_GATE ? 4 : 1) void conv1d_mfma_kernel(const ov_conv1d_params p,
                                                                      const int tiles_per_wg) {
   static_assert(WVM * WVN == 4, "4 matrix waves per workgroup");
   static_assert(CHUNK % UNIT == 0 && (CHUNK / UNIT == 2 || CHUNK / UNIT == 4), "chunk = 2 or 4 units");
@@ -222,7 +224,10 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_mfma_kernel(const ov_co
   constexpr int XS4 = XS / 4;
   constexpr int BUF = CHUNK * XS;       // floats per LDS buffer
   constexpr int NITEM = VEC ? CHUNK * XS4 : CHUNK * XS;
-  constexpr int NBATCH = (NITEM + 64 * NLD * LB - 1) / (64 * NLD * LB);
+  // loads in flight per loader lane: the whole chunk in one batch when that needs <= LB_MAX of them
+  constexpr int PER_LANE = (NITEM + 64 * NLD - 1) / (64 * NLD);
+  constexpr int LB = PER_LANE < LB_MAX ? PER_LANE : LB_MAX;
+  constexpr int NBATCH = (PER_LANE + LB - 1) / LB;
   static_assert(NLD == 1 || NLD == 2 || NLD == 4, "1, 2 or 4 loader waves");
 
   __shared__ __attribute__((aligned(16))) float xs[2 * BUF];
@@ -238,7 +243,12 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_mfma_kernel(const ov_co
   const int tile_begin = blockIdx.x * tiles_per_wg;
   const int tile_end = min(ntiles, tile_begin + tiles_per_wg);
 
-  if (wave >= 4) {
+  // Written as a chain of equalities on purpose: with `wave >= 4` hipcc (ROCm 7.2) allocates 12 more
+  // VGPRs for the matrix path (132 instead of 120), which costs a wave per SIMD and 5-25 % on MI355X.
+  bool is_loader = false;
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) is_loader |= (wave == 4 + i);
+  if (is_loader) {
     // ================================ loader waves ===============================================
     const float* __restrict__ xb = p.x + (int64_t)b * p.x_bstride;
     const float slope = p.in_slope;
@@ -338,31 +348,41 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_mfma_kernel(const ov_co
     for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
       __syncthreads();  // loader finished buffer (it & 1); we finished reading the other one
       const float* xl = xs + (it & 1) * BUF + xl_off;
+      // One k-step = one ci pair x one tap = WM*WN MFMAs (256 cycles of matrix pipe).  The B operands
+      // of k-step s+1 are read from LDS while the MFMAs of k-step s run (explicit double buffer,
+      // pinned by sched_barrier): left to itself hipcc issues each ds_read right before the MFMA that
+      // consumes it and the wave eats the LDS latency every k-step (-15...35 % on MI355X).
+      constexpr int STEPS = UPC * 4 * K;
+      float bcur[WN], bnxt[WN];
 #pragma unroll
-      for (int uu = 0; uu < UPC; ++uu) {
-        const float* xu = xl + uu * UNIT * XS;
+      for (int j = 0; j < WN; ++j) bcur[j] = xl[32 * j];   // k-step 0: unit 0, pair 0, tap 0
 #pragma unroll
-        for (int g = 0; g < K; ++g) {
+      for (int sa = 0; sa < STEPS; ++sa) {
+        const int u = sa & 3;
+        if (u == 0) {
           ++rec;  // the record after the last real one is zero padding written by the packer
 #pragma unroll
           for (int i = 0; i < WM; ++i) a_nxt[i] = (wbase + (size_t)rec * 64)[widx[i]];
-          // Pin the prefetch here: without this hipcc sinks the loads next to their first use and
-          // every group starts with an L2-latency stall.
-          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (sa + 1 < STEPS) {
+          const int uu = (sa + 1) / (4 * K), sn = (sa + 1) - uu * (4 * K);
+          const int pp = sn / K, tap = sn - pp * K;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int s = 4 * g + u;
-            const int pp = s / K, tap = s - pp * K;
-            float bv[WN];
+          for (int j = 0; j < WN; ++j) bnxt[j] = xl[(uu * UNIT + 2 * pp) * XS + 32 * j + tap * DIL];
+        }
+        // Pin the prefetches here: without this hipcc sinks the loads next to their first use.
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < WN; ++j) bv[j] = xu[(2 * pp) * XS + 32 * j + tap * DIL];
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][u], bcur[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (sa + 1 < STEPS) {
 #pragma unroll
-              for (int j = 0; j < WN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][u], bv[j], acc[i][j], 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
+          for (int j = 0; j < WN; ++j) bcur[j] = bnxt[j];
+        }
+        if (u == 3) {
 #pragma unroll
           for (int i = 0; i < WM; ++i) a_cur[i] = a_nxt[i];
         }
@@ -397,7 +417,7 @@ int conv1d_launch(const ov_conv1d_params* p, hipStream_t stream) {
 enum { TILE_128x128 = 0, TILE_64x256 = 1, TILE_32x512 = 2, TILE_32x256 = 3 };
 
 struct ConvVariant {
-  int K, dil, tile, vec, epi, nld;
+  int K, dil, tile, chunk, vec, epi, nld;
   conv_launch_fn fn;
 };
 
@@ -414,7 +434,8 @@ struct ConvVariant {
   template __global__ void conv1d_mfma_kernel<K, DIL, OV_TILE_##TILE, CHUNK, (VEC) != 0, EPI, NLD>(           \
       const ov_conv1d_params, const int);
 #define OV_X_ROW(K, DIL, TILE, CHUNK, VEC, EPI, NLD)                                                         \
-  {K, DIL, TILE_##TILE, VEC, EPI, NLD, conv1d_launch<K, DIL, OV_TILE_##TILE, CHUNK, (VEC) != 0, EPI, NLD>},
+  {K, DIL, TILE_##TILE, CHUNK, VEC, EPI, NLD,                                                                \
+   conv1d_launch<K, DIL, OV_TILE_##TILE, CHUNK, (VEC) != 0, EPI, NLD>},
 #if defined(__HIP_DEVICE_COMPILE__)
 #define OV_DEFINE_VARIANTS(table, LIST) LIST(OV_X_INST)
 #else
@@ -435,6 +456,7 @@ OV_DECLARE_VARIANTS(kVariantsB2)
 OV_DECLARE_VARIANTS(kVariantsC1)
 OV_DECLARE_VARIANTS(kVariantsC2)
 OV_DECLARE_VARIANTS(kVariantsD)
+OV_DECLARE_VARIANTS(kVariantsE)
 OV_DECLARE_VARIANTS(kVariantsS)
 OV_DECLARE_VARIANTS(kVariantsW)
 

@@ -98,15 +98,19 @@ __global__ void sequence_mask_kernel(const int64_t* __restrict__ lengths, float*
   if (t < T) mask[(int64_t)b * ld + t] = t < lengths[b] ? 1.f : 0.f;
 }
 
-static conv_launch_fn find_variant(int K, int dil, int tile, int vec, int epi, int nld) {
+// chunk = 0 matches the default chunk of the (K) class: 32 channels for 1x1, 16 otherwise.
+static conv_launch_fn find_variant(int K, int dil, int tile, int chunk, int vec, int epi, int nld) {
+  if (chunk == 0) chunk = K == 1 ? 32 : 16;
   const ConvVariant* tabs[] = {kVariantsA1, kVariantsA2, kVariantsB1, kVariantsB2, kVariantsC1,
-                               kVariantsC2, kVariantsD,  kVariantsS,  kVariantsW};
+                               kVariantsC2, kVariantsD,  kVariantsE,  kVariantsS,  kVariantsW};
   const int ns[] = {kVariantsA1Count, kVariantsA2Count, kVariantsB1Count, kVariantsB2Count, kVariantsC1Count,
-                    kVariantsC2Count, kVariantsDCount,  kVariantsSCount,  kVariantsWCount};
+                    kVariantsC2Count, kVariantsDCount,  kVariantsECount,  kVariantsSCount,  kVariantsWCount};
   for (unsigned t = 0; t < sizeof(ns) / sizeof(ns[0]); ++t)
     for (int i = 0; i < ns[t]; ++i) {
       const ConvVariant& v = tabs[t][i];
-      if (v.K == K && v.dil == dil && v.tile == tile && v.vec == vec && v.epi == epi && v.nld == nld) return v.fn;
+      if (v.K == K && v.dil == dil && v.tile == tile && v.chunk == chunk && v.vec == vec && v.epi == epi &&
+          v.nld == nld)
+        return v.fn;
     }
   return nullptr;
 }
@@ -188,6 +192,7 @@ int ov_conv1d_f32(const ov_conv1d_params* pin, ov_stream_t stream) {
       return OV_E_ALIGN;
   }
   if ((reinterpret_cast<uintptr_t>(p->w) & 15)) return OV_E_ALIGN;
+  if (p->chunk != 0 && p->chunk != 16 && p->chunk != 32) return OV_E_BADARG;
   if (p->tile < 0 || p->tile > 4 || (p->loaders != 0 && p->loaders != 1 && p->loaders != 2 && p->loaders != 4))
     return OV_E_BADARG;
   int tile = TILE_128x128;
@@ -204,7 +209,8 @@ int ov_conv1d_f32(const ov_conv1d_params* pin, ov_stream_t stream) {
     if (p->loaders) { pref[0] = pref[1] = pref[2] = p->loaders; }
     else loader_preference(tiles_try[ti], p->K, pref);
     for (int vec = can_vec ? 1 : 0; vec >= 0 && !fn; --vec)
-      for (int li = 0; li < 3 && !fn; ++li) fn = find_variant(p->K, p->dil, tiles_try[ti], vec, epi, pref[li]);
+      for (int li = 0; li < 3 && !fn; ++li)
+        fn = find_variant(p->K, p->dil, tiles_try[ti], p->chunk, vec, epi, pref[li]);
   }
   if (!fn) return OV_E_UNSUPPORTED;
   return fn(p, static_cast<hipStream_t>(stream));

@@ -89,7 +89,7 @@ def conv_transpose_as_conv(w, stride):
 def launch_conv(layer, x, x_off, x_bs, out, out_off, out_bs, B, L, epi=EPI_LINEAR, flags=0, in_slope=1.0,
                 scale=1.0, res=None, res_off=0, res_bs=0, add=None, add_bs=0, out2=None, out2_bs=0, mask=None,
                 bias_b=None, bias_b_off=0, bias_b_bs=0, split=0, phase_s=1, cin=None, rows=None, tiles_per_wg=0,
-                x_ld=0, out_ld=0, mask_bs=0, tile=0, loaders=0):
+                x_ld=0, out_ld=0, mask_bs=0, tile=0, loaders=0, chunk=0):
     """Fill ``ov_conv1d_params`` and launch on torch's current stream of ``x``'s device.
     Offsets, row strides (``*_ld``, 0 = dense) and batch strides are in elements."""
     p = ConvParams()
@@ -108,7 +108,7 @@ def launch_conv(layer, x, x_off, x_bs, out, out_off, out_bs, B, L, epi=EPI_LINEA
     p.Cout = layer.cout
     p.K, p.dil, p.epi, p.flags, p.split, p.phase_s = layer.K, layer.dil, epi, flags, split, phase_s
     p.in_slope, p.scale = in_slope, scale
-    p.tiles_per_wg, p.tile, p.loaders = tiles_per_wg, tile, loaders
+    p.tiles_per_wg, p.tile, p.loaders, p.chunk = tiles_per_wg, tile, loaders, chunk
     p.x_ld, p.out_ld, p.mask_bstride = x_ld, out_ld, mask_bs
     stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(_lib.load().ov_conv1d_f32(ctypes.byref(p), stream), "ov_conv1d_f32")

@@ -323,3 +323,16 @@ def test_forced_variant_that_does_not_exist_is_an_error():
     x, out = torch.zeros(B, c, L, device=DEV), torch.zeros(B, c, L, device=DEV)
     with pytest.raises(_lib.OvError, match="OV_E_UNSUPPORTED"):
         launch_conv(layer, x, 0, c * L, out, 0, c * L, B, L, tile=3)   # no k=5 32x512 instantiation
+
+
+@pytest.mark.parametrize("c,d", [(128, 1), (256, 5), (64, 3), (64, 1)])
+def test_k3_with_32_channel_chunks(c, d):
+    """The k = 3 MRF convs also exist with 32-channel LDS chunks (ov_conv1d_params.chunk = 32)."""
+    B, L, k = 2, 1096, 3
+    x, res = _rand(B, c, L, seed=1), _rand(B, c, L, seed=2)
+    w, bias = _rand(c, c, k, seed=3, scale=(c * k) ** -0.5), _rand(c, seed=4, scale=0.1)
+    ref = F.conv1d(F.leaky_relu(x, 0.1), w, bias, dilation=d, padding=d) + res
+    layer = PackedConv(w, bias, DEV, K=k, dil=d)
+    out = torch.full((B, c, L), float("nan"), device=DEV)
+    launch_conv(layer, x.to(DEV), 0, c * L, out, 0, c * L, B, L, in_slope=0.1, res=res.to(DEV), res_bs=c * L, chunk=32)
+    _close(out, ref, what=f"C={c} k=3 d={d} chunk=32")

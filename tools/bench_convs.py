@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--tpw", type=int, nargs="+", default=[0])
     ap.add_argument("--loaders", type=int, nargs="+", default=[0])
     ap.add_argument("--tiles", type=int, nargs="+", default=[0])
+    ap.add_argument("--chunks", type=int, nargs="+", default=[0])
     ap.add_argument("--channels", type=int, nargs="+", default=[256, 128, 64, 32])
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
@@ -35,7 +36,7 @@ def main():
     stages = [(256, 6888), (128, 55104), (64, 110208), (32, 220416)]
     from openvoice_amd._lib import OvError
     print(f"B={B}")
-    print(f"{'C':>4} {'L':>7} {'k':>2} {'d':>1} {'epi':>8} {'tile':>4} {'nld':>3} {'tpw':>3} {'ms':>8} {'TF/s':>7} {'%peak':>6}")
+    print(f"{'C':>4} {'L':>7} {'k':>2} {'d':>1} {'epi':>8} {'tile':>4} {'nld':>3} {'ch':>2} {'tpw':>3} {'ms':>8} {'TF/s':>7} {'%peak':>6}")
     for c, L in stages:
         if c not in args.channels:
             continue
@@ -47,8 +48,9 @@ def main():
             for d, mode in ((1, "plain"), (5, "plain"), (1, "res+add")):
                 w = torch.randn(c, c, k) * (c * k) ** -0.5
                 layer = PackedConv(w, torch.zeros(c), dev, K=k, dil=d)
-                for tile, nld, tpw in [(t, n, w_) for t in args.tiles for n in args.loaders for w_ in args.tpw]:
-                    kw = dict(in_slope=0.1, tiles_per_wg=tpw, tile=tile, loaders=nld)
+                for tile, nld, tpw, chunk in [(t, n, w_, ch) for t in args.tiles for n in args.loaders
+                                              for w_ in args.tpw for ch in args.chunks]:
+                    kw = dict(in_slope=0.1, tiles_per_wg=tpw, tile=tile, loaders=nld, chunk=chunk)
                     if mode != "plain":
                         kw.update(res=res, res_bs=c * L, add=add, add_bs=c * L, scale=1.0 / 3.0)
                     try:
@@ -64,7 +66,7 @@ def main():
                     torch.cuda.synchronize()
                     ms = e0.elapsed_time(e1) / args.reps
                     tf = 2.0 * c * c * k * L * B / ms / 1e9
-                    print(f"{c:>4} {L:>7} {k:>2} {d:>1} {mode:>8} {tile:>4} {nld:>3} {tpw:>3} {ms:8.3f} {tf:7.1f} "
+                    print(f"{c:>4} {L:>7} {k:>2} {d:>1} {mode:>8} {tile:>4} {nld:>3} {chunk:>2} {tpw:>3} {ms:8.3f} {tf:7.1f} "
                           f"{100 * tf / PEAK:6.1f}", flush=True)
         del x, res, add, out
     if args.wn:
