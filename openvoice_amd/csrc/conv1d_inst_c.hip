@@ -1,4 +1,5 @@
-// Tile 32x512: MRF stage 3 (C = 32); 4 loader waves.
+// MRF convs with C = 32: tile 32x512 (1x4 matrix waves, 32x128 per wave), 16-channel chunks (two per
+// tile, 66 KB LDS, 2 workgroups per CU), 4 loader waves.
 #include "conv1d_mfma.h"
 namespace ovk {
 #define LIST(X) \
@@ -11,5 +12,5 @@ namespace ovk {
   X(11, 1, 32x512, 16, 1, OV_EPI_LINEAR, 4) \
   X(11, 3, 32x512, 16, 1, OV_EPI_LINEAR, 4) \
   X(11, 5, 32x512, 16, 1, OV_EPI_LINEAR, 4)
-OV_DEFINE_VARIANTS(kVariantsC2, LIST)
+OV_DEFINE_VARIANTS(kVariantsC, LIST)
 }  // namespace ovk

@@ -54,7 +54,7 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? 
 // per element, so the element loops are straight-line code with 16 loads in flight.
 template <int EPI, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 (&acc)[WM][WN], int b, int tcol0,
-                                              int mtile0, int q, int lane) {
+                                              int mtile0, int q, int lane, bool preloaded) {
   const uint32_t L = (uint32_t)p.L;        // valid columns
   const uint32_t LD = (uint32_t)p.out_ld;  // row stride of out / res / add / out2
   const uint32_t half = (uint32_t)lane >> 5;
@@ -158,8 +158,9 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
         } else {
           const uint32_t voff = rbase * LD + col;   // the lane's only per-element offset
           if constexpr (EPI == OV_EPI_LINEAR) {
-            const float* resb = p.res ? p.res + (int64_t)b * p.res_bstride : nullptr;
-            const float* addb = p.add ? p.add + (int64_t)b * p.add_bstride : nullptr;
+            // `preloaded`: res and add already sit in the accumulators (conv_preload)
+            const float* resb = (p.res && !preloaded) ? p.res + (int64_t)b * p.res_bstride : nullptr;
+            const float* addb = (p.add && !preloaded) ? p.add + (int64_t)b * p.add_bstride : nullptr;
             const float mkv = (p.flags & OV_F_MASK_V) ? mk : 1.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] *= mkv;
@@ -203,6 +204,48 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
       }
     }
   }
+}
+
+// ---- accumulator initialisation -------------------------------------------------------------------
+// LINEAR with a residual (and the MRF running sum): the accumulators START as res (+ add) instead of
+// zero, so the epilogue has nothing to read.  The loads are issued at the top of the tile, where the
+// wave is about to wait an HBM round trip for the loaders' first chunk anyway; read in the epilogue
+// they cost one exposed round trip per 32x32 fragment with the matrix pipe idle (measured: +8...25 %
+// on the conv2 launches).  fp32 addition order changes (res first instead of last): ~1 ulp.
+// Returns true when res/add are now in `acc` (uniform across the workgroup).
+template <int EPI, int WM, int WN>
+__device__ __forceinline__ bool conv_preload(const ov_conv1d_params& p, f32x16 (&acc)[WM][WN], int b, int tcol0,
+                                             int mtile0, int lane) {
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if constexpr (EPI != OV_EPI_LINEAR) return false;
+  if (!p.res || (p.flags & OV_F_MASK_V)) return false;   // v*mask + res keeps the epilogue order
+  const uint32_t L = (uint32_t)p.L, LD = (uint32_t)p.out_ld, half = (uint32_t)lane >> 5;
+  const float* resb = p.res + (int64_t)b * p.res_bstride;
+  const float* addb = p.add ? p.add + (int64_t)b * p.add_bstride : nullptr;
+  const uint32_t col0 = (uint32_t)tcol0 + ((uint32_t)lane & 31u);
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const uint32_t mt = (uint32_t)(mtile0 + i);
+    if (mt * 32u >= (uint32_t)p.Cout) continue;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const uint32_t col = col0 + 32u * j;
+      if (col >= L) continue;
+      const uint32_t voff = (mt * 32u + 4u * half) * LD + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = (resb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff];
+      if (addb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += (addb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff];
+      }
+    }
+  }
+  return true;
 }
 
 // K taps, dilation DIL; wave tile = (32*WM) x (32*WN); WVM x WVN matrix waves per workgroup;
@@ -337,12 +380,7 @@ __global__ __launch_bounds__(64 * (4 + NLD), EPI == OV_EPI_GATE ? 4 : 1) void co
   int it = 0;
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     f32x16 acc[WM][WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-      for (int j = 0; j < WN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const bool preloaded = conv_preload<EPI, WM, WN>(p, acc, b, tile * N_BLK + wn * (32 * WN), mtile0, lane);
 
     int rec = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
@@ -393,7 +431,8 @@ __global__ __launch_bounds__(64 * (4 + NLD), EPI == OV_EPI_GATE ? 4 : 1) void co
 #pragma unroll
       for (int i = 0; i < WM; ++i) a_cur[i] = wbase[widx[i]];
     }
-    conv_epilogue<EPI, WM, WN>(p, acc, b, tile * N_BLK + wn * (32 * WN), mtile0, blockIdx.y * WVM + wm, lane);
+    conv_epilogue<EPI, WM, WN>(p, acc, b, tile * N_BLK + wn * (32 * WN), mtile0, blockIdx.y * WVM + wm, lane,
+                               preloaded);
   }
 }
 
@@ -449,12 +488,9 @@ struct ConvVariant {
 #define OV_DECLARE_VARIANTS(table)  \
   extern const ConvVariant table[]; \
   extern const int table##Count;
-OV_DECLARE_VARIANTS(kVariantsA1)
-OV_DECLARE_VARIANTS(kVariantsA2)
-OV_DECLARE_VARIANTS(kVariantsB1)
-OV_DECLARE_VARIANTS(kVariantsB2)
-OV_DECLARE_VARIANTS(kVariantsC1)
-OV_DECLARE_VARIANTS(kVariantsC2)
+OV_DECLARE_VARIANTS(kVariantsA)
+OV_DECLARE_VARIANTS(kVariantsB)
+OV_DECLARE_VARIANTS(kVariantsC)
 OV_DECLARE_VARIANTS(kVariantsD)
 OV_DECLARE_VARIANTS(kVariantsE)
 OV_DECLARE_VARIANTS(kVariantsS)

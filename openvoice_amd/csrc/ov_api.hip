@@ -98,13 +98,10 @@ __global__ void sequence_mask_kernel(const int64_t* __restrict__ lengths, float*
   if (t < T) mask[(int64_t)b * ld + t] = t < lengths[b] ? 1.f : 0.f;
 }
 
-// chunk = 0 matches the default chunk of the (K) class: 32 channels for 1x1, 16 otherwise.
 static conv_launch_fn find_variant(int K, int dil, int tile, int chunk, int vec, int epi, int nld) {
-  if (chunk == 0) chunk = K == 1 ? 32 : 16;
-  const ConvVariant* tabs[] = {kVariantsA1, kVariantsA2, kVariantsB1, kVariantsB2, kVariantsC1,
-                               kVariantsC2, kVariantsD,  kVariantsE,  kVariantsS,  kVariantsW};
-  const int ns[] = {kVariantsA1Count, kVariantsA2Count, kVariantsB1Count, kVariantsB2Count, kVariantsC1Count,
-                    kVariantsC2Count, kVariantsDCount,  kVariantsECount,  kVariantsSCount,  kVariantsWCount};
+  const ConvVariant* tabs[] = {kVariantsA, kVariantsB, kVariantsC, kVariantsD, kVariantsE, kVariantsS, kVariantsW};
+  const int ns[] = {kVariantsACount, kVariantsBCount, kVariantsCCount, kVariantsDCount,
+                    kVariantsECount, kVariantsSCount, kVariantsWCount};
   for (unsigned t = 0; t < sizeof(ns) / sizeof(ns[0]); ++t)
     for (int i = 0; i < ns[t]; ++i) {
       const ConvVariant& v = tabs[t][i];
@@ -115,12 +112,19 @@ static conv_launch_fn find_variant(int K, int dil, int tile, int chunk, int vec,
   return nullptr;
 }
 
-// Loader-wave preference order for a (tile, K) class; the first instantiated one wins.  Chosen from
-// the per-shape measurements in profiles/ (tools/bench_convs.py --loaders ...).
+// Tuning choices, from the per-shape sweeps under profiles/ (tools/bench_convs.py):
+//  * loader waves: 4 for 1x1 convs and for the 64- and 32-row tiles (a chunk is consumed in
+//    1.7-2.5 us of matrix work there), 2 for 128x128; 1 was never best once the kernels fit 4
+//    waves per SIMD;
+//  * channels per LDS chunk: 32 wherever the double buffer still allows >= 2 workgroups per CU
+//    (fewer chunk hand-offs: +1...10 %), 16 for the 32-row tiles.
 static void loader_preference(int tile, int K, int out[3]) {
-  if (K == 1) { out[0] = 4; out[1] = 2; out[2] = 1; return; }
-  if (tile == TILE_128x128) { out[0] = 2; out[1] = 1; out[2] = 4; return; }
-  out[0] = 4; out[1] = 2; out[2] = 1;
+  if (K == 1 || tile != TILE_128x128) { out[0] = 4; out[1] = 2; out[2] = 1; return; }
+  out[0] = 2; out[1] = 4; out[2] = 1;
+}
+static void chunk_preference(int tile, int K, int out[2]) {
+  if (K != 1 && (tile == TILE_32x512 || tile == TILE_32x256)) { out[0] = 16; out[1] = 32; return; }
+  out[0] = 32; out[1] = 16;
 }
 
 }  // namespace ovk
@@ -202,15 +206,19 @@ int ov_conv1d_f32(const ov_conv1d_params* pin, ov_stream_t stream) {
   const bool can_vec = (p->x_ld % 4 == 0) && !(reinterpret_cast<uintptr_t>(p->x) & 15) && (p->x_bstride % 4 == 0);
   int pref[3];
   conv_launch_fn fn = nullptr;
-  // forced tile / loader count: exact match or OV_E_UNSUPPORTED (measurement knobs must not silently
+  // forced tile / loader count / chunk: exact match or OV_E_UNSUPPORTED (measurement knobs must not silently
   // fall back); otherwise the preferred tile, then 128x128, 16-byte staging before 4-byte.
   const int tiles_try[2] = {tile, p->tile > 0 ? tile : (int)TILE_128x128};
+  int cpref[2];
   for (int ti = 0; ti < 2 && !fn; ++ti) {
     if (p->loaders) { pref[0] = pref[1] = pref[2] = p->loaders; }
     else loader_preference(tiles_try[ti], p->K, pref);
+    if (p->chunk) { cpref[0] = cpref[1] = p->chunk; }
+    else chunk_preference(tiles_try[ti], p->K, cpref);
     for (int vec = can_vec ? 1 : 0; vec >= 0 && !fn; --vec)
-      for (int li = 0; li < 3 && !fn; ++li)
-        fn = find_variant(p->K, p->dil, tiles_try[ti], p->chunk, vec, epi, pref[li]);
+      for (int ci = 0; ci < 2 && !fn; ++ci)
+        for (int li = 0; li < 3 && !fn; ++li)
+          fn = find_variant(p->K, p->dil, tiles_try[ti], cpref[ci], vec, epi, pref[li]);
   }
   if (!fn) return OV_E_UNSUPPORTED;
   return fn(p, static_cast<hipStream_t>(stream));

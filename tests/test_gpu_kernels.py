@@ -299,13 +299,13 @@ def test_conv_transpose_from_padded_rows(s, cin, cout, L):
     _close(out, ref, what=f"convT from padded rows s={s}")
 
 
-@pytest.mark.parametrize("c,tile,loaders", [(32, 3, 1), (32, 3, 2), (32, 3, 4), (32, 4, 2), (32, 4, 4),
-                                            (64, 2, 1), (64, 2, 2), (64, 2, 4), (128, 1, 1), (128, 1, 2),
-                                            (32, 1, 2), (64, 1, 1)])
+@pytest.mark.parametrize("c,tile,loaders,chunk", [(32, 3, 4, 16), (32, 4, 4, 16), (64, 2, 4, 32), (64, 2, 4, 16),
+                                                  (128, 1, 2, 32), (128, 1, 2, 16), (256, 1, 2, 32),
+                                                  (32, 1, 2, 32), (64, 1, 2, 16)])
 @pytest.mark.parametrize("k,d", [(3, 1), (7, 3), (11, 5)])
-def test_every_tile_and_loader_count(c, tile, loaders, k, d):
-    """All (tile, loader-wave count) instantiations of the MRF convs give the same answer: tile ids
-    1..4 = 128x128, 64x256, 32x512, 32x256; forcing one must not fall back silently."""
+def test_every_tile_chunk_and_loader_count(c, tile, loaders, chunk, k, d):
+    """All (tile, channels-per-chunk, loader-wave count) instantiations of the MRF convs give the same
+    answer: tile ids 1..4 = 128x128, 64x256, 32x512, 32x256; forcing one must not fall back silently."""
     B, L = 2, 2312
     x, res = _rand(B, c, L, seed=1), _rand(B, c, L, seed=2)
     w, bias = _rand(c, c, k, seed=3, scale=(c * k) ** -0.5), _rand(c, seed=4, scale=0.1)
@@ -313,8 +313,8 @@ def test_every_tile_and_loader_count(c, tile, loaders, k, d):
     layer = PackedConv(w, bias, DEV, K=k, dil=d)
     out = torch.full((B, c, L), float("nan"), device=DEV)
     launch_conv(layer, x.to(DEV), 0, c * L, out, 0, c * L, B, L, in_slope=0.1, res=res.to(DEV), res_bs=c * L,
-                tile=tile, loaders=loaders)
-    _close(out, ref, what=f"C={c} k={k} d={d} tile={tile} loaders={loaders}")
+                tile=tile, loaders=loaders, chunk=chunk)
+    _close(out, ref, what=f"C={c} k={k} d={d} tile={tile} loaders={loaders} chunk={chunk}")
 
 
 def test_forced_variant_that_does_not_exist_is_an_error():
@@ -325,14 +325,18 @@ def test_forced_variant_that_does_not_exist_is_an_error():
         launch_conv(layer, x, 0, c * L, out, 0, c * L, B, L, tile=3)   # no k=5 32x512 instantiation
 
 
-@pytest.mark.parametrize("c,d", [(128, 1), (256, 5), (64, 3), (64, 1)])
-def test_k3_with_32_channel_chunks(c, d):
-    """The k = 3 MRF convs also exist with 32-channel LDS chunks (ov_conv1d_params.chunk = 32)."""
-    B, L, k = 2, 1096, 3
-    x, res = _rand(B, c, L, seed=1), _rand(B, c, L, seed=2)
-    w, bias = _rand(c, c, k, seed=3, scale=(c * k) ** -0.5), _rand(c, seed=4, scale=0.1)
-    ref = F.conv1d(F.leaky_relu(x, 0.1), w, bias, dilation=d, padding=d) + res
-    layer = PackedConv(w, bias, DEV, K=k, dil=d)
-    out = torch.full((B, c, L), float("nan"), device=DEV)
-    launch_conv(layer, x.to(DEV), 0, c * L, out, 0, c * L, B, L, in_slope=0.1, res=res.to(DEV), res_bs=c * L, chunk=32)
-    _close(out, ref, what=f"C={c} k=3 d={d} chunk=32")
+def test_residual_is_preloaded_only_without_value_mask():
+    """LINEAR with a residual starts the accumulators at res (+ add); with OV_F_MASK_V the reference
+    order v*mask + res must be kept (the mask must not touch the residual)."""
+    B, C, L, k = 2, 64, 777, 3
+    x, res, add = _rand(B, C, L, seed=1), _rand(B, C, L, seed=2), _rand(B, C, L, seed=3)
+    w, bias = _rand(C, C, k, seed=4, scale=0.1), _rand(C, seed=5)
+    mask = (torch.arange(L)[None, :] < torch.tensor([L, 300])[:, None]).float()
+    conv = F.conv1d(x, w, bias, padding=1)
+    layer = PackedConv(w, bias, DEV, K=k)
+    out = torch.full((B, C, L), float("nan"), device=DEV)
+    launch_conv(layer, x.to(DEV), 0, C * L, out, 0, C * L, B, L, res=res.to(DEV), res_bs=C * L, add=add.to(DEV),
+                add_bs=C * L, scale=0.5, flags=F_MASK_V, mask=mask.to(DEV))
+    _close(out, (conv * mask[:, None] + res + add) * 0.5, what="mask_v + res + add")
+    launch_conv(layer, x.to(DEV), 0, C * L, out, 0, C * L, B, L, res=res.to(DEV), res_bs=C * L, scale=0.5)
+    _close(out, (conv + res) * 0.5, what="res only")
