@@ -26,6 +26,33 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PMC_TRAFFIC_FILE = os.path.join(REPO, "profiles", "pmc_traffic_latest.json")
+
+
+def mrf_alg_bytes_per_launch(cfg, B, frames):
+    """Algorithmic HBM bytes of the average MRF launch: conv1 reads x and writes
+    t (2 tensor passes), conv2 reads t and the residual and writes (3), the last conv2 of ResBlocks 2
+    and 3 also reads the running MRF sum (+1 each); tensor = B * C * L * 4 bytes per stage."""
+    ch, L, total, launches = cfg["upsample_initial_channel"], frames, 0.0, 0
+    nk, nd = len(cfg["resblock_kernel_sizes"]), len(cfg["resblock_dilation_sizes"][0])
+    for u in cfg["upsample_rates"]:
+        ch //= 2
+        L *= u
+        passes = nk * nd * (2 + 3) + (nk - 1)
+        total += passes * 4.0 * B * ch * L
+        launches += nk * nd * 2
+    return total / launches
+
+
+def pmc_traffic():
+    """HBM bytes per MRF launch measured with rocprofv3 PMC counters in a separate run of this same
+    command (scripts/gpu_session.sh, tools/pmc_traffic.py); None when no summary is committed."""
+    try:
+        with open(PMC_TRAFFIC_FILE) as fh:
+            rec = json.load(fh)
+        return rec.get("calibrated", rec["nominal"])["bytes_per_launch"], rec
+    except (OSError, KeyError, ValueError):
+        return None, None
 SAMPLE_RATE = 22050
 
 
@@ -162,6 +189,8 @@ def main():
         rec[2] += e0.elapsed_time(e1) * 1e-3
     n_mrf, f_mrf, t_mrf = by_tag["mrf"]
     achieved = f_mrf / t_mrf / 1e12
+    traffic, traffic_rec = pmc_traffic()
+    alg_bytes = mrf_alg_bytes_per_launch(cfg, B, frames)
     all_flops = sum(r[1] for r in by_tag.values())
     all_conv_s = sum(r[2] for r in by_tag.values())
 
@@ -190,7 +219,9 @@ def main():
                        "parallelism": f"dp{world} (utterance sharding, RCCL broadcast of src/tgt se)"},
             "per_batch_latency_rtf": round(args.seconds / (ms * 1e-3), 2),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per MRF launch (rocprofv3 PMC, profiles/pmc_traffic_latest.json)",
+                         "alg_bytes_per_launch": round(alg_bytes),
                          "kernel": "ovk::conv1d_mfma_kernel on the MRF ResBlock convs",
                          "launches_per_step": n_mrf, "avg_launch_ms": round(t_mrf / n_mrf * 1e3, 4),
                          "alg_gflop_per_launch": round(f_mrf / n_mrf / 1e9, 2),

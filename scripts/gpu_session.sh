@@ -31,5 +31,6 @@ if [ "${PROFILE:-0}" = "1" ]; then
   echo "== pmc fetch" ; (cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OLDPWD/gpurun_out/pmc_fetch" -o r1 --output-format csv -- python "$OLDPWD/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --pmc-calibration > "$OLDPWD/gpurun_out/pmc_fetch.log" 2>&1)
   echo "== pmc write" ; (cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OLDPWD/gpurun_out/pmc_write" -o r1 --output-format csv -- python "$OLDPWD/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --pmc-calibration > "$OLDPWD/gpurun_out/pmc_write.log" 2>&1)
   python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write > gpurun_out/pmc_summary.txt 2>&1; tail -30 gpurun_out/pmc_summary.txt
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > gpurun_out/pmc_traffic.json 2>gpurun_out/pmc_traffic.err; cat gpurun_out/pmc_traffic.json
   find gpurun_out -name '*kernel_trace.csv' -size +20M -delete
 fi
