@@ -112,6 +112,153 @@ def converter_param_spec(spec_channels, inter_channels, hidden_channels, resbloc
     return spec
 
 
+# ---- V1 base-speaker TTS (n_speakers > 0): text encoder, duration predictors, speaker table ----------
+SDP_FILTER = 192          # StochasticDurationPredictor(hidden, 192, 3, 0.5, 4) -- reference: openvoice/models.py:461
+SDP_KERNEL = 3
+SDP_FLOWS = 4
+SDP_DDS_LAYERS = 3
+SDP_NUM_BINS = 10         # ConvFlow defaults, reference: openvoice/modules.py:466-467
+SDP_TAIL_BOUND = 5.0
+DP_FILTER = 256           # DurationPredictor(hidden, 256, 3, 0.5) -- reference: openvoice/models.py:462
+DP_KERNEL = 3
+ATTN_WINDOW = 4           # attentions.Encoder default window_size, reference: openvoice/attentions.py:46
+
+
+def _dds(spec, prefix, channels, kernel, n_layers):
+    """DDSConv parameters (reference: openvoice/modules.py:84-115)."""
+    for i in range(n_layers):
+        spec[f"{prefix}.convs_sep.{i}.weight"] = (channels, 1, kernel)
+        spec[f"{prefix}.convs_sep.{i}.bias"] = (channels,)
+    for i in range(n_layers):
+        spec[f"{prefix}.convs_1x1.{i}.weight"] = (channels, channels, 1)
+        spec[f"{prefix}.convs_1x1.{i}.bias"] = (channels,)
+    for name in ("norms_1", "norms_2"):
+        for i in range(n_layers):
+            spec[f"{prefix}.{name}.{i}.gamma"] = (channels,)
+            spec[f"{prefix}.{name}.{i}.beta"] = (channels,)
+
+
+def _sdp_flows(spec, prefix, filt):
+    """ElementwiseAffine(2) + 4 x (ConvFlow(2, filt, 3, n_layers=3), Flip) -- reference:
+    openvoice/models.py:113-127; Flip (even indices 2, 4, ..) owns no parameters."""
+    spec[f"{prefix}.0.m"] = (2, 1)
+    spec[f"{prefix}.0.logs"] = (2, 1)
+    for f in range(SDP_FLOWS):
+        p = f"{prefix}.{2 * f + 1}"
+        spec[p + ".pre.weight"] = (filt, 1, 1)
+        spec[p + ".pre.bias"] = (filt,)
+        _dds(spec, p + ".convs", filt, SDP_KERNEL, SDP_DDS_LAYERS)
+        spec[p + ".proj.weight"] = (3 * SDP_NUM_BINS - 1, filt, 1)
+        spec[p + ".proj.bias"] = (3 * SDP_NUM_BINS - 1,)
+
+
+def tts_param_spec(n_vocab, n_speakers, inter_channels, hidden_channels, filter_channels, n_heads, n_layers,
+                   kernel_size, gin_channels=256, **_unused):
+    """Ordered ``{name: shape}`` of the tensors the V1 TTS model adds to the converter schema
+    (``enc_p``, ``sdp``, ``dp``, ``emb_g``; reference: openvoice/models.py:16-180, :450-464,
+    openvoice/attentions.py:37-121, :210-262, :410-436)."""
+    spec = OrderedDict()
+    H, dk = hidden_channels, hidden_channels // n_heads
+    spec["enc_p.emb.weight"] = (n_vocab, H)
+    for i in range(n_layers):
+        a = f"enc_p.encoder.attn_layers.{i}"
+        spec[a + ".emb_rel_k"] = (1, 2 * ATTN_WINDOW + 1, dk)
+        spec[a + ".emb_rel_v"] = (1, 2 * ATTN_WINDOW + 1, dk)
+        for c in ("conv_q", "conv_k", "conv_v", "conv_o"):
+            spec[f"{a}.{c}.weight"] = (H, H, 1)
+            spec[f"{a}.{c}.bias"] = (H,)
+    for i in range(n_layers):
+        spec[f"enc_p.encoder.norm_layers_1.{i}.gamma"] = (H,)
+        spec[f"enc_p.encoder.norm_layers_1.{i}.beta"] = (H,)
+    for i in range(n_layers):
+        f = f"enc_p.encoder.ffn_layers.{i}"
+        spec[f + ".conv_1.weight"] = (filter_channels, H, kernel_size)
+        spec[f + ".conv_1.bias"] = (filter_channels,)
+        spec[f + ".conv_2.weight"] = (H, filter_channels, kernel_size)
+        spec[f + ".conv_2.bias"] = (H,)
+    for i in range(n_layers):
+        spec[f"enc_p.encoder.norm_layers_2.{i}.gamma"] = (H,)
+        spec[f"enc_p.encoder.norm_layers_2.{i}.beta"] = (H,)
+    spec["enc_p.proj.weight"] = (2 * inter_channels, H, 1)
+    spec["enc_p.proj.bias"] = (2 * inter_channels,)
+    F = SDP_FILTER
+    _sdp_flows(spec, "sdp.flows", F)
+    spec["sdp.post_pre.weight"] = (F, 1, 1)
+    spec["sdp.post_pre.bias"] = (F,)
+    spec["sdp.post_proj.weight"] = (F, F, 1)
+    spec["sdp.post_proj.bias"] = (F,)
+    _dds(spec, "sdp.post_convs", F, SDP_KERNEL, SDP_DDS_LAYERS)
+    _sdp_flows(spec, "sdp.post_flows", F)
+    spec["sdp.pre.weight"] = (F, H, 1)
+    spec["sdp.pre.bias"] = (F,)
+    spec["sdp.proj.weight"] = (F, F, 1)
+    spec["sdp.proj.bias"] = (F,)
+    _dds(spec, "sdp.convs", F, SDP_KERNEL, SDP_DDS_LAYERS)
+    spec["sdp.cond.weight"] = (F, gin_channels, 1)
+    spec["sdp.cond.bias"] = (F,)
+    spec["dp.conv_1.weight"] = (DP_FILTER, H, DP_KERNEL)
+    spec["dp.conv_1.bias"] = (DP_FILTER,)
+    spec["dp.norm_1.gamma"] = (DP_FILTER,)
+    spec["dp.norm_1.beta"] = (DP_FILTER,)
+    spec["dp.conv_2.weight"] = (DP_FILTER, DP_FILTER, DP_KERNEL)
+    spec["dp.conv_2.bias"] = (DP_FILTER,)
+    spec["dp.norm_2.gamma"] = (DP_FILTER,)
+    spec["dp.norm_2.beta"] = (DP_FILTER,)
+    spec["dp.proj.weight"] = (1, DP_FILTER, 1)
+    spec["dp.proj.bias"] = (1,)
+    spec["dp.cond.weight"] = (H, gin_channels, 1)
+    spec["dp.cond.bias"] = (H,)
+    spec["emb_g.weight"] = (n_speakers, gin_channels)
+    return spec
+
+
+def tts_full_param_spec(n_vocab, n_speakers, spec_channels, **cfg):
+    """Schema of ``SynthesizerTrn(n_vocab, spec_channels, n_speakers > 0)``: dec, enc_q, flow, then
+    enc_p / sdp / dp / emb_g (no ref_enc) -- reference: openvoice/models.py:428-464."""
+    spec = OrderedDict((k, v) for k, v in converter_param_spec(spec_channels, **cfg).items()
+                       if not k.startswith("ref_enc."))
+    spec.update(tts_param_spec(n_vocab, n_speakers, **cfg))
+    return spec
+
+
+def synthetic_tts_state_dict(hps_model, n_vocab=68, n_speakers=10, spec_channels=513, seed=4321):
+    """Calibrated random weights for the V1 TTS model: the converter recipe for dec/enc_q/flow plus
+    fan-in scaled text-encoder / duration-predictor weights chosen so that predicted durations are a
+    few frames per token (not all 1, not hundreds) and the spline flows are non-trivial."""
+    cfg = dict(hps_model.items()) if hasattr(hps_model, "items") else dict(hps_model)
+    base = synthetic_state_dict(cfg, spec_channels, seed=seed)
+    out = OrderedDict((k, v) for k, v in base.items() if not k.startswith("ref_enc."))
+    gen = torch.Generator().manual_seed(seed + 1)
+    for name, shape in tts_param_spec(n_vocab, n_speakers, **cfg).items():
+        if name.endswith(".gamma"):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=gen)
+        elif name.endswith(".beta") or (name.endswith(".bias") and len(shape) == 1):
+            t = 0.05 * torch.randn(shape, generator=gen)
+        elif name == "enc_p.emb.weight":
+            t = torch.randn(shape, generator=gen) * shape[1] ** -0.5
+        elif name == "emb_g.weight":
+            t = 0.3 * torch.randn(shape, generator=gen)
+        elif name.endswith(("emb_rel_k", "emb_rel_v")):
+            t = torch.randn(shape, generator=gen) * shape[2] ** -0.5
+        elif name.endswith((".m", ".logs")):
+            t = 0.2 * torch.randn(shape, generator=gen)
+        else:
+            fan = 1
+            for s in shape[1:]:
+                fan *= s
+            gain = 1.0
+            if ".convs_sep." in name:
+                gain = 1.5
+            if name.endswith("proj.weight") and ".flows." in name:
+                gain = 3.0          # spline parameters: make bins/derivatives visibly non-uniform
+            t = gain * torch.randn(shape, generator=gen) / fan ** 0.5
+        out[name] = t
+    # durations: logw ~ 0.2 * sdp + 0.8 * dp; aim at exp(logw) ~ 2-6 frames per token
+    out["dp.proj.bias"] = torch.tensor([1.2])
+    out["dp.proj.weight"] = out["dp.proj.weight"] * 0.5
+    return out
+
+
 def effective_weight(sd, prefix):
     """Dense weight of layer ``prefix``: plain ``.weight`` or folded ``weight_g``/``weight_v``.
 

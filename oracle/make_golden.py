@@ -23,7 +23,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 REFERENCE = "/root/reference"
 
-from openvoice_amd.params import synthetic_state_dict  # noqa: E402
+from openvoice_amd.params import synthetic_state_dict, synthetic_tts_state_dict  # noqa: E402
 from openvoice_amd.utils import CONVERTER_MODEL_CONFIG  # noqa: E402
 
 GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
@@ -69,6 +69,67 @@ CASES = [
 ]
 
 
+TTS_WEIGHT_SEED = 4321
+TTS_VOCAB, TTS_SPEAKERS = 68, 10
+TTS_CASES = [
+    # name, token lengths (batch = len), speaker ids, noise_scale, length_scale, noise_scale_w, sdp_ratio
+    dict(name="tts_b3_tx23_ragged", lengths=[23, 15, 7], sid=[0, 3, 9], noise_scale=0.667, length_scale=1.0,
+         noise_scale_w=0.6, sdp_ratio=0.2),
+    dict(name="tts_b1_tx40_slow", lengths=[40], sid=[5], noise_scale=0.667, length_scale=1.3,
+         noise_scale_w=0.6, sdp_ratio=0.2),
+    dict(name="tts_b2_tx5_tiny", lengths=[5, 3], sid=[1, 2], noise_scale=0.0, length_scale=1.0,
+         noise_scale_w=0.8, sdp_ratio=0.5),
+]
+
+
+def make_tts_golden(ref_models):
+    """BaseSpeakerTTS model half: SynthesizerTrn.infer (openvoice/models.py:467-490) and its parts.
+    The two RNG draws -- torch.randn in the stochastic duration predictor (models.py:175) and
+    torch.randn_like for the prior sample (models.py:487) -- are patched to return recorded tensors."""
+    sd = synthetic_tts_state_dict(CONVERTER_MODEL_CONFIG, TTS_VOCAB, TTS_SPEAKERS, 513, seed=TTS_WEIGHT_SEED)
+    model = ref_models.SynthesizerTrn(TTS_VOCAB, 513, n_speakers=TTS_SPEAKERS, **CONVERTER_MODEL_CONFIG).eval()
+    model.load_state_dict(sd, strict=True)
+    schema = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    torch.save(schema, os.path.join(GOLDEN_DIR, "tts_state_dict_schema.pt"))
+    for case in TTS_CASES:
+        lengths = torch.tensor(case["lengths"], dtype=torch.long)
+        B, Tx = len(case["lengths"]), max(case["lengths"])
+        gen = torch.Generator().manual_seed(300 + len(case["name"]))
+        tokens = torch.randint(0, TTS_VOCAB, (B, Tx), generator=gen)
+        sid = torch.tensor(case["sid"], dtype=torch.long)
+        noise_w = torch.randn(B, 2, Tx, generator=gen)
+        noise_z_full = torch.randn(B, 192, 64 * Tx, generator=gen)
+        real_randn, real_randn_like = torch.randn, torch.randn_like
+
+        def fake_randn(*shape, **kw):
+            shape = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+            assert shape == (B, 2, Tx), shape
+            return noise_w.clone()
+
+        torch.randn = fake_randn
+        torch.randn_like = lambda x, *a, **k: noise_z_full[:, :, :x.shape[2]].clone()
+        try:
+            with torch.no_grad():
+                o, attn, y_mask, (z, z_p, m_p, logs_p) = model.infer(
+                    tokens, lengths, sid=sid, noise_scale=case["noise_scale"], length_scale=case["length_scale"],
+                    noise_scale_w=case["noise_scale_w"], sdp_ratio=case["sdp_ratio"])
+                x, m_tok, logs_tok, x_mask = model.enc_p(tokens, lengths)
+                g = model.emb_g(sid).unsqueeze(-1)
+                logw_sdp = model.sdp(x, x_mask, g=g, reverse=True, noise_scale=case["noise_scale_w"])
+                logw_dp = model.dp(x, x_mask, g=g)
+        finally:
+            torch.randn, torch.randn_like = real_randn, real_randn_like
+        Ty = z.shape[2]
+        rec = dict(case=case, weight_seed=TTS_WEIGHT_SEED, n_vocab=TTS_VOCAB, n_speakers=TTS_SPEAKERS,
+                   tokens=tokens, lengths=lengths, sid=sid, noise_w=noise_w, noise_z=noise_z_full[:, :, :Ty].clone(),
+                   x=x, m_tok=m_tok, logs_tok=logs_tok, x_mask=x_mask, logw_sdp=logw_sdp, logw_dp=logw_dp,
+                   o=o, attn=attn, y_mask=y_mask, z=z, z_p=z_p, m_p=m_p, logs_p=logs_p)
+        torch.save(rec, os.path.join(GOLDEN_DIR, case["name"] + ".pt"))
+        w = attn[:, 0].sum(1)
+        print(f"{case['name']}: Ty {Ty} o {tuple(o.shape)} |o|max {o.abs().max():.3f} durations/token "
+              f"{w[0, :8].tolist()} z std {z.std():.3f}")
+
+
 def main():
     warnings.filterwarnings("ignore")
     torch.manual_seed(0)
@@ -76,6 +137,9 @@ def main():
     ref_models, spectrogram_torch = import_reference()
     sd = synthetic_state_dict(CONVERTER_MODEL_CONFIG, 513, seed=WEIGHT_SEED)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    make_tts_golden(ref_models)
+    if "--tts-only" in sys.argv:
+        return
     for case in CASES:
         model = ref_models.SynthesizerTrn(0, 513, n_speakers=0, zero_g=case["zero_g"],
                                           **CONVERTER_MODEL_CONFIG).eval()

@@ -24,3 +24,11 @@ def synth_sd():
     from openvoice_amd.params import synthetic_state_dict
     from openvoice_amd.utils import CONVERTER_MODEL_CONFIG
     return synthetic_state_dict(CONVERTER_MODEL_CONFIG, 513, seed=1234)
+
+
+@pytest.fixture(scope="session")
+def synth_tts_sd():
+    """Calibrated synthetic weights of the V1 TTS model (68 symbols, 10 speakers)."""
+    from openvoice_amd.params import synthetic_tts_state_dict
+    from openvoice_amd.utils import CONVERTER_MODEL_CONFIG
+    return synthetic_tts_state_dict(CONVERTER_MODEL_CONFIG, 68, 10, 513, seed=4321)
