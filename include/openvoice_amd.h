@@ -159,6 +159,73 @@ int ov_conv2d_s2_relu_f32(const float* x, const float* w, const float* bias, flo
 int ov_gru_f32(const float* gi, const float* whh_t, const float* bhh, float* h_out, int N, int H, int T,
                ov_stream_t stream);
 
+/* ---- V1 base-speaker TTS front end (SynthesizerTrn.infer, reference openvoice/models.py:467-490) ----
+ * Token-rate tensors are (B, C, T) fp32 with rows `ld` floats apart (ld >= T), like the frame-rate
+ * tensors of the converter.  The dense 1x1 / k3 convs of this path go through ov_conv1d_f32. */
+
+/* out[b][h][t] = t < lengths[b] ? emb[tokens[b][t]][h] * scale : 0 -- nn.Embedding * sqrt(H), transposed and
+ * masked (models.py:49-54).  tokens [B][T] int64 (ids outside [0, V) are clamped; check them on the host). */
+int ov_embed_f32(const int64_t* tokens, const float* emb, const int64_t* lengths, float* out, int B, int T, int H,
+                 int V, int ld, float scale, ov_stream_t stream);
+
+enum {
+  OV_LN_PRE_RELU = 1, /* relu before the statistics: DurationPredictor conv -> relu -> norm (models.py:91-97) */
+  OV_LN_POST_GELU = 2 /* exact (erf) GELU after the affine: DDSConv (modules.py:122-126)                      */
+};
+/* Channel LayerNorm of modules.py:17-29 / attentions.py:12-24 with the surrounding elementwise ops fused:
+ * v = x (+ res) [relu]; y = (v - mean_c) * rstd_c * gamma + beta [gelu]; y += res2; y *= mask[b][t].
+ * res, res2, mask may be NULL; out may alias x or res2. */
+int ov_layernorm_ch_f32(const float* x, const float* res, const float* gamma, const float* beta, const float* res2,
+                        const float* mask, float* out, int B, int C, int T, int ld, float eps, int flags,
+                        ov_stream_t stream);
+
+/* Multi-head self-attention with windowed relative-position keys and values (attentions.py:264-329):
+ * q, k, v, out are (B, n_heads*dk, T); emb_k / emb_v are the shared [2*window+1][dk] tables; scores of masked
+ * (query, key) pairs are set to -1e4 before the softmax as in the reference.  q, k, v share the batch stride
+ * qkv_bstride (they may be row blocks of one fused projection output).  dk must be 96; T <= 1199. */
+int ov_rel_attention_f32(const float* q, const float* k, const float* v, const float* emb_k, const float* emb_v,
+                         const float* mask, float* out, int64_t qkv_bstride, int64_t out_bstride, int B, int n_heads,
+                         int dk, int T, int ld, int window, ov_stream_t stream);
+
+/* Depthwise dilated conv on the masked input, DDSConv.convs_sep (modules.py:102-112, :121):
+ * out[b][c][t] = bias[c] + sum_j w[c][j] * (x*mask)[b][c][t + (j - (K-1)/2) * dil];  w is [C][K], K odd. */
+int ov_dwconv1d_f32(const float* x, const float* w, const float* bias, const float* mask, float* out, int B, int C,
+                    int T, int ld, int K, int dil, ov_stream_t stream);
+
+/* ConvFlow.pre (1 -> C pointwise conv) + DDSConv's `x + g` (modules.py:487-488, :118-119):
+ * out[b][c][t] = w[c] * x0[b][t] + bias[c] + g[b][c][t]   (g may be NULL); x0 rows are x0_bstride apart. */
+int ov_expand1_f32(const float* x0, int64_t x0_bstride, const float* w, const float* bias, const float* g, float* out,
+                   int B, int C, int T, int ld, ov_stream_t stream);
+
+/* out[b][c][t] = (x[b][c][t] + bias_b[b][c]) * mask[b][t]: DurationPredictor's `x + cond(g)` and the `x * x_mask`
+ * in front of its first conv (models.py:88-90). */
+int ov_add_bias_mask_f32(const float* x, const float* bias_b, const float* mask, float* out, int B, int C, int T,
+                         int ld, ov_stream_t stream);
+
+/* ConvFlow.forward(reverse=True) after its projection (modules.py:493-511, transforms.py:50-188): channel c1
+ * of z (B, 2, T) goes through the inverse rational-quadratic spline with linear tails whose 3*num_bins-1
+ * unnormalised parameters are the first rows of h (B, >= 3*num_bins-1, T); both channels are then masked.
+ * c0, c1 in {0, 1} select the physical channels (the Flips between flows are not materialised).  num_bins = 10. */
+int ov_rq_spline_inverse_f32(float* z, int64_t z_bstride, int c0, int c1, const float* h, int64_t h_bstride,
+                             const float* mask, int B, int T, int ld, int num_bins, int filter_channels,
+                             float tail_bound, ov_stream_t stream);
+
+/* Durations (models.py:474-479; ElementwiseAffine reverse modules.py:397-399 for the one channel that is used):
+ * logw = ((z_sdp - ea_m) * exp(-ea_logs) * mask) * sdp_ratio + dp * (1 - sdp_ratio);
+ * cum[b][t] = inclusive prefix sum of ceil(exp(logw) * mask * length_scale) (int32); y_len[b] = max(1, total). */
+int ov_duration_f32(const float* z_sdp, int64_t z_bstride, float ea_m, float ea_logs, const float* dp,
+                    int64_t dp_bstride, const float* mask, float* logw, int32_t* cum, int64_t* y_len, int B, int T,
+                    int ld, float sdp_ratio, float length_scale, ov_stream_t stream);
+
+/* generate_path + the two attn matmuls + the prior sample (models.py:480-487, commons.py:128-142): frame t' of
+ * utterance b takes token j with cum[j-1] <= t' < cum[j];  z_p = m_p + noise * exp(logs_p) * noise_scale with
+ * m_p = logs_p = 0 for t' >= y_len[b].  m_tok / logs_tok are (B, C, Tx) with batch stride tok_bstride (the two
+ * halves of the encoder's projection).  m_p, logs_p (B, C, Ty rows ldy) and attn [B][Ty][Tx] are optional outputs. */
+int ov_expand_prior_f32(const float* m_tok, const float* logs_tok, int64_t tok_bstride, int ldx, const int32_t* cum,
+                        const int64_t* x_len, const int64_t* y_len, const float* noise, int64_t noise_bstride, int ldn, float* z_p,
+                        float* m_p, float* logs_p, float* attn, int B, int C, int Tx, int Ty, int ldy,
+                        float noise_scale, ov_stream_t stream);
+
 /* Library/ABI version (major*100 + minor). */
 int ov_version(void);
 

@@ -18,6 +18,9 @@ F_MASK_V = 1
 F_OUT2_INIT = 2
 
 _fp = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+LN_PRE_RELU, LN_POST_GELU = 1, 2
 
 
 class ConvParams(ctypes.Structure):
@@ -54,6 +57,19 @@ SIGNATURES = {
     "ov_conv2d_s2_relu_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, _fp]),
     "ov_gru_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
+    "ov_embed_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, ctypes.c_float, _fp]),
+    "ov_layernorm_ch_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, ctypes.c_float, _i, _fp]),
+    "ov_rel_attention_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _i64, _i, _i, _i, _i, _i, _i,
+                                            _fp]),
+    "ov_add_bias_mask_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp]),
+    "ov_dwconv1d_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
+    "ov_expand1_f32": (ctypes.c_int, [_fp, _i64, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp]),
+    "ov_rq_spline_inverse_f32": (ctypes.c_int, [_fp, _i64, _i, _i, _fp, _i64, _fp, _i, _i, _i, _i, _i,
+                                                ctypes.c_float, _fp]),
+    "ov_duration_f32": (ctypes.c_int, [_fp, _i64, ctypes.c_float, ctypes.c_float, _fp, _i64, _fp, _fp, _fp, _fp,
+                                       _i, _i, _i, ctypes.c_float, ctypes.c_float, _fp]),
+    "ov_expand_prior_f32": (ctypes.c_int, [_fp, _fp, _i64, _i, _fp, _fp, _fp, _fp, _i64, _i, _fp, _fp, _fp, _fp,
+                                           _i, _i, _i, _i, _i, ctypes.c_float, _fp]),
 }
 
 _lib = None

@@ -133,7 +133,7 @@ using namespace ovk;
 
 extern "C" {
 
-int ov_version(void) { return 101; }
+int ov_version(void) { return 102; }
 
 int ov_conv1d_pack_rows(int Cout) { return (Cout + 127) / 128 * 128; }
 

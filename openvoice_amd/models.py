@@ -3,9 +3,9 @@
 Keeps the constructor signature, parameter names (so released ``checkpoint.pth`` files load with
 ``load_state_dict``) and the inference entry points of the reference class
 (reference: openvoice/models.py:399-499) but contains no eager PyTorch compute: ``voice_conversion``
-and ``ref_enc`` run on ``ConverterEngine`` (hand-written gfx950 kernels).  Only the converter
-variant (``n_speakers == 0``: ``enc_q``, ``flow``, ``dec``, ``ref_enc``) is in scope for this
-round; the V1 TTS variant (``enc_p``/``sdp``/``dp``) is SURVEY.md section 8(f) item 1.
+and ``ref_enc`` run on ``ConverterEngine`` and ``infer`` on ``TtsEngine`` (hand-written gfx950
+kernels).  ``n_speakers == 0`` builds the converter variant (``enc_q``, ``flow``, ``dec``, ``ref_enc``),
+``n_speakers > 0`` the V1 base-speaker TTS variant (adds ``enc_p``, ``sdp``, ``dp``, ``emb_g``).
 """
 import weakref
 
@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from .engine import ConverterEngine
-from .params import converter_param_spec
+from .params import converter_param_spec, tts_full_param_spec
 
 
 def _attach(root, dotted, tensor):
@@ -44,11 +44,8 @@ class SynthesizerTrn(nn.Module):
                  upsample_rates, upsample_initial_channel, upsample_kernel_sizes, n_speakers=256,
                  gin_channels=256, zero_g=False, **kwargs):
         super().__init__()
-        if n_speakers != 0:
-            raise NotImplementedError(
-                "only the tone-colour converter (n_speakers == 0) runs on the MI355X engine so far; "
-                "the V1 BaseSpeakerTTS model (enc_p/sdp/dp) is not built yet")
         self.n_speakers = n_speakers
+        self.n_vocab = n_vocab
         self.zero_g = zero_g
         self.spec_channels = spec_channels
         self.model_cfg = dict(
@@ -56,11 +53,16 @@ class SynthesizerTrn(nn.Module):
             resblock_kernel_sizes=list(resblock_kernel_sizes),
             resblock_dilation_sizes=[list(d) for d in resblock_dilation_sizes],
             upsample_rates=list(upsample_rates), upsample_initial_channel=upsample_initial_channel,
-            upsample_kernel_sizes=list(upsample_kernel_sizes), gin_channels=gin_channels)
-        self.ref_enc = _ReferenceEncoderHandle(self)
+            upsample_kernel_sizes=list(upsample_kernel_sizes), gin_channels=gin_channels,
+            filter_channels=filter_channels, n_heads=n_heads, n_layers=n_layers, kernel_size=kernel_size)
+        if n_speakers == 0:     # converter variant: ref_enc, no text side (reference: models.py:450-452)
+            self.ref_enc = _ReferenceEncoderHandle(self)
+            spec = converter_param_spec(spec_channels, **self.model_cfg)
+        else:                   # V1 base-speaker TTS: enc_p, sdp, dp, emb_g (reference: models.py:453-464)
+            spec = tts_full_param_spec(n_vocab, n_speakers, spec_channels, **self.model_cfg)
         gen = torch.Generator().manual_seed(0)
-        for name, shape in converter_param_spec(spec_channels, **self.model_cfg).items():
-            if name.endswith("weight_g") or name == "ref_enc.layernorm.weight":
+        for name, shape in spec.items():
+            if name.endswith(("weight_g", ".gamma")) or name == "ref_enc.layernorm.weight":
                 init = torch.ones(shape)
             elif len(shape) == 1:
                 init = torch.zeros(shape)
@@ -83,15 +85,30 @@ class SynthesizerTrn(nn.Module):
         dev = next(self.parameters()).device
         key = (str(dev), bool(self.zero_g))
         if self._engine is None or self._engine_key != key:
-            self._engine = ConverterEngine(self.state_dict(), self.model_cfg, self.spec_channels, dev,
-                                           zero_g=self.zero_g)
+            if self.n_speakers == 0:
+                self._engine = ConverterEngine(self.state_dict(), self.model_cfg, self.spec_channels, dev,
+                                               zero_g=self.zero_g)
+            else:
+                from .tts_engine import TtsEngine
+                self._engine = TtsEngine(self.state_dict(), self.model_cfg, self.spec_channels, dev,
+                                         self.n_vocab, self.n_speakers)
             self._engine_key = key
         return self._engine
 
     def voice_conversion(self, y, y_lengths, sid_src, sid_tgt, tau=1.0, noise=None):
         """reference: openvoice/models.py:492-499; ``noise`` is the explicit form of the
         reference's ``randn_like`` draw (optional)."""
-        return self.engine().voice_conversion(y, y_lengths, sid_src, sid_tgt, tau=tau, noise=noise)
+        eng = self.engine()
+        if self.n_speakers != 0:
+            eng = eng.core      # a TTS checkpoint also carries enc_q / flow / dec
+        return eng.voice_conversion(y, y_lengths, sid_src, sid_tgt, tau=tau, noise=noise)
 
-    def infer(self, *args, **kwargs):
-        raise NotImplementedError("SynthesizerTrn.infer (V1 TTS path) is not built yet")
+    def infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1., sdp_ratio=0.2,
+              max_len=None, noise_w=None, noise_z=None):
+        """reference: openvoice/models.py:467-490; ``noise_w`` / ``noise_z`` are the explicit forms of the
+        reference's two RNG draws (optional).  Returns ``(o, attn, y_mask, (z, z_p, m_p, logs_p))``."""
+        if self.n_speakers == 0:
+            raise RuntimeError("infer() needs the TTS model (n_speakers > 0); this is the converter variant")
+        return self.engine().infer(x, x_lengths, sid, noise_scale=noise_scale, length_scale=length_scale,
+                                   noise_scale_w=noise_scale_w, sdp_ratio=sdp_ratio, max_len=max_len,
+                                   noise_w=noise_w, noise_z=noise_z)

@@ -44,10 +44,22 @@ def test_engine_rejects_cpu_device(synth_sd):
         ConverterEngine(synth_sd, utils.CONVERTER_MODEL_CONFIG, 513, "cpu")
 
 
-def test_v1_tts_model_is_reported_as_not_built(tmp_path):
+def test_v1_tts_model_owns_the_reference_schema(synth_tts_sd):
+    """SynthesizerTrn(n_speakers > 0) holds enc_p / sdp / dp / emb_g under the reference's parameter names
+    (released base-speaker checkpoints load strictly); without a ROCm device infer() fails loudly."""
+    from openvoice_amd._lib import OvError
     from openvoice_amd.models import SynthesizerTrn
-    with pytest.raises(NotImplementedError):
-        SynthesizerTrn(68, 513, n_speakers=10, **utils.CONVERTER_MODEL_CONFIG)
+    model = SynthesizerTrn(68, 513, n_speakers=10, **utils.CONVERTER_MODEL_CONFIG)
+    missing, unexpected = model.load_state_dict(synth_tts_sd, strict=True)
+    assert not missing and not unexpected and not hasattr(model, "ref_enc")
+    back = model.state_dict()
+    assert all(torch.equal(back[k], synth_tts_sd[k]) for k in synth_tts_sd)
+    if not torch.cuda.is_available():
+        with pytest.raises(OvError):
+            model.infer(torch.zeros(1, 3, dtype=torch.long), torch.tensor([3]), sid=torch.tensor([0]))
+    conv = SynthesizerTrn(0, 513, n_speakers=0, **utils.CONVERTER_MODEL_CONFIG)
+    with pytest.raises(RuntimeError, match="converter variant"):
+        conv.infer(torch.zeros(1, 3, dtype=torch.long), torch.tensor([3]))
 
 
 def test_state_dict_round_trip_strict(synth_sd):
