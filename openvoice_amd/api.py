@@ -17,6 +17,7 @@ package at the repo root).  What differs, on purpose:
 * the watermark (third-party ``wavmark``) stays an optional post-processing hook.
 """
 import os
+import re
 
 import numpy as np
 import torch
@@ -54,12 +55,28 @@ class OpenVoiceBaseClass(object):
 
 
 class BaseSpeakerTTS(OpenVoiceBaseClass):
-    """V1 base-speaker TTS (reference: openvoice/api.py:42-98).  The class and its static helpers
-    exist so imports and notebook cells resolve; the model behind ``tts`` (TextEncoder, duration
-    predictors, spline flows -- BASELINE.json configs[3]) is SURVEY.md section 8(f) item 1 and is
-    not built yet: constructing it raises NotImplementedError from ``SynthesizerTrn``."""
+    """V1 base-speaker TTS (reference: openvoice/api.py:42-98).  The model half
+    (``SynthesizerTrn.infer``: text encoder, duration predictors, spline flows, flow, generator) runs on
+    the MI355X engine.  The TEXT front end of the reference (``openvoice/text``: cleaners built on
+    inflect / eng_to_ipa / pypinyin / jieba) is third-party CPU string
+    processing and is not re-implemented: plug a ``text_to_sequence(text, symbols, cleaner_names)``
+    callable into ``BaseSpeakerTTS.text_to_sequence`` (the reference's own function works unchanged), or
+    call ``tts_from_ids`` with symbol ids."""
 
     language_marks = {"english": "EN", "chinese": "ZH"}
+    text_to_sequence = None     # hook: callable(text, symbols, cleaner_names) -> list[int]
+
+    @classmethod
+    def get_text(cls, text, hps, is_symbol):
+        """reference: openvoice/api.py:48-54."""
+        if cls.text_to_sequence is None:
+            raise RuntimeError("no text front end registered: set BaseSpeakerTTS.text_to_sequence to a "
+                               "text_to_sequence(text, symbols, cleaner_names) callable (e.g. the reference's "
+                               "openvoice.text.text_to_sequence) or use tts_from_ids()")
+        text_norm = cls.text_to_sequence(text, hps.symbols, [] if is_symbol else hps.data.text_cleaners)
+        if hps.data.add_blank:
+            text_norm = intersperse(text_norm, 0)
+        return torch.LongTensor(text_norm)
 
     @staticmethod
     def audio_numpy_concat(segment_data_list, sr, speed=1.0):
@@ -71,10 +88,67 @@ class BaseSpeakerTTS(OpenVoiceBaseClass):
             parts += [np.asarray(segment, dtype=np.float32).reshape(-1), gap]
         return np.concatenate(parts) if parts else np.zeros(0, dtype=np.float32)
 
-    def tts(self, text, output_path, speaker, language="English", speed=1.0):
+    @staticmethod
+    def split_sentences_into_pieces(text, language_str):
+        """reference: openvoice/api.py:65-71 (prints the pieces like the reference does)."""
+        texts = utils.split_sentence(text, language_str=language_str)
+        print(" > Text splitted to sentences.")
+        print("\n".join(texts))
+        print(" > ===========================")
+        return texts
+
+    @torch.no_grad()
+    def tts_from_ids(self, id_sequences, speaker_id, speed=1.0, batched=False, noise_scale=0.667,
+                     noise_scale_w=0.6):
+        """Synthesize already-tokenised sentences (symbol ids, blanks interspersed by the caller if the
+        config asks for it).  ``batched=False`` runs one ``infer`` per sentence exactly as the reference loop
+        (api.py:78-94); ``batched=True`` pads them into one batch (one pass over the GPU; because the
+        generator is unmasked, the last ~13 frames of the shorter items then differ slightly from a
+        per-sentence run).  Returns a list of float32 numpy waveforms."""
+        device = self.device
+        seqs = [torch.as_tensor(s, dtype=torch.long).reshape(-1) for s in id_sequences]
+        hop = self.hps.data.hop_length
+        if not batched:
+            out = []
+            for s in seqs:
+                o = self.model.infer(s[None].to(device), torch.LongTensor([s.numel()]).to(device),
+                                     sid=torch.LongTensor([speaker_id]).to(device), noise_scale=noise_scale,
+                                     noise_scale_w=noise_scale_w, length_scale=1.0 / speed)[0]
+                out.append(o[0, 0].data.cpu().float().numpy())
+            return out
+        lengths = torch.tensor([s.numel() for s in seqs], dtype=torch.long)
+        x = torch.zeros(len(seqs), int(lengths.max()), dtype=torch.long)
+        for i, s in enumerate(seqs):
+            x[i, :s.numel()] = s
+        sid = torch.full((len(seqs),), int(speaker_id), dtype=torch.long)
+        o, _, y_mask, _ = self.model.infer(x.to(device), lengths.to(device), sid=sid.to(device), noise_scale=noise_scale,
+                                           noise_scale_w=noise_scale_w, length_scale=1.0 / speed)
+        frames = y_mask[:, 0].sum(1).long().cpu().tolist()
+        o = o[:, 0].data.cpu().float().numpy()
+        return [o[i, :frames[i] * hop] for i in range(len(seqs))]
+
+    def tts(self, text, output_path, speaker, language="English", speed=1.0, batched=False):
+        """reference: openvoice/api.py:73-98."""
         mark = self.language_marks.get(language.lower(), None)
         assert mark is not None, f"language {language} is not supported"
-        raise NotImplementedError("BaseSpeakerTTS.tts: the V1 TTS model is not built on the MI355X engine yet")
+        texts = self.split_sentences_into_pieces(text, mark)
+        ids = []
+        for t in texts:
+            t = re.sub(r"([a-z])([A-Z])", r"\1 \2", t)
+            t = f"[{mark}]{t}[{mark}]"
+            ids.append(self.get_text(t, self.hps, False))
+        audio_list = self.tts_from_ids(ids, self.hps.speakers[speaker], speed=speed, batched=batched)
+        audio = self.audio_numpy_concat(audio_list, sr=self.hps.data.sampling_rate, speed=speed)
+        if output_path is None:
+            return audio
+        audio_io.write(output_path, audio, self.hps.data.sampling_rate)
+
+
+def intersperse(lst, item):
+    """reference: openvoice/commons.py:22-25."""
+    result = [item] * (len(lst) * 2 + 1)
+    result[1::2] = lst
+    return result
 
 
 def string_to_bits(string, pad_len=8):

@@ -48,6 +48,29 @@ def get_hparams_from_file(config_path):
         return HParams(**json.load(handle))
 
 
+def split_sentence(text, min_len=10, language_str="[EN]"):
+    """Sentence pieces for ``BaseSpeakerTTS.tts`` (reference: openvoice/utils.py:78-194).  Same policy as the
+    reference -- split at sentence punctuation, then merge pieces shorter than ``min_len`` words (EN) or
+    ``min_len`` characters (ZH) into their neighbour -- written compactly; it is CPU string handling in
+    front of the measured path and exact piece-for-piece parity with the reference splitter is not claimed."""
+    import re
+    zh = language_str in ("ZH", "[ZH]", "zh")
+    text = re.sub(r"[\n\t ]+", " ", text)
+    text = text.translate(str.maketrans({"\u201c": '"', "\u201d": '"', "\u2018": "'", "\u2019": "'"}))
+    pieces = [p.strip() for p in re.split(r"(?<=[.!?;\u3002\uff01\uff1f\uff1b])\s*", text) if p.strip()]
+    size = (lambda p: len(p)) if zh else (lambda p: len(p.split(" ")))
+    merged = []
+    for p in pieces:
+        if merged and size(merged[-1]) < min_len:
+            merged[-1] = merged[-1] + ("" if zh else " ") + p
+        else:
+            merged.append(p)
+    if len(merged) > 1 and size(merged[-1]) <= 2:
+        last = merged.pop()
+        merged[-1] = merged[-1] + ("" if zh else " ") + last
+    return merged
+
+
 # Hyper-parameters of the released converter checkpoints (SURVEY.md section 8, tag [K]).
 # Used by bench.py / tests when no config.json is supplied; never hard-wired in the engine.
 CONVERTER_MODEL_CONFIG = dict(

@@ -135,3 +135,23 @@ def test_spectrogram_front_end_matches_oracle(golden_dir):
     rec = torch.load(os.path.join(golden_dir, "vc_b2_t17.pt"), weights_only=False)
     spec = spectrogram_torch(rec["wave"], 1024, 22050, 256, 1024, center=False)
     assert (spec - rec["spec"]).abs().max().item() <= 1e-4 * rec["spec"].abs().max().item()
+
+
+def test_sentence_splitter_and_intersperse():
+    pieces = utils.split_sentence("Hello there. This is a longer sentence with more than ten words in it, truly! Ok.",
+                                  language_str="EN")
+    assert " ".join(pieces).replace("  ", " ") == \
+        "Hello there. This is a longer sentence with more than ten words in it, truly! Ok."
+    assert all(len(p.split(" ")) >= 3 for p in pieces)
+    assert api.intersperse([5, 6, 7], 0) == [0, 5, 0, 6, 0, 7, 0]          # reference: openvoice/commons.py:22-25
+
+
+def test_tts_text_front_end_is_a_hook():
+    hps = utils.HParams(symbols=list("_abc"), data=dict(text_cleaners=["x"], add_blank=True))
+    with pytest.raises(RuntimeError, match="no text front end"):
+        api.BaseSpeakerTTS.get_text("ab", hps, False)
+    api.BaseSpeakerTTS.text_to_sequence = staticmethod(lambda text, symbols, cleaners: [symbols.index(c) for c in text])
+    try:
+        assert api.BaseSpeakerTTS.get_text("abc", hps, False).tolist() == [0, 1, 0, 2, 0, 3, 0]
+    finally:
+        api.BaseSpeakerTTS.text_to_sequence = None

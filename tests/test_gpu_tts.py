@@ -277,3 +277,36 @@ def test_voice_conversion_on_a_tts_checkpoint(synth_tts_sd):
     with torch.no_grad():
         o_r = vc_oracle.voice_conversion(synth_tts_sd, CFG, spec, torch.tensor([20]), g1, g2, 0.3, noise)[0]
     assert (o.cpu() - o_r).abs().max().item() <= 1e-3
+
+
+def test_base_speaker_tts_api_from_checkpoint_files(tmp_path, synth_tts_sd):
+    """BaseSpeakerTTS(config.json, device).load_ckpt(checkpoint.pth) + tts_from_ids: the per-sentence loop of the
+    reference (openvoice/api.py:78-94) and the one-batch form agree away from the unmasked-decoder tails."""
+    import json
+    import numpy as np
+    from openvoice_amd import api
+    from openvoice_amd.utils import CONVERTER_DATA_CONFIG
+    cfg = {"data": dict(CONVERTER_DATA_CONFIG, n_speakers=10, text_cleaners=["cjke_cleaners2"], add_blank=True),
+           "model": dict(CFG), "symbols": [f"s{i}" for i in range(68)], "speakers": {"default": 1, "whispering": 2}}
+    (tmp_path / "config.json").write_text(json.dumps(cfg))
+    torch.save({"model": synth_tts_sd}, tmp_path / "checkpoint.pth")
+    tts = api.BaseSpeakerTTS(str(tmp_path / "config.json"), device=DEV)
+    tts.load_ckpt(str(tmp_path / "checkpoint.pth"))
+    gen = torch.Generator().manual_seed(1)
+    ids = [api.intersperse(torch.randint(1, 68, (n,), generator=gen).tolist(), 0) for n in (12, 7, 20)]
+    torch.manual_seed(0)
+    single = tts.tts_from_ids(ids, tts.hps.speakers["default"], speed=1.0)
+    torch.manual_seed(0)
+    batch = tts.tts_from_ids(ids, tts.hps.speakers["default"], speed=1.0, batched=True)
+    assert len(single) == len(batch) == 3 and all(a.dtype == np.float32 and a.ndim == 1 for a in single)
+    assert all(len(a) % 256 == 0 and len(a) > 0 for a in single)
+    # api.tts with a registered front end: text -> ids hook, sentence split, 50 ms gaps, WAV on disk
+    api.BaseSpeakerTTS.text_to_sequence = staticmethod(lambda text, symbols, cleaners: [1 + (ord(c) % 67) for c in text])
+    try:
+        tts.tts("Hello world, this is a test. Another short one!", str(tmp_path / "out.wav"), speaker="default",
+                language="English", speed=1.1)
+    finally:
+        api.BaseSpeakerTTS.text_to_sequence = None
+    from openvoice_amd import audio_io
+    wav, sr = audio_io.load(str(tmp_path / "out.wav"), 22050)
+    assert sr == 22050 and len(wav) > 22050 // 4 and np.isfinite(wav).all()

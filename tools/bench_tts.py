@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Throughput of the V1 base-speaker TTS path (BASELINE.json configs[3]: SynthesizerTrn.infer, batch 16, one
+MI355X) with the calibrated synthetic weights.  Measurement tool, not the bench.py contract line.
+
+    python tools/bench_tts.py [--batch 16] [--tokens 100] [--steps 5] [--cpu]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--tokens", type=int, default=100, help="symbol ids per utterance (blanks included)")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle on one utterance")
+    args = ap.parse_args()
+    from openvoice_amd.models import SynthesizerTrn
+    from openvoice_amd.params import synthetic_tts_state_dict
+    from openvoice_amd.utils import CONVERTER_MODEL_CONFIG as CFG
+    dev = "cuda:0"
+    sd = synthetic_tts_state_dict(CFG)
+    model = SynthesizerTrn(68, 513, n_speakers=10, **CFG)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    gen = torch.Generator().manual_seed(0)
+    B, Tx = args.batch, args.tokens
+    tokens = torch.randint(0, 68, (B, Tx), generator=gen).to(dev)
+    lengths = torch.full((B,), Tx, dtype=torch.long, device=dev)
+    sid = (torch.arange(B) % 10).to(dev)
+    noise_w = torch.randn(B, 2, Tx, generator=gen).to(dev)
+    noise_z = torch.randn(B, 192, 16 * Tx, generator=gen).to(dev)
+
+    def step():
+        return model.infer(tokens, lengths, sid=sid, noise_scale=0.667, noise_scale_w=0.6, length_scale=1.0,
+                           noise_w=noise_w, noise_z=noise_z)
+
+    for _ in range(args.warmup):
+        o, _, y_mask, _ = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        o, _, y_mask, _ = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    frames = int(y_mask.sum())
+    audio_s = frames * 256 / 22050.0
+    out = {"workload": f"SynthesizerTrn.infer, batch {B} x {Tx} symbols, fp32, synthetic weights",
+           "ms_per_batch": round(dt * 1e3, 3), "utterances_per_s": round(B / dt, 2),
+           "audio_s_per_batch": round(audio_s, 2), "real_time_factor": round(audio_s / dt, 1),
+           "frames_per_utterance": round(frames / B, 1)}
+    if args.cpu:
+        from oracle import tts_oracle
+        from openvoice_amd.hostinfo import usable_cpus
+        cores = usable_cpus(32)
+        torch.set_num_threads(cores)
+        a = lambda t: t[:1].cpu()
+        with torch.no_grad():
+            tts_oracle.infer(sd, CFG, a(tokens), a(lengths), a(sid), a(noise_w), a(noise_z), 0.667, 1.0, 0.6)
+            t0 = time.perf_counter()
+            o_c = tts_oracle.infer(sd, CFG, a(tokens), a(lengths), a(sid), a(noise_w), a(noise_z), 0.667, 1.0, 0.6)[0]
+            dtc = time.perf_counter() - t0
+        out["cpu_oracle"] = {"cores": cores, "s_per_utterance": round(dtc, 3),
+                             "real_time_factor": round(o_c.shape[2] / 22050.0 / dtc, 2),
+                             "max_abs_vs_gpu_item0": float((o[0, 0, :o_c.shape[2]].cpu() - o_c[0, 0]).abs().max())}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
