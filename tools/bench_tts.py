@@ -70,7 +70,10 @@ def main():
             dtc = time.perf_counter() - t0
         out["cpu_oracle"] = {"cores": cores, "s_per_utterance": round(dtc, 3),
                              "real_time_factor": round(o_c.shape[2] / 22050.0 / dtc, 2),
-                             "max_abs_vs_gpu_item0": float((o[0, 0, :o_c.shape[2]].cpu() - o_c[0, 0]).abs().max())}
+                             # the generator is unmasked: in a padded batch the last ~13 frames of an item see
+                             # conv_pre(0) + bias instead of the signal edge, so compare away from the tail
+                             "max_abs_vs_gpu_item0_excl_last_20_frames":
+                                 float((o[0, 0, :o_c.shape[2] - 5120].cpu() - o_c[0, 0, :-5120]).abs().max())}
     print(json.dumps(out))
 
 
