@@ -57,7 +57,11 @@ enum {
   /* ConvTranspose1d written as a 3-tap conv over stride-many output phases, reference
    * openvoice/models.py:279 (weights packed with row = cout*phase_s + phase):
    * out[b][cout][phase_s*t + phase] = v                                                        */
-  OV_EPI_CONVT = 5
+  OV_EPI_CONVT = 5,
+  /* Spectrogram magnitude, reference openvoice/mel_processing.py:61-74: rows paired like OV_EPI_GATE
+   * (tile 2q = real parts of bins 32q.., tile 2q+1 = imaginary parts): out[b][f][t] = sqrt(re^2 + im^2 + scale)
+   * for f < Cout (Cout need not be a multiple of 32); no bias.  Used with the even-K framing conv.           */
+  OV_EPI_MAGNITUDE = 6
 };
 
 enum {
@@ -92,7 +96,8 @@ typedef struct ov_conv1d_params {
   int32_t out_ld;        /* row stride of out/res/add/out2; 0 = L (CONVT: L * phase_s)          */
   int32_t M;             /* packed rows = 32 * m_tiles, as passed to ov_conv1d_pack_f32          */
   int32_t Cout;          /* rows >= Cout (LINEAR/COUPLE/RESSKIP) are padding and never stored    */
-  int32_t K, dil;        /* taps, dilation; padding is (K-1)*dil/2                               */
+  int32_t K, dil;        /* taps, dilation; odd K: 'same' padding (K-1)*dil/2; even K: taps t .. t+(K-1)*dil,
+                          * no left padding (the framing conv of the spectrogram)                   */
   int32_t epi, flags, split, phase_s;
   int32_t tiles_per_wg;  /* consecutive time tiles walked by one workgroup; 0 = 1                */
   int32_t tile;          /* 0 = chosen by the dispatcher; else 1 + tile id (128x128, 64x256,
@@ -121,6 +126,14 @@ int ov_conv1d_pack_f32(const float* w, int Cout, int Cin, int K, float* dst);
  * :296-306 (ResBlock1), :439-455 (coupling), openvoice/models.py:216-220 (posterior encoder),
  * :273-286 (generator conv_pre, ups, MRF). */
 int ov_conv1d_f32(const ov_conv1d_params* p, ov_stream_t stream);
+
+/* Framing for the linear spectrogram, reference openvoice/mel_processing.py:54-58 (reflect pad) and the framing
+ * step of torch.stft at :61-72: hops[b][c][u] = ypad[hop*u + c] for u < U, with ypad the waveform [B][N]
+ * reflect-padded by `pad` samples on each side (zero beyond that).  hops is (B, hop, U) with rows ld apart.
+ * With n_fft = 4*hop the windowed DFT + magnitude is then ov_conv1d_f32 with K = 4, Cin = hop and
+ * OV_EPI_MAGNITUDE (weights = window * cos / -sin, rows paired re/im). */
+int ov_frame_hops_f32(const float* wave, float* hops, int B, int N, int hop, int pad, int U, int ld,
+                      ov_stream_t stream);
 
 /* conv_post + tanh, reference openvoice/models.py:287-289:
  * out[b][0][t] = tanh( sum_{c,j} w[c][j] * lrelu(x[b][c][t+j-(K-1)/2], in_slope) ), no bias.

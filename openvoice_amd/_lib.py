@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libopenvoice_amd.so")
 OV_OK = 0
 OV_ERRORS = {-1: "OV_E_BADARG", -2: "OV_E_UNSUPPORTED", -3: "OV_E_ALIGN", -4: "OV_E_LAUNCH"}
 
-EPI_LINEAR, EPI_GATE, EPI_RESSKIP, EPI_COUPLE, EPI_POSTERIOR, EPI_CONVT = range(6)
+EPI_LINEAR, EPI_GATE, EPI_RESSKIP, EPI_COUPLE, EPI_POSTERIOR, EPI_CONVT, EPI_MAGNITUDE = range(7)
 F_MASK_V = 1
 F_OUT2_INIT = 2
 
@@ -57,6 +57,7 @@ SIGNATURES = {
     "ov_conv2d_s2_relu_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, _fp]),
     "ov_gru_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
+    "ov_frame_hops_f32": (ctypes.c_int, [_fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
     "ov_embed_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, ctypes.c_float, _fp]),
     "ov_layernorm_ch_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, ctypes.c_float, _i, _fp]),
     "ov_rel_attention_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _i64, _i, _i, _i, _i, _i, _i,

@@ -13,6 +13,8 @@ namespace ovk {
   X(3, 1, 128x128, 16, 0, OV_EPI_CONVT, 2) \
   X(3, 1, 128x128, 32, 1, OV_EPI_CONVT, 2) \
   X(3, 1, 64x256, 16, 1, OV_EPI_CONVT, 4) \
-  X(3, 1, 64x256, 32, 1, OV_EPI_CONVT, 4)
+  X(3, 1, 64x256, 32, 1, OV_EPI_CONVT, 4) \
+  X(4, 1, 128x128, 32, 1, OV_EPI_MAGNITUDE, 4) \
+  X(4, 1, 128x128, 32, 0, OV_EPI_MAGNITUDE, 4)
 OV_DEFINE_VARIANTS(kVariantsS, LIST)
 }  // namespace ovk

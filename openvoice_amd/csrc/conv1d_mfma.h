@@ -66,7 +66,25 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
   float* outb = p.out + (int64_t)b * p.out_bstride;
   const uint32_t col0 = (uint32_t)tcol0 + ((uint32_t)lane & 31u);
 
-  if constexpr (EPI == OV_EPI_GATE || EPI == OV_EPI_POSTERIOR) {
+  if constexpr (EPI == OV_EPI_MAGNITUDE) {
+    static_assert(WM == 2, "magnitude pairs two 32-row tiles per wave");
+    // q = pair index: packed tile 2q holds the real parts of output rows 32q.., tile 2q+1 the imaginary parts
+    if ((uint32_t)q * 32u >= Cout) return;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const uint32_t col = col0 + 32u * j;
+      if (col >= L) continue;
+      const uint32_t rbase = (uint32_t)q * 32u + 4u * half;
+      const uint32_t voff = rbase * LD + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t rr = (r & 3) + 8 * (r >> 2);
+        const float re = acc[0][j][r], im = acc[1][j][r];
+        if (rbase + rr < Cout) (outb + (size_t)rr * LD)[voff] = sqrtf(re * re + im * im + scale);
+      }
+    }
+    return;
+  } else if constexpr (EPI == OV_EPI_GATE || EPI == OV_EPI_POSTERIOR) {
     static_assert(WM == 2, "gate/posterior pair two 32-row tiles per wave");
     // q = pair index: packed tiles 2q (tanh | m), 2q+1 (sigmoid | logs)
     if ((uint32_t)q * 32u >= Cout) return;
@@ -261,9 +279,12 @@ __global__ __launch_bounds__(64 * (4 + NLD), EPI == OV_EPI_GATE ? 4 : 1) void co
   static_assert(CHUNK % UNIT == 0 && (CHUNK / UNIT == 2 || CHUNK / UNIT == 4), "chunk = 2 or 4 units");
   constexpr int UPC = CHUNK / UNIT;
   constexpr int N_BLK = 32 * WN * WVN;
-  constexpr int PAD = (K - 1) * DIL / 2;
+  // Odd K: 'same' padding, taps t - PAD ... t + PAD.  Even K (the framing conv of the spectrogram):
+  // forward alignment, taps t ... t + (K-1)*DIL, i.e. no left halo.
+  constexpr int PAD = (K % 2 == 1) ? (K - 1) * DIL / 2 : 0;
+  constexpr int PADR = (K - 1) * DIL - PAD;
   constexpr int PADA = (PAD + 3) / 4 * 4;
-  constexpr int XS = N_BLK + 2 * PADA;  // LDS row stride (floats), multiple of 4
+  constexpr int XS = N_BLK + PADA + (PADR + 3) / 4 * 4;  // LDS row stride (floats), multiple of 4
   constexpr int XS4 = XS / 4;
   constexpr int BUF = CHUNK * XS;       // floats per LDS buffer
   constexpr int NITEM = VEC ? CHUNK * XS4 : CHUNK * XS;

@@ -98,6 +98,33 @@ __global__ void sequence_mask_kernel(const int64_t* __restrict__ lengths, float*
   if (t < T) mask[(int64_t)b * ld + t] = t < lengths[b] ? 1.f : 0.f;
 }
 
+// Framing for the spectrogram (reference: openvoice/mel_processing.py:54-58 reflect pad, :61-72 framing inside
+// torch.stft): hops[b][c][u] = ypad[hop*u + c], ypad = y reflect-padded by `pad` samples on both sides.  With
+// n_fft = 4*hop, frame t is hops[:, t .. t+3], so the windowed DFT becomes a 4-tap conv over u with `hop` input
+// channels.  A 32-hop x `hop`-sample tile is read coalesced along samples, transposed through LDS and written
+// coalesced along u.
+__global__ __launch_bounds__(256) void frame_hops_kernel(const float* __restrict__ wave, float* __restrict__ hops,
+                                                         int N, int hop, int pad, int U, int ld) {
+  extern __shared__ float tile[];   // [32][hop + 1]
+  const int b = blockIdx.y, u0 = blockIdx.x * 32;
+  const int HS = hop + 1;
+  const float* y = wave + (int64_t)b * N;
+  for (int idx = threadIdx.x; idx < 32 * hop; idx += 256) {
+    const int du = idx / hop, c = idx - du * hop;
+    const int64_t i = (int64_t)(u0 + du) * hop + c - pad;     // index into the un-padded signal
+    float v = 0.f;
+    if (u0 + du < U && i > -(int64_t)N && i < 2 * (int64_t)N - 1) {
+      const int64_t k = i < 0 ? -i : (i >= N ? 2 * ((int64_t)N - 1) - i : i);
+      if (i >= -(int64_t)pad && i < (int64_t)N + pad) v = y[k];
+    }
+    tile[du * HS + c] = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;   // 8 groups of 32 lanes, lanes along u
+  for (int c = grp; c < hop; c += 8)
+    if (u0 + lane < U) hops[((int64_t)b * hop + c) * ld + u0 + lane] = tile[lane * HS + c];
+}
+
 static conv_launch_fn find_variant(int K, int dil, int tile, int chunk, int vec, int epi, int nld) {
   const ConvVariant* tabs[] = {kVariantsA, kVariantsB, kVariantsC, kVariantsD, kVariantsE, kVariantsS, kVariantsW};
   const int ns[] = {kVariantsACount, kVariantsBCount, kVariantsCCount, kVariantsDCount,
@@ -133,7 +160,7 @@ using namespace ovk;
 
 extern "C" {
 
-int ov_version(void) { return 102; }
+int ov_version(void) { return 103; }
 
 int ov_conv1d_pack_rows(int Cout) { return (Cout + 127) / 128 * 128; }
 
@@ -172,13 +199,13 @@ int ov_conv1d_f32(const ov_conv1d_params* pin, ov_stream_t stream) {
     return OV_E_BADARG;
   if (p->B > 65535) return OV_E_BADARG;
   const int epi = p->epi;
-  if (epi < OV_EPI_LINEAR || epi > OV_EPI_CONVT) return OV_E_BADARG;
-  if ((epi == OV_EPI_GATE || epi == OV_EPI_POSTERIOR) && (p->M % 64 != 0)) return OV_E_BADARG;
+  if (epi < OV_EPI_LINEAR || epi > OV_EPI_MAGNITUDE) return OV_E_BADARG;
+  const bool paired = epi == OV_EPI_GATE || epi == OV_EPI_POSTERIOR || epi == OV_EPI_MAGNITUDE;
+  if (paired && (p->M % 64 != 0)) return OV_E_BADARG;
   if (epi == OV_EPI_POSTERIOR && !p->res) return OV_E_BADARG;
   if (epi == OV_EPI_RESSKIP && (!p->out2 || p->split % 32 != 0)) return OV_E_BADARG;
   if (!p->bias) return OV_E_BADARG;   // layers without a bias pass a zero vector (M floats)
-  if (epi != OV_EPI_GATE && epi != OV_EPI_POSTERIOR &&
-      ((int64_t)p->Cout * (epi == OV_EPI_CONVT ? p->phase_s : 1)) % 32 != 0)
+  if (!paired && ((int64_t)p->Cout * (epi == OV_EPI_CONVT ? p->phase_s : 1)) % 32 != 0)
     return OV_E_UNSUPPORTED;          // rows are stored in whole 32-row fragments
   if ((epi == OV_EPI_GATE || epi == OV_EPI_POSTERIOR) && p->Cout % 32 != 0) return OV_E_UNSUPPORTED;
   if (epi == OV_EPI_CONVT && (p->phase_s <= 0 || 32 % p->phase_s != 0)) return OV_E_BADARG;
@@ -201,8 +228,8 @@ int ov_conv1d_f32(const ov_conv1d_params* pin, ov_stream_t stream) {
     return OV_E_BADARG;
   int tile = TILE_128x128;
   if (p->tile > 0) tile = p->tile - 1;
-  else if (p->M <= 32 && epi != OV_EPI_GATE && epi != OV_EPI_POSTERIOR) tile = TILE_32x512;
-  else if (p->M <= 64) tile = TILE_64x256;
+  else if (p->M <= 32 && !paired) tile = TILE_32x512;
+  else if (p->M <= 64 && !paired) tile = TILE_64x256;
   const bool can_vec = (p->x_ld % 4 == 0) && !(reinterpret_cast<uintptr_t>(p->x) & 15) && (p->x_bstride % 4 == 0);
   int pref[3];
   conv_launch_fn fn = nullptr;
@@ -222,6 +249,17 @@ int ov_conv1d_f32(const ov_conv1d_params* pin, ov_stream_t stream) {
   }
   if (!fn) return OV_E_UNSUPPORTED;
   return fn(p, static_cast<hipStream_t>(stream));
+}
+
+int ov_frame_hops_f32(const float* wave, float* hops, int B, int N, int hop, int pad, int U, int ld,
+                      ov_stream_t stream) {
+  if (!wave || !hops || B <= 0 || N <= 0 || hop <= 0 || hop > 1024 || pad < 0 || pad >= N || U <= 0 || ld < U ||
+      B > 65535)
+    return OV_E_BADARG;
+  dim3 grid((U + 31) / 32, B);
+  hipLaunchKernelGGL(frame_hops_kernel, grid, dim3(256), (size_t)32 * (hop + 1) * sizeof(float),
+                     static_cast<hipStream_t>(stream), wave, hops, N, hop, pad, U, ld);
+  return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
 }
 
 int ov_conv_post_tanh_f32(const float* x, const float* w, float* out, int B, int C, int L, int K,

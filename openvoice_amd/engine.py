@@ -304,9 +304,13 @@ class ConverterEngine:
         replaces the reference's ``torch.randn_like`` draw (models.py:220); when omitted it is drawn
         from torch's generator on the device."""
         dev = self.device
-        spec = spec.to(dev, torch.float32).contiguous()
+        spec = spec.to(dev, torch.float32)
         B, F, T = spec.shape
         assert F == self.spec_channels
+        # rows may be padded (the native spectrogram returns a [B, F, T] view of 16-byte aligned rows)
+        if not (spec.stride(2) == 1 and spec.stride(1) >= T and spec.stride(0) >= F * spec.stride(1)):
+            spec = spec.contiguous()
+        spec_ld, spec_bs = spec.stride(1), spec.stride(0)
         C, H = self.inter, self.hidden
         lengths = spec_lengths.to(dev, torch.int64).contiguous()
         g_src = sid_src.to(dev, torch.float32).reshape(sid_src.shape[0], -1).contiguous()
@@ -327,8 +331,8 @@ class ConverterEngine:
         cond_tgt = [self._linear(g_tgt, cp["wn"].cond_w, cp["wn"].cond_b) for cp in self.couplings]
         cond_d = self._linear(g_d, self.dec_cond_w, self.dec_cond_b)
         # ---- posterior encoder (models.py:212-221) -------------------------------------------------
-        self._conv(self.q_pre, spec, 0, F * T, ws["h"], 0, H * Tp, B, T, flags=F_MASK_V, mask=mask, mask_bs=Tp,
-                   out_ld=Tp, tag="q_pre")
+        self._conv(self.q_pre, spec, 0, spec_bs, ws["h"], 0, H * Tp, B, T, flags=F_MASK_V, mask=mask, mask_bs=Tp,
+                   x_ld=spec_ld, out_ld=Tp, tag="q_pre")
         self._wavenet(self.q_wn, ws, B, T, cond_q, mask)
         z, z_p, z_hat = ws["z"], ws["z_p"], ws["z_hat"]
         self._conv(self.q_proj, ws["skip"], 0, H * Tp, z, 0, C * Tp, B, T, epi=EPI_POSTERIOR, res=ws["noise"],

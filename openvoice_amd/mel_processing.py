@@ -1,20 +1,81 @@
 """Linear-magnitude spectrogram front-end of the converter (same signature as the reference's
-``spectrogram_torch``, reference: openvoice/mel_processing.py:40-75).
+``spectrogram_torch``, reference: openvoice/mel_processing.py:40-75):
 
-reflect-pad (n_fft - hop)/2 -> STFT (periodic Hann, center=False, onesided) -> sqrt(re^2+im^2+1e-6).
-The FFT itself is torch.stft (rocFFT on device): host glue that the scope table allows for this
-round; the magnitude is fused into one elementwise pass.
+    reflect-pad (n_fft - hop)/2 -> STFT (periodic Hann, center=False, onesided) -> sqrt(re^2 + im^2 + 1e-6)
+
+On a ROCm device the whole thing is two launches of this repo's own kernels (no rocFFT, no eager
+elementwise ops): ``ov_frame_hops_f32`` lays the reflect-padded waveform out as (B, hop, U) "hop
+phases", after which -- because n_fft = 4 * hop for every released config -- the windowed DFT of frame t
+is a 4-tap conv over u with ``hop`` input channels and 2 * (n_fft/2 + 1) output rows, run on the fp32
+MFMA conv kernel with the magnitude fused into its epilogue (``OV_EPI_MAGNITUDE``: real / imaginary
+rows paired in one wave, like the WaveNet gate).  DFT-as-GEMM costs 1.8 GFLOP per 10 s utterance against
+0.05 for an FFT -- 0.3 % of a conversion -- and removes ~10 launches, three full-size temporaries and the
+FFT library from the path.  Weights ``hann[n] * cos / -sin(2 pi f n / n_fft)`` are built once in float64.
+
+For CPU tensors (host-side tooling, the CPU test-suite) and for configs with n_fft != 4 * hop the
+function evaluates the same definition with ``torch.stft``; the engine itself never runs on CPU.
 
 Difference from the reference, on purpose: the reference evaluates ``torch.min(y) < -1.1`` /
 ``torch.max(y) > 1.1`` as Python bools purely to print a warning, which costs two device->host
 syncs per call (hard part 7).  Here the range check runs only when
 ``OV_CHECK_RANGE=1`` is set.
 """
+import ctypes
+import math
 import os
 
 import torch
 
 _hann = {}
+_native = {}
+
+
+class _NativeSpectrogram:
+    """Packed DFT weights + launch logic for one (device, n_fft, hop)."""
+
+    def __init__(self, device, n_fft, hop):
+        from . import _lib
+        from .engine import PackedConv
+        self.lib = _lib.load()
+        self.device, self.n_fft, self.hop = device, n_fft, hop
+        self.bins = n_fft // 2 + 1
+        tiles = (self.bins + 31) // 32
+        n = torch.arange(n_fft, dtype=torch.float64)
+        window = 0.5 - 0.5 * torch.cos(2 * math.pi * n / n_fft)                   # periodic Hann (torch.hann_window)
+        f = torch.arange(self.bins, dtype=torch.float64)[:, None]
+        ang = 2 * math.pi * f * n[None, :] / n_fft
+        re, im = window * torch.cos(ang), -window * torch.sin(ang)               # [bins, n_fft]
+        w = torch.zeros(tiles * 64, n_fft, dtype=torch.float64)                   # row pairing: tile 2q re, 2q+1 im
+        for q in range(tiles):
+            lo, hi = 32 * q, min(32 * q + 32, self.bins)
+            w[64 * q: 64 * q + hi - lo] = re[lo:hi]
+            w[64 * q + 32: 64 * q + 32 + hi - lo] = im[lo:hi]
+        # conv weight [rows, Cin = hop, K = 4]: W[r][c][j] = w[r][hop * j + c]
+        wc = w.reshape(tiles * 64, n_fft // hop, hop).transpose(1, 2).contiguous().float()
+        self.layer = PackedConv(wc, None, device, K=n_fft // hop, cout=self.bins)
+
+    def __call__(self, y):
+        from . import _lib
+        from .engine import launch_conv, padded_frames
+        y = y.contiguous()
+        B, N = y.shape
+        pad = (self.n_fft - self.hop) // 2
+        if pad >= N:
+            raise ValueError("waveform shorter than the reflect padding")       # torch's reflect pad raises too
+        T = (N + 2 * pad - self.n_fft) // self.hop + 1
+        if T < 1:
+            raise ValueError("waveform shorter than one frame")
+        U = T + self.n_fft // self.hop - 1
+        ldu, lds = padded_frames(U), padded_frames(T)
+        hops = torch.empty(B, self.hop, ldu, dtype=torch.float32, device=y.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream(y.device).cuda_stream)
+        _lib.check(self.lib.ov_frame_hops_f32(ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(hops.data_ptr()), B, N,
+                                              self.hop, pad, U, ldu, st), "ov_frame_hops_f32")
+        spec = torch.zeros(B, self.bins, lds, dtype=torch.float32, device=y.device)
+        launch_conv(self.layer, hops, 0, self.hop * ldu, spec, 0, self.bins * lds, B, T, epi=_lib.EPI_MAGNITUDE,
+                    scale=1e-6, rows=self.layer.rows, x_ld=ldu, out_ld=lds)
+        # rows are padded to a multiple of 4 floats (16-byte aligned for the next conv); the caller sees [B, bins, T]
+        return spec[:, :, :T]
 
 
 def spectrogram_torch(y, n_fft, sampling_rate, hop_size, win_size, center=False):
@@ -24,6 +85,12 @@ def spectrogram_torch(y, n_fft, sampling_rate, hop_size, win_size, center=False)
             print("min value is ", lo)
         if hi > 1.1:
             print("max value is ", hi)
+    if y.is_cuda and y.dtype == torch.float32 and not center and win_size == n_fft and n_fft == 4 * hop_size:
+        key = (str(y.device), n_fft, hop_size)
+        eng = _native.get(key)
+        if eng is None:
+            eng = _native[key] = _NativeSpectrogram(y.device, n_fft, hop_size)
+        return eng(y)
     key = (win_size, y.dtype, str(y.device))
     window = _hann.get(key)
     if window is None:

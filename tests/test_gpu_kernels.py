@@ -340,3 +340,20 @@ def test_residual_is_preloaded_only_without_value_mask():
     _close(out, (conv * mask[:, None] + res + add) * 0.5, what="mask_v + res + add")
     launch_conv(layer, x.to(DEV), 0, C * L, out, 0, C * L, B, L, res=res.to(DEV), res_bs=C * L, scale=0.5)
     _close(out, (conv + res) * 0.5, what="res only")
+
+
+@pytest.mark.parametrize("B,N", [(2, 256 * 17), (1, 220500), (3, 5000), (1, 1024 - 768 + 1)])
+def test_native_spectrogram_matches_torch_stft(B, N):
+    """ov_frame_hops_f32 + the K = 4 framing conv with the magnitude epilogue against the reference
+    definition (openvoice/mel_processing.py:40-75) evaluated with torch.stft on the CPU.  |spec| reaches
+    ~10^2 (a 1024-sample window of a full-scale sinusoid), the bound is 2e-5 of that."""
+    from openvoice_amd.mel_processing import spectrogram_torch
+    gen = torch.Generator().manual_seed(N)
+    t = torch.arange(N, dtype=torch.float32) / 22050
+    y = 0.6 * torch.sin(2 * torch.pi * (200 + 300 * torch.arange(B)[:, None]) * t) + 0.05 * torch.randn(B, N, generator=gen)
+    ref = spectrogram_torch(y, 1024, 22050, 256, 1024, center=False)                 # CPU: torch.stft
+    got = spectrogram_torch(y.to(DEV), 1024, 22050, 256, 1024, center=False)         # device: native kernels
+    assert got.shape == ref.shape == (B, 513, (N - 256) // 256 + 1)
+    _close(got, ref, what=f"spectrogram B={B} N={N}")
+    # the view's storage rows are 16-byte aligned and padded columns hold no garbage
+    assert got.stride(2) == 1 and got.stride(1) % 4 == 0
