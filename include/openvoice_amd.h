@@ -72,7 +72,8 @@ enum {
 /* One Conv1d launch.  Input length == output length L ('same' padding, stride 1), as every conv
  * on the converter path (reference: openvoice/modules.py:163-171, :228-283, models.py:238,266).
  * Rows may be padded: x rows are x_ld floats apart, out/res/add/out2 rows out_ld floats apart (both
- * >= L; columns >= L are never read as data and never written).  16-byte staging loads are used
+ * >= L; columns >= L are never read as data and never written).  The forward-aligned even-K conv reads
+ * L + (K-1)*dil input columns (x_ld must cover them) and writes L.  16-byte staging loads are used
  * when x, x_bstride and x_ld are 16-byte aligned -- L itself may be ragged. */
 typedef struct ov_conv1d_params {
   const float* x;        /* [B][>=Cin][L]; channel offset already applied to the pointer        */

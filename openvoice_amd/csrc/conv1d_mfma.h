@@ -318,6 +318,8 @@ __global__ __launch_bounds__(64 * (4 + NLD), EPI == OV_EPI_GATE ? 4 : 1) void co
     const float slope = p.in_slope;
     const uint32_t ldx = (uint32_t)p.x_ld;
     const int llane = (wave - 4) * 64 + lane;   // position among the NLD * 64 loader lanes
+    // valid INPUT columns: L for 'same' convs; the forward-aligned even-K conv consumes (K-1)*DIL more
+    const int Lin = L + ((K % 2 == 1) ? 0 : (K - 1) * DIL);
     int it = 0;
     for (int tile = tile_begin; tile < tile_end; ++tile) {
       const int t0 = tile * N_BLK;
@@ -335,9 +337,9 @@ __global__ __launch_bounds__(64 * (4 + NLD), EPI == OV_EPI_GATE ? 4 : 1) void co
               const int row = idx / XS4, c4 = idx - row * XS4;
               const int ci = chunk * CHUNK + row;
               const int t = t0 - PADA + 4 * c4;     // multiple of 4: a vector is wholly < 0 or >= 0
-              const bool ok = idx < NITEM && ci < Cin && t >= 0 && t < L;
+              const bool ok = idx < NITEM && ci < Cin && t >= 0 && t < Lin;
               const uint32_t goff = ok ? (uint32_t)ci * ldx + (uint32_t)t : 0u;   // always valid
-              nval[i] = ok ? min(L - t, 4) : 0;     // ragged L: a vector may straddle the row end
+              nval[i] = ok ? min(Lin - t, 4) : 0;   // ragged L: a vector may straddle the row end
               stg[i] = *reinterpret_cast<const f32x4*>(xb + goff);
             }
 #pragma unroll
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(64 * (4 + NLD), EPI == OV_EPI_GATE ? 4 : 1) void co
               const int row = idx / XS, c = idx - row * XS;
               const int ci = chunk * CHUNK + row;
               const int t = t0 - PADA + c;
-              const bool ok = idx < NITEM && ci < Cin && t >= 0 && t < L;
+              const bool ok = idx < NITEM && ci < Cin && t >= 0 && t < Lin;
               const uint32_t goff = ok ? (uint32_t)ci * ldx + (uint32_t)t : 0u;
               nval[i] = ok ? 1 : 0;
               stg[i] = xb[goff];

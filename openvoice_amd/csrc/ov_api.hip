@@ -214,7 +214,8 @@ int ov_conv1d_f32(const ov_conv1d_params* pin, ov_stream_t stream) {
   if (p->x_ld == 0) p->x_ld = p->L;
   if (p->out_ld == 0) p->out_ld = (int32_t)lout;
   if (p->mask_bstride == 0) p->mask_bstride = p->L;
-  if (p->x_ld < p->L || p->out_ld < lout || (p->mask && p->mask_bstride < p->L)) return OV_E_BADARG;
+  const int64_t lin = (int64_t)p->L + ((p->K % 2 == 0) ? (int64_t)(p->K - 1) * p->dil : 0);   // input columns read
+  if (p->x_ld < lin || p->out_ld < lout || (p->mask && p->mask_bstride < p->L)) return OV_E_BADARG;
   // per-utterance offsets are 32-bit inside the kernels
   if ((int64_t)p->Cin * p->x_ld > UINT32_MAX || (int64_t)(p->M + 32) * p->out_ld > UINT32_MAX) return OV_E_BADARG;
   if (epi == OV_EPI_CONVT) {

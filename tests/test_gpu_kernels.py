@@ -342,7 +342,7 @@ def test_residual_is_preloaded_only_without_value_mask():
     _close(out, (conv + res) * 0.5, what="res only")
 
 
-@pytest.mark.parametrize("B,N", [(2, 256 * 17), (1, 220500), (3, 5000), (1, 1024 - 768 + 1)])
+@pytest.mark.parametrize("B,N", [(2, 256 * 17), (1, 220500), (3, 5000), (1, 385)])
 def test_native_spectrogram_matches_torch_stft(B, N):
     """ov_frame_hops_f32 + the K = 4 framing conv with the magnitude epilogue against the reference
     definition (openvoice/mel_processing.py:40-75) evaluated with torch.stft on the CPU.  |spec| reaches
