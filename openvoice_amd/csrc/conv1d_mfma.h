@@ -312,7 +312,11 @@ __global__ __launch_bounds__(64 * (4 + NLD), EPI == OV_EPI_GATE ? 4 : 1) void co
   bool is_loader = false;
 #pragma unroll
   for (int i = 0; i < NLD; ++i) is_loader |= (wave == 4 + i);
+#ifndef OV_EXP
+#define OV_EXP 0   // measurement builds only (scripts/exp_sync.sh): 1 = no loads, no barriers; 2 = no loads
+#endif
   if (is_loader) {
+    if (OV_EXP == 1) return;
     // ================================ loader waves ===============================================
     const float* __restrict__ xb = p.x + (int64_t)b * p.x_bstride;
     const float slope = p.in_slope;
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(64 * (4 + NLD), EPI == OV_EPI_GATE ? 4 : 1) void co
       for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
         float* dst = xs + (it & 1) * BUF;
 #pragma unroll 1   // one batch of LB loads per lane in flight at a time: bounds the loader's VGPRs
-        for (int bt = 0; bt < NBATCH; ++bt) {
+        for (int bt = 0; bt < (OV_EXP ? 0 : NBATCH); ++bt) {
           if constexpr (VEC) {
             f32x4 stg[LB];
             int nval[LB];   // valid leading elements of each vector (0 = zero fill); a VGPR count,
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(64 * (4 + NLD), EPI == OV_EPI_GATE ? 4 : 1) void co
 
     int rec = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
-      __syncthreads();  // loader finished buffer (it & 1); we finished reading the other one
+      if (OV_EXP != 1) __syncthreads();  // loader finished buffer (it & 1); we finished reading the other one
       const float* xl = xs + (it & 1) * BUF + xl_off;
       // One k-step = one ci pair x one tap = WM*WN MFMAs (256 cycles of matrix pipe).  The B operands
       // of k-step s+1 are read from LDS while the MFMAs of k-step s run (explicit double buffer,
@@ -466,9 +470,10 @@ int conv1d_launch(const ov_conv1d_params* p, hipStream_t stream) {
   constexpr int M_BLK = 32 * WM * WVM, N_BLK = 32 * WN * WVN;
   const int ntiles = (p->L + N_BLK - 1) / N_BLK;
   const int mblocks = (p->M + M_BLK - 1) / M_BLK;
-  // One time tile per workgroup unless the caller asks otherwise: measured on MI355X, walking 2-4
-  // tiles per workgroup was never better than 1 by more than 2 % and usually worse (coarser tail).
-  const int tpw = p->tiles_per_wg > 0 ? p->tiles_per_wg : 1;
+  // Time tiles walked by one workgroup (the loaders run ahead across the tile boundary).  Measured on
+  // MI355X (profiles/r01_s16): 2 is worth 2-5 % for the 32-row tiles and for M >= 256 (stage 0, whose 54
+  // tiles x 2 M-blocks make a coarse grid), nothing at M = 64 / 128; 4 is worse everywhere (coarser tail).
+  const int tpw = p->tiles_per_wg > 0 ? p->tiles_per_wg : ((M_BLK == 32 || p->M >= 256) && ntiles >= 8 ? 2 : 1);
   dim3 grid((ntiles + tpw - 1) / tpw, mblocks, p->B);
   hipLaunchKernelGGL((conv1d_mfma_kernel<K, DIL, WM, WN, WVM, WVN, CHUNK, VEC, EPI, NLD>), grid,
                      dim3(64 * (4 + NLD)), 0, stream, *p, tpw);

@@ -48,8 +48,8 @@ def main():
             for d, mode in ((1, "plain"), (5, "plain"), (1, "res+add")):
                 w = torch.randn(c, c, k) * (c * k) ** -0.5
                 layer = PackedConv(w, torch.zeros(c), dev, K=k, dil=d)
-                for tile, nld, tpw, chunk in [(t, n, w_, ch) for t in args.tiles for n in args.loaders
-                                              for w_ in args.tpw for ch in args.chunks]:
+                import itertools
+                for tile, nld, tpw, chunk in itertools.product(args.tiles, args.loaders, args.tpw, args.chunks):
                     kw = dict(in_slope=0.1, tiles_per_wg=tpw, tile=tile, loaders=nld, chunk=chunk)
                     if mode != "plain":
                         kw.update(res=res, res_bs=c * L, add=add, add_bs=c * L, scale=1.0 / 3.0)
