@@ -32,6 +32,14 @@
 
 namespace ovk {
 
+// Internal epilogue codes: OV_EPI_CONVT with the phase count known at compile time (the dispatcher maps
+// phase_s = 8 / 2 to them; any other power of two takes the generic OV_EPI_CONVT instance).  Separate
+// kernels rather than a runtime switch: the three store patterns inlined into one kernel cost 176-190 VGPRs
+// (one workgroup per CU), each alone fits the 128-VGPR budget of the other epilogues.
+constexpr int EPI_CONVT_S8 = 16;
+constexpr int EPI_CONVT_S2 = 17;
+constexpr bool is_convt(int epi) { return epi == OV_EPI_CONVT || epi == EPI_CONVT_S8 || epi == EPI_CONVT_S2; }
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -134,7 +142,7 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
     for (int i = 0; i < WM; ++i) {
       const uint32_t mt = (uint32_t)(mtile0 + i);
       // rows are stored in whole 32-row fragments (the dispatcher checks Cout*phase_s % 32 == 0)
-      if (mt * 32u >= (EPI == OV_EPI_CONVT ? Cout * (uint32_t)p.phase_s : Cout)) continue;
+      if (mt * 32u >= (is_convt(EPI) ? Cout * (uint32_t)p.phase_s : Cout)) continue;
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const uint32_t col = col0 + 32u * j;
@@ -148,16 +156,16 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] += bias_b[rbase + (r & 3) + 8 * (r >> 2)];
         }
-        if constexpr (EPI == OV_EPI_CONVT) {
+        if constexpr (is_convt(EPI)) {
           const uint32_t s = (uint32_t)p.phase_s;
           const uint32_t Lout = LD;   // row stride of the upsampled output (>= L * s)
-          if (s == 8) {          // row = co*8 + phase: r&3 walks 4 consecutive output samples
+          if constexpr (EPI == EPI_CONVT_S8) {   // row = co*8 + phase: r&3 walks 4 consecutive output samples
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               f32x4 o = {v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
               *reinterpret_cast<f32x4*>(outb + (size_t)(mt * 4u + c) * Lout + (8u * col + 4u * half)) = o;
             }
-          } else if (s == 2) {   // row = co*2 + phase
+          } else if constexpr (EPI == EPI_CONVT_S2) {   // row = co*2 + phase
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
               const int r = 2 * jj;
@@ -273,7 +281,7 @@ __device__ __forceinline__ bool conv_preload(const ov_conv1d_params& p, f32x16 (
 // The gate epilogue lands at 130 VGPRs on its own; it is held to 128 (4 waves per SIMD, 1-2 VGPRs
 // spilled in the epilogue) because the third workgroup per CU is worth more than the spill costs.
 template <int K, int DIL, int WM, int WN, int WVM, int WVN, int CHUNK, bool VEC, int EPI, int NLD>
-__global__ __launch_bounds__(64 * (4 + NLD), EPI == OV_EPI_GATE ? 4 : 1) void conv1d_mfma_kernel(const ov_conv1d_params p,
+__global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_CONVT_S8 || EPI == EPI_CONVT_S2) ? 4 : 1) void conv1d_mfma_kernel(const ov_conv1d_params p,
                                                                      const int tiles_per_wg) {
   static_assert(WVM * WVN == 4, "4 matrix waves per workgroup");
   static_assert(CHUNK % UNIT == 0 && (CHUNK / UNIT == 2 || CHUNK / UNIT == 4), "chunk = 2 or 4 units");

@@ -234,6 +234,8 @@ int ov_conv1d_f32(const ov_conv1d_params* pin, ov_stream_t stream) {
   const bool can_vec = (p->x_ld % 4 == 0) && !(reinterpret_cast<uintptr_t>(p->x) & 15) && (p->x_bstride % 4 == 0);
   int pref[3];
   conv_launch_fn fn = nullptr;
+  // ConvTranspose: phase counts 8 and 2 have their own instances (compile-time store pattern)
+  const int kernel_epi = epi != OV_EPI_CONVT ? epi : (p->phase_s == 8 ? EPI_CONVT_S8 : (p->phase_s == 2 ? EPI_CONVT_S2 : epi));
   // forced tile / loader count / chunk: exact match or OV_E_UNSUPPORTED (measurement knobs must not silently
   // fall back); otherwise the preferred tile, then 128x128, 16-byte staging before 4-byte.
   const int tiles_try[2] = {tile, p->tile > 0 ? tile : (int)TILE_128x128};
@@ -246,7 +248,7 @@ int ov_conv1d_f32(const ov_conv1d_params* pin, ov_stream_t stream) {
     for (int vec = can_vec ? 1 : 0; vec >= 0 && !fn; --vec)
       for (int ci = 0; ci < 2 && !fn; ++ci)
         for (int li = 0; li < 3 && !fn; ++li)
-          fn = find_variant(p->K, p->dil, tiles_try[ti], cpref[ci], vec, epi, pref[li]);
+          fn = find_variant(p->K, p->dil, tiles_try[ti], cpref[ci], vec, kernel_epi, pref[li]);
   }
   if (!fn) return OV_E_UNSUPPORTED;
   return fn(p, static_cast<hipStream_t>(stream));
