@@ -128,3 +128,77 @@ def test_benchmark_size_properties_round_trip_and_batch_independence(synth_sd):
     for b in (0, 5, 31):
         ob = model.voice_conversion(spec[b:b + 1], lengths[b:b + 1].to(DEV), g, g, tau=0.3, noise=noise[b:b + 1])[0]
         assert torch.equal(ob[0], o1[b]), f"item {b}: batch-32 and batch-1 results differ"
+
+
+def test_tone_color_converter_api_end_to_end_from_files(tmp_path, synth_sd):
+    """BASELINE.json configs[0] plumbing (the reference demo flow, openvoice/api.py:114-160,
+    se_extractor.py:129-152) with WAV files standing in for the MP3 resources (no MP3 decoder in the image):
+    config.json + checkpoint.pth on disk -> ToneColorConverter -> get_se / extract_se -> convert -> WAV on disk,
+    checked against the CPU oracle run on the same samples (tau = 0 makes the conversion deterministic)."""
+    import json
+    import numpy as np
+    from openvoice_amd import api, audio_io, se_extractor
+    from openvoice_amd.utils import default_converter_hparams
+    from oracle import vc_oracle
+    hps = default_converter_hparams("v2")
+    cfg = {"_version_": "v2", "data": dict(hps.data.items()), "model": dict(hps.model.items())}
+    (tmp_path / "config.json").write_text(json.dumps(cfg))
+    torch.save({"model": synth_sd}, tmp_path / "checkpoint.pth")
+    sr = 22050
+    t = np.arange(int(2.3 * sr)) / sr
+    src = (0.4 * np.sin(2 * np.pi * 220 * t) + 0.2 * np.sin(2 * np.pi * 1370 * t + 1.0)).astype(np.float32)
+    ref = (0.5 * np.sin(2 * np.pi * 330 * np.arange(int(21 * sr)) / sr) *
+           (1 + 0.3 * np.sin(2 * np.pi * 3 * np.arange(int(21 * sr)) / sr))).astype(np.float32)
+    audio_io.write(str(tmp_path / "src.wav"), src, sr)
+    audio_io.write(str(tmp_path / "ref.wav"), ref, sr)
+    tcc = api.ToneColorConverter(str(tmp_path / "config.json"), device=DEV, enable_watermark=False)
+    tcc.load_ckpt(str(tmp_path / "checkpoint.pth"))
+    assert tcc.version == "v2" and tcc.model.zero_g is True
+    tgt_se, name = se_extractor.get_se(str(tmp_path / "ref.wav"), tcc, target_dir=str(tmp_path / "processed"), vad=True)
+    src_se = tcc.extract_se(str(tmp_path / "src.wav"), se_save_path=str(tmp_path / "se" / "src.pth"))
+    assert tgt_se.shape == src_se.shape == (1, 256, 1) and os.path.exists(tmp_path / "se" / "src.pth")
+    assert os.path.exists(tmp_path / "processed" / name / "se.pth")
+    # oracle: same decoded samples (16-bit WAV round trip), same embeddings, tau = 0
+    wav16, _ = audio_io.load(str(tmp_path / "src.wav"), sr)
+    with torch.no_grad():
+        spec = vc_oracle.spectrogram(torch.from_numpy(wav16)[None])
+        segs = sorted((tmp_path / "processed" / name / "wavs").glob("*.wav"))
+        ses = []
+        for seg in segs:
+            w, _ = audio_io.load(str(seg), sr)
+            ses.append(vc_oracle.reference_encoder(synth_sd, vc_oracle.spectrogram(torch.from_numpy(w)[None]).transpose(1, 2)))
+        se_ref = torch.stack(ses).mean(0).unsqueeze(-1)
+        o_ref = vc_oracle.voice_conversion(synth_sd, dict(hps.model.items()), spec, torch.tensor([spec.shape[2]]),
+                                           src_se.cpu(), tgt_se.cpu(), 0.0, torch.zeros(1, 192, spec.shape[2]),
+                                           zero_g=True)[0]
+    assert len(segs) == 2 and (tgt_se.cpu() - se_ref).abs().max().item() <= 1e-4
+    audio = tcc.convert(str(tmp_path / "src.wav"), src_se, tgt_se, output_path=None, tau=0.0)
+    assert audio.dtype == np.float32 and audio.shape == (spec.shape[2] * 256,)
+    err = np.abs(audio - o_ref[0, 0].numpy()).max()
+    print("api convert vs oracle:", err)
+    assert err <= 1e-3
+    tcc.convert(str(tmp_path / "src.wav"), src_se, tgt_se, output_path=str(tmp_path / "out.wav"), tau=0.0)
+    back, _ = audio_io.load(str(tmp_path / "out.wav"), sr)
+    assert np.abs(back - audio).max() <= 1.0 / 32768 + 1e-6
+    # batched entry: ragged list == per-item convert away from the unmasked-decoder tails
+    o_b, n_b = tcc.convert_batch([src, src[: sr]], src_se, tgt_se, tau=0.0)
+    assert n_b.tolist() == [spec.shape[2] * 256, ((sr - 256) // 256 + 1) * 256]
+    assert np.abs(o_b[0, 0].cpu().numpy()[: len(audio)] - audio).max() <= 1e-3
+
+
+def test_voice_conversion_matches_reference_at_benchmark_length(golden_dir, synth_sd):
+    """The waveform -> spectrogram -> voice_conversion path at T = 861 frames against the unmodified reference's
+    own output (fixture tests/golden/vc_b1_t861_benchmark_length.pt)."""
+    from openvoice_amd.mel_processing import spectrogram_torch
+    from test_oracle_golden import benchmark_length_inputs
+    rec = torch.load(os.path.join(golden_dir, "vc_b1_t861_benchmark_length.pt"), weights_only=False)
+    wave, g_src, g_tgt, noise = benchmark_length_inputs(rec)
+    model = _model(synth_sd, rec["case"]["zero_g"])
+    spec = spectrogram_torch(wave.to(DEV), 1024, 22050, 256, 1024, center=False)
+    o_hat, _, (z, z_p, z_hat) = model.voice_conversion(spec, torch.tensor([861]).to(DEV), g_src.to(DEV), g_tgt.to(DEV),
+                                                       tau=rec["case"]["tau"], noise=noise.to(DEV))
+    torch.cuda.synchronize()
+    err = (o_hat.cpu() - rec["o_hat"]).abs().max().item()
+    print("T=861 vs reference: o_hat err", err)
+    assert (z_hat.cpu().sum(2) - rec["z_hat_sum"]).abs().max().item() <= 5e-3
+    assert err <= O_HAT_TOL

@@ -75,3 +75,33 @@ def test_param_spec_matches_reference_schema(golden_dir):
     assert set(spec) == set(schema)
     for key, shape in schema.items():
         assert tuple(spec[key]) == tuple(shape), key
+
+
+def benchmark_length_inputs(rec):
+    """Inputs of the compact T = 861 fixture, regenerated from its seeds exactly as oracle/make_golden.py drew them."""
+    from oracle.make_golden import synth_wave
+    seed, t = rec["seed"], rec["case"]["frames"]
+    wave = synth_wave(1, 256 * t, seed)
+    gen = torch.Generator().manual_seed(seed + 1)
+    g_src = 0.3 * torch.randn((1, 256, 1), generator=gen)
+    g_tgt = 0.3 * torch.randn((1, 256, 1), generator=gen)
+    noise = torch.randn(1, 192, t, generator=gen)
+    return wave, g_src, g_tgt, noise
+
+
+def test_voice_conversion_matches_reference_at_benchmark_length(golden_dir, synth_sd):
+    """T = 861 frames (10 s @ 22.05 kHz, the length BASELINE.json's metric is quoted on), output of the
+    unmodified reference; the fixture stores o_hat in full and per-channel sums of spec / z / z_p / z_hat."""
+    rec = _load(golden_dir, "vc_b1_t861_benchmark_length")
+    wave, g_src, g_tgt, noise = benchmark_length_inputs(rec)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        spec = vc_oracle.spectrogram(wave)
+        o_hat, _, (z, z_p, z_hat) = vc_oracle.voice_conversion(
+            synth_sd, CONVERTER_MODEL_CONFIG, spec, torch.tensor([spec.shape[2]]), g_src, g_tgt, rec["case"]["tau"],
+            noise, zero_g=rec["case"]["zero_g"])
+    assert spec.shape[2] == 861
+    assert (spec.sum(2) - rec["spec_sum"]).abs().max().item() <= 1e-4 * rec["spec_sum"].abs().max().item()
+    for got, key in ((z, "z_sum"), (z_p, "z_p_sum"), (z_hat, "z_hat_sum")):
+        assert (got.sum(2) - rec[key]).abs().max().item() <= 5e-3, key       # sums of 861 values of |z| ~ 1
+    assert (o_hat - rec["o_hat"]).abs().max().item() <= 2e-5
