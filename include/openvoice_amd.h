@@ -100,7 +100,8 @@ typedef struct ov_conv1d_params {
   int32_t K, dil;        /* taps, dilation; odd K: 'same' padding (K-1)*dil/2; even K: taps t .. t+(K-1)*dil,
                           * no left padding (the framing conv of the spectrogram)                   */
   int32_t epi, flags, split, phase_s;
-  int32_t tiles_per_wg;  /* consecutive time tiles walked by one workgroup; 0 = launcher's choice */
+  int32_t tiles_per_wg;  /* 0 = persistent launch (one workgroup per resident slot, striding over the tiles);
+                          * n > 0 = ceil(tiles / n) workgroups (1: one tile each) -- tests / measurement     */
   int32_t tile;          /* 0 = chosen by the dispatcher; else 1 + tile id (128x128, 64x256,
                           * 32x512, 32x256) -- tuning / measurement knob                         */
   int32_t loaders;       /* loader waves per workgroup: 0 = chosen by the dispatcher, else 1/2/4 */

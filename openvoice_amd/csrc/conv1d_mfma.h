@@ -20,8 +20,11 @@
 // pipe on the k=3 convs.  With the roles split, the matrix waves' vmcnt queue holds weight
 // fragments only.
 //
-// A workgroup walks `tiles_per_wg` consecutive time tiles; the loader runs one chunk ahead across
-// tile boundaries, so only the first tile of a workgroup pays an exposed HBM round trip.
+// Workgroups are persistent: the launch puts as many workgroups on the chip as fit at once and each walks
+// the flattened (utterance, M-block, time-tile) list with the grid as stride.  The loaders run one chunk
+// ahead across tile boundaries and the first weight record of the next tile is requested before the
+// epilogue of the current one, so only the first tile of a workgroup pays the launch / first-round-trip
+// cost (~9 us per workgroup, measured; 20-30 % of a k = 3 tile).
 //
 // fp32 MFMA is bit-exact fmaf-chain arithmetic (no TF32-style truncation on gfx950), so parity
 // with the fp32 reference is limited only by summation order.
@@ -281,8 +284,7 @@ __device__ __forceinline__ bool conv_preload(const ov_conv1d_params& p, f32x16 (
 // The gate epilogue lands at 130 VGPRs on its own; it is held to 128 (4 waves per SIMD, 1-2 VGPRs
 // spilled in the epilogue) because the third workgroup per CU is worth more than the spill costs.
 template <int K, int DIL, int WM, int WN, int WVM, int WVN, int CHUNK, bool VEC, int EPI, int NLD>
-__global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_CONVT_S8 || EPI == EPI_CONVT_S2) ? 4 : 1) void conv1d_mfma_kernel(const ov_conv1d_params p,
-                                                                     const int tiles_per_wg) {
+__global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_CONVT_S8 || EPI == EPI_CONVT_S2) ? 4 : 1) void conv1d_mfma_kernel(const ov_conv1d_params p) {
   static_assert(WVM * WVN == 4, "4 matrix waves per workgroup");
   static_assert(CHUNK % UNIT == 0 && (CHUNK / UNIT == 2 || CHUNK / UNIT == 4), "chunk = 2 or 4 units");
   constexpr int UPC = CHUNK / UNIT;
@@ -307,13 +309,15 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.z;
   const int L = p.L, Cin = p.Cin;
   const int nunits = packed_units(Cin);
   const int nchunks = nunits / UPC;
+  // work list: wid = (b * mblocks + mblock) * ntiles + tile, walked with the grid as stride
   const int ntiles = (L + N_BLK - 1) / N_BLK;
-  const int tile_begin = blockIdx.x * tiles_per_wg;
-  const int tile_end = min(ntiles, tile_begin + tiles_per_wg);
+  const int mblocks = (p.M + 32 * WM * WVM - 1) / (32 * WM * WVM);
+  const int total = ntiles * mblocks * p.B;
+  const int wstride = gridDim.x;
+  if ((int)blockIdx.x >= total) return;
 
   // Written as a chain of equalities on purpose: with `wave >= 4` hipcc (ROCm 7.2) allocates 12 more
   // VGPRs for the matrix path (132 instead of 120), which costs a wave per SIMD and 5-25 % on MI355X.
@@ -326,15 +330,15 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
   if (is_loader) {
     if (OV_EXP == 1) return;
     // ================================ loader waves ===============================================
-    const float* __restrict__ xb = p.x + (int64_t)b * p.x_bstride;
     const float slope = p.in_slope;
     const uint32_t ldx = (uint32_t)p.x_ld;
     const int llane = (wave - 4) * 64 + lane;   // position among the NLD * 64 loader lanes
     // valid INPUT columns: L for 'same' convs; the forward-aligned even-K conv consumes (K-1)*DIL more
     const int Lin = L + ((K % 2 == 1) ? 0 : (K - 1) * DIL);
     int it = 0;
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
-      const int t0 = tile * N_BLK;
+    for (int wid = blockIdx.x; wid < total; wid += wstride) {
+      const int t0 = (wid % ntiles) * N_BLK;
+      const float* __restrict__ xb = p.x + (int64_t)(wid / (ntiles * mblocks)) * p.x_bstride;
       for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
         float* dst = xs + (it & 1) * BUF;
 #pragma unroll 1   // one batch of LB loads per lane in flight at a time: bounds the loader's VGPRs
@@ -397,7 +401,9 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
   // ================================== matrix waves ================================================
   const int wm = wave / WVN, wn = wave % WVN;
   const int recs_per_mtile = nunits * K + 1;
-  const int mtile0 = (blockIdx.y * WVM + wm) * WM;
+  int wid = blockIdx.x;
+  int tile = wid % ntiles, mblk = (wid / ntiles) % mblocks, b = wid / (ntiles * mblocks);
+  int mtile0 = (mblk * WVM + wm) * WM;
 
   // weight fragments: scalar base + per-lane 32-bit index (in 16-byte units), record stride 64
   const f32x4* __restrict__ wbase = reinterpret_cast<const f32x4*>(p.w);
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
   for (int i = 0; i < WM; ++i) a_cur[i] = wbase[widx[i]];
 
   int it = 0;
-  for (int tile = tile_begin; tile < tile_end; ++tile) {
+  while (true) {
     f32x16 acc[WM][WN];
     const bool preloaded = conv_preload<EPI, WM, WN>(p, acc, b, tile * N_BLK + wn * (32 * WN), mtile0, lane);
 
@@ -461,14 +467,34 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
         }
       }
     }
-    // first weight record of the next tile: in flight while the epilogue runs
-    if (tile + 1 < tile_end) {
+    // next work item; its first weight record is in flight while the epilogue of this one runs
+    const int nwid = wid + wstride;
+    const bool more = nwid < total;
+    const int ntile = nwid % ntiles, nmblk = (nwid / ntiles) % mblocks, nb = nwid / (ntiles * mblocks);
+    const int nmtile0 = (nmblk * WVM + wm) * WM;
+    uint32_t nwidx[WM];
 #pragma unroll
-      for (int i = 0; i < WM; ++i) a_cur[i] = wbase[widx[i]];
+    for (int i = 0; i < WM; ++i) nwidx[i] = (uint32_t)(nmtile0 + i) * (uint32_t)recs_per_mtile * 64u + (uint32_t)lane;
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a_cur[i] = wbase[nwidx[i]];
     }
-    conv_epilogue<EPI, WM, WN>(p, acc, b, tile * N_BLK + wn * (32 * WN), mtile0, blockIdx.y * WVM + wm, lane,
-                               preloaded);
+    conv_epilogue<EPI, WM, WN>(p, acc, b, tile * N_BLK + wn * (32 * WN), mtile0, mblk * WVM + wm, lane, preloaded);
+    if (!more) break;
+    wid = nwid; tile = ntile; mblk = nmblk; b = nb; mtile0 = nmtile0;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) widx[i] = nwidx[i];
   }
+}
+
+// Workgroups of one kernel instance that fit on the chip at once (occupancy x CUs).
+inline int query_resident_workgroups(const void* kernel, int block_threads) {
+  int per_cu = 0, dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, 0) != hipSuccess || per_cu <= 0)
+    return 512;   // 2 per CU on an MI355X
+  return per_cu * prop.multiProcessorCount;
 }
 
 typedef int (*conv_launch_fn)(const ov_conv1d_params*, hipStream_t);
@@ -478,13 +504,19 @@ int conv1d_launch(const ov_conv1d_params* p, hipStream_t stream) {
   constexpr int M_BLK = 32 * WM * WVM, N_BLK = 32 * WN * WVN;
   const int ntiles = (p->L + N_BLK - 1) / N_BLK;
   const int mblocks = (p->M + M_BLK - 1) / M_BLK;
-  // Time tiles walked by one workgroup (the loaders run ahead across the tile boundary).  Measured on
-  // MI355X (profiles/r01_s16): 2 is worth 2-5 % for the 32-row tiles and for M >= 256 (stage 0, whose 54
-  // tiles x 2 M-blocks make a coarse grid), nothing at M = 64 / 128; 4 is worse everywhere (coarser tail).
-  const int tpw = p->tiles_per_wg > 0 ? p->tiles_per_wg : ((M_BLK == 32 || p->M >= 256) && ntiles >= 8 ? 2 : 1);
-  dim3 grid((ntiles + tpw - 1) / tpw, mblocks, p->B);
-  hipLaunchKernelGGL((conv1d_mfma_kernel<K, DIL, WM, WN, WVM, WVN, CHUNK, VEC, EPI, NLD>), grid,
-                     dim3(64 * (4 + NLD)), 0, stream, *p, tpw);
+  // Persistent launch: one workgroup per resident slot, each strides over the work list -- when every slot
+  // gets >= 16 tiles, so that the +-1 tile imbalance stays under ~6 %; smaller launches (stage 0 of the
+  // generator: 6.75 tiles per slot, the frame-rate layers) use one workgroup per tile and leave the balancing
+  // to the hardware dispatcher (measured, profiles/r01_s20: persistent +2-5 % at 27 tiles per slot, -5-8 % at
+  // 6.75).  A positive tiles_per_wg forces ceil(total / tiles_per_wg) workgroups (tests, A/B measurements).
+  const long total = (long)ntiles * mblocks * p->B;
+  auto kernel = conv1d_mfma_kernel<K, DIL, WM, WN, WVM, WVN, CHUNK, VEC, EPI, NLD>;
+  static int slots = 0;   // per kernel instance (this function is instantiated once per variant)
+  if (slots == 0) slots = query_resident_workgroups(reinterpret_cast<const void*>(kernel), 64 * (4 + NLD));
+  long nwg = p->tiles_per_wg > 0 ? (total + p->tiles_per_wg - 1) / p->tiles_per_wg
+                                 : (total >= 16L * slots ? (long)slots : total);
+  if (nwg > total) nwg = total;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)nwg), dim3(64 * (4 + NLD)), 0, stream, *p);
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
 }
 
@@ -507,7 +539,7 @@ struct ConvVariant {
 // device pass) and the host-side dispatch table `table` / `table##Count`.
 #define OV_X_INST(K, DIL, TILE, CHUNK, VEC, EPI, NLD)                                                        \
   template __global__ void conv1d_mfma_kernel<K, DIL, OV_TILE_##TILE, CHUNK, (VEC) != 0, EPI, NLD>(           \
-      const ov_conv1d_params, const int);
+      const ov_conv1d_params);
 #define OV_X_ROW(K, DIL, TILE, CHUNK, VEC, EPI, NLD)                                                         \
   {K, DIL, TILE_##TILE, CHUNK, VEC, EPI, NLD,                                                                \
    conv1d_launch<K, DIL, OV_TILE_##TILE, CHUNK, (VEC) != 0, EPI, NLD>},
