@@ -107,21 +107,7 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
       const float mk = mrow ? mrow[col] : 1.f;
       const uint32_t voff = ((uint32_t)q * 32u + 4u * half) * LD + col;
       const uint32_t rbase = (uint32_t)q * 64u + 4u * half;
-      f32x16 v0 = acc[0][j], v1 = acc[1][j];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const uint32_t rr = (r & 3) + 8 * (r >> 2);
-        v0[r] += bias[rbase + rr];
-        v1[r] += bias[rbase + rr + 32u];
-      }
-      if (bias_b) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const uint32_t rr = (r & 3) + 8 * (r >> 2);
-          v0[r] += bias_b[rbase + rr];
-          v1[r] += bias_b[rbase + rr + 32u];
-        }
-      }
+      const f32x16 v0 = acc[0][j], v1 = acc[1][j];   // bias (+ bias_b) already inside (conv_preload)
       if constexpr (EPI == OV_EPI_GATE) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -152,13 +138,7 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
         if (col >= L) continue;
         const float mk = mrow ? mrow[col] : 1.f;
         const uint32_t rbase = mt * 32u + 4u * half;
-        f32x16 v = acc[i][j];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] += bias[rbase + (r & 3) + 8 * (r >> 2)];
-        if (bias_b) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] += bias_b[rbase + (r & 3) + 8 * (r >> 2)];
-        }
+        f32x16 v = acc[i][j];   // bias (+ bias_b) already inside (conv_preload)
         if constexpr (is_convt(EPI)) {
           const uint32_t s = (uint32_t)p.phase_s;
           const uint32_t Lout = LD;   // row stride of the upsampled output (>= L * s)
@@ -245,15 +225,37 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
 template <int EPI, int WM, int WN>
 __device__ __forceinline__ bool conv_preload(const ov_conv1d_params& p, f32x16 (&acc)[WM][WN], int b, int tcol0,
                                              int mtile0, int lane) {
+  // Every epilogue wants v = acc + bias[row] (+ bias_b[b][row]): the accumulators start there, so the
+  // epilogue issues no bias loads (they used to cost one exposed L2 round trip per 32x32 fragment, ~1 us
+  // x WM*WN per tile with the matrix pipe idle).  Rows of padding tiles are left at zero and never stored.
+  const uint32_t half = (uint32_t)lane >> 5;
+  {
+    const float* __restrict__ bias = p.bias;
+    const float* __restrict__ bias_b = p.bias_b ? p.bias_b + (int64_t)b * p.bias_b_bstride : nullptr;
+    const uint32_t row_limit = (EPI == OV_EPI_GATE || EPI == OV_EPI_POSTERIOR || EPI == OV_EPI_MAGNITUDE)
+                                   ? 2u * (uint32_t)p.Cout
+                                   : (is_convt(EPI) ? (uint32_t)p.Cout * (uint32_t)p.phase_s : (uint32_t)p.Cout);
 #pragma unroll
-  for (int i = 0; i < WM; ++i)
+    for (int i = 0; i < WM; ++i) {
+      const uint32_t rbase = (uint32_t)(mtile0 + i) * 32u + 4u * half;
+      f32x16 bv;
 #pragma unroll
-    for (int j = 0; j < WN; ++j)
+      for (int r = 0; r < 16; ++r) bv[r] = 0.f;
+      if (EPI != OV_EPI_MAGNITUDE && (uint32_t)(mtile0 + i) * 32u < row_limit) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) bv[r] = bias[rbase + (r & 3) + 8 * (r >> 2)];
+        if (bias_b) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) bv[r] += bias_b[rbase + (r & 3) + 8 * (r >> 2)];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) acc[i][j] = bv;
+    }
+  }
   if constexpr (EPI != OV_EPI_LINEAR) return false;
   if (!p.res || (p.flags & OV_F_MASK_V)) return false;   // v*mask + res keeps the epilogue order
-  const uint32_t L = (uint32_t)p.L, LD = (uint32_t)p.out_ld, half = (uint32_t)lane >> 5;
+  const uint32_t L = (uint32_t)p.L, LD = (uint32_t)p.out_ld;
   const float* resb = p.res + (int64_t)b * p.res_bstride;
   const float* addb = p.add ? p.add + (int64_t)b * p.add_bstride : nullptr;
   const uint32_t col0 = (uint32_t)tcol0 + ((uint32_t)lane & 31u);
@@ -267,7 +269,7 @@ __device__ __forceinline__ bool conv_preload(const ov_conv1d_params& p, f32x16 (
       if (col >= L) continue;
       const uint32_t voff = (mt * 32u + 4u * half) * LD + col;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = (resb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff];
+      for (int r = 0; r < 16; ++r) acc[i][j][r] += (resb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff];
       if (addb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] += (addb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff];
