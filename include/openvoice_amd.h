@@ -241,6 +241,29 @@ int ov_expand_prior_f32(const float* m_tok, const float* logs_tok, int64_t tok_b
                         float* m_p, float* logs_p, float* attn, int B, int C, int Tx, int Ty, int ldy,
                         float noise_scale, ov_stream_t stream);
 
+/* ---- bf16 generator (BASELINE.json configs[4]; reference openvoice/models.py:272-291, modules.py:296-306) ------
+ * Channels-last bf16 activations (B, L, C): C contiguous, rows dense.  bf16 values are passed as uint16_t bit
+ * patterns.  Accumulation and bias are fp32; outputs are rounded to nearest even. */
+typedef struct ov_conv1d_bf16_params {
+  const uint16_t* x;    /* [B][L][Cin] bf16                                                              */
+  const uint16_t* w;    /* packed by ov_conv1d_bf16_pack                                                  */
+  const float* bias;    /* [Cout] fp32 or NULL                                                            */
+  uint16_t* out;        /* [B][L][Cout] bf16                                                              */
+  const uint16_t* res;  /* residual, like out, or NULL                                                    */
+  const uint16_t* add;  /* second addend (MRF running sum), like out, or NULL                             */
+  int32_t B, L, Cin, Cout, K, dil;   /* 'same' padding (K-1)*dil/2; Cin % 32 == 0, Cout % 32 == 0, <= 256 */
+  float in_slope;       /* leaky-ReLU slope applied to x while staging (1.0f = identity)                  */
+  float scale;          /* out = (conv + bias + res + add) * scale                                        */
+} ov_conv1d_bf16_params;
+
+/* Number of bf16 elements ov_conv1d_bf16_pack writes for a dense fp32 [Cout][Cin][K] weight (0 if unsupported). */
+size_t ov_conv1d_bf16_pack_size(int Cout, int Cin, int K);
+/* Round a dense HOST fp32 weight to bf16 and lay it out in MFMA B-fragment order (HOST dst). */
+int ov_conv1d_bf16_pack(const float* w, int Cout, int Cin, int K, uint16_t* dst);
+/* ResBlock conv of the generator in bf16: out = (conv1d(lrelu(x)) + bias [+ res] [+ add]) * scale
+ * (reference openvoice/modules.py:296-306, models.py:280-286), k in {3,7,11}, dilation in {1,3,5}. */
+int ov_conv1d_bf16cl(const ov_conv1d_bf16_params* p, ov_stream_t stream);
+
 /* Library/ABI version (major*100 + minor). */
 int ov_version(void);
 

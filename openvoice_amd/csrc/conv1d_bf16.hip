@@ -1,0 +1,277 @@
+// bf16 channels-last Conv1d for the HiFi-GAN generator (BASELINE.json configs[4]: "bf16 HiFi-GAN decoder",
+// SURVEY.md section 8f item 3).  Activations live in HBM as bf16 (B, L, C) -- channels contiguous -- so that the
+// 8 consecutive-k bf16 values a lane feeds to v_mfma_f32_32x32x16_bf16 are ONE aligned 16-byte LDS read; with
+// the fp32 path's (B, C, L) layout the same operand would be 8 reads from 8 rows.  In bf16 the generator is
+// HBM-bound (13.6 ms of matrix time against ~23 ms of tensor traffic at batch 64), so
+// the kernel is organised around traffic: one workgroup produces ALL output channels of its time tile (x is
+// read once, out written once; the residual and the MRF running sum start in the accumulators), fp32
+// accumulation, fp32 bias, round-to-nearest-even on the way out.
+//
+// GEMM view: D[t][co] = sum_{tap, ci} X[t + tap*DIL - PAD][ci] * W[co][ci][tap];  M = time (A operand, from
+// LDS), N = output channels (B operand: weights pre-packed in fragment order, streamed from L2), K = (tap, ci).
+// Any consistent labelling of the 16 k-slots of one MFMA works because A and B use the same one: slot (h, i)
+// of a lane (h = lane >> 5, i < 8) is input channel 16*kb + 8*h + i of the current chunk in both operands.
+//
+// Workgroup = 4 matrix waves + 2 loader waves, as in conv1d_mfma.h: the loaders stage 32-channel chunks of
+// the time tile (+ halo, leaky-ReLU applied in fp32 on the way in, zero outside [0, L)) into a double-buffered
+// LDS tile with an 80-byte row pitch (conflict-free ds_read_b128 for 32 consecutive rows).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include "openvoice_amd.h"
+
+namespace ovk16 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CH = 32;          // input channels per LDS chunk = 2 MFMA k-blocks
+constexpr int PITCH = 80;       // bytes per LDS row: 64 data + 16 pad
+constexpr int NLD = 2;          // loader waves
+
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  __bf16 h = (__bf16)f;         // v_cvt_pk_bf16_f32: round to nearest even
+  uint16_t u;
+  __builtin_memcpy(&u, &h, 2);
+  return u;
+}
+
+// WM x WN fragments of 32x32 per matrix wave; WVT x WVC matrix waves (time x channel) per workgroup.
+template <int K, int DIL, int WM, int WN, int WVT, int WVC>
+__global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_conv1d_bf16_params p) {
+  static_assert(WVT * WVC == 4, "4 matrix waves");
+  constexpr int TT = 32 * WM * WVT;             // time rows per workgroup
+  constexpr int PAD = (K - 1) * DIL / 2;
+  constexpr int R = TT + 2 * PAD;               // staged rows
+  constexpr int BUF = R * PITCH;                // bytes per LDS buffer
+  constexpr int NITEM = R * 4;                  // 16-byte vectors per chunk
+  constexpr int PER_LANE = (NITEM + 64 * NLD - 1) / (64 * NLD);
+  __shared__ __attribute__((aligned(16))) unsigned char xs[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * TT;
+  const int L = p.L, Cin = p.Cin, Cout = p.Cout;
+  const int nchunks = Cin / CH;
+
+  bool is_loader = false;
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) is_loader |= (wave == 4 + i);
+  if (is_loader) {
+    const uint16_t* __restrict__ xb = p.x + (int64_t)b * L * Cin;
+    const float slope = p.in_slope;
+    const int llane = (wave - 4) * 64 + lane;
+    for (int c = 0; c < nchunks; ++c) {
+      unsigned char* dst = xs + (c & 1) * BUF;
+      u32x4 stg[PER_LANE];
+      int ok[PER_LANE];
+#pragma unroll
+      for (int i = 0; i < PER_LANE; ++i) {
+        const int idx = i * (64 * NLD) + llane;
+        const int row = idx >> 2, q = idx & 3;
+        const int t = t0 - PAD + row;
+        ok[i] = (idx < NITEM && t >= 0 && t < L) ? 1 : 0;
+        const int64_t off = ok[i] ? ((int64_t)t * Cin + c * CH + q * 8) : 0;
+        stg[i] = *reinterpret_cast<const u32x4*>(xb + off);
+      }
+#pragma unroll
+      for (int i = 0; i < PER_LANE; ++i) {
+        const int idx = i * (64 * NLD) + llane;
+        if (idx < NITEM) {
+          u32x4 v = stg[i];
+          if (!ok[i]) v = u32x4{0u, 0u, 0u, 0u};
+          else if (slope != 1.f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+              lo = lo > 0.f ? lo : lo * slope;
+              hi = hi > 0.f ? hi : hi * slope;
+              v[e] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+            }
+          }
+          *reinterpret_cast<u32x4*>(dst + (idx >> 2) * PITCH + (idx & 3) * 16) = v;
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---------------------------------- matrix waves ---------------------------------------------------
+  const int wt = wave / WVC, wc = wave % WVC;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ntile0 = wc * WN;                               // first 32-channel output tile of this wave
+  const int trow0 = wt * (32 * WM);                         // first time row (within the workgroup tile)
+  const int ntiles_co = (Cout + 31) / 32;
+
+  // accumulators start at bias (+ residual + running sum): nothing is read in the epilogue
+  f32x16 acc[WM][WN];
+  {
+    const uint16_t* resb = p.res ? p.res + (int64_t)b * L * Cout : nullptr;
+    const uint16_t* addb = p.add ? p.add + (int64_t)b * L * Cout : nullptr;
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+      const int co = 32 * (ntile0 + n) + l31;
+      const float bv = (p.bias && co < Cout) ? p.bias[co] : 0.f;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t = t0 + trow0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float v = bv;
+          if (t < L && co < Cout) {
+            if (resb) v += bf2f(resb[(int64_t)t * Cout + co]);
+            if (addb) v += bf2f(addb[(int64_t)t * Cout + co]);
+          }
+          acc[i][n][r] = v;
+        }
+      }
+    }
+  }
+
+  // packed weights: record index ((nt * nchunks + c) * K + tap) * 2 + kb, 64 lanes x 16 bytes each
+  const u32x4* __restrict__ wbase = reinterpret_cast<const u32x4*>(p.w);
+  uint32_t widx[WN];
+#pragma unroll
+  for (int n = 0; n < WN; ++n) widx[n] = (uint32_t)(ntile0 + n) * (uint32_t)(nchunks * K * 2) * 64u + (uint32_t)lane;
+  const bool wave_has_cols = ntile0 < ntiles_co;
+
+  u32x4 bcur[WN], bnxt[WN];
+#pragma unroll
+  for (int n = 0; n < WN; ++n) bcur[n] = wave_has_cols && (ntile0 + n) < ntiles_co ? wbase[widx[n]] : u32x4{0u, 0u, 0u, 0u};
+  // per-lane LDS byte offset of the A operand: row (trow0 + lane & 31), k-slot half
+  const int xl_off = (trow0 + l31) * PITCH + half * 16;
+
+  int rec = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();
+    const unsigned char* xl = xs + (c & 1) * BUF + xl_off;
+    constexpr int STEPS = 2 * K;                            // (tap, k-block) pairs of one chunk
+    u32x4 acur[WM], anxt[WM];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) acur[i] = *reinterpret_cast<const u32x4*>(xl + (32 * i) * PITCH);   // tap 0, kb 0
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      ++rec;   // one zero record per output tile is appended by the packer for the final prefetch
+#pragma unroll
+      for (int n = 0; n < WN; ++n)
+        bnxt[n] = (ntile0 + n) < ntiles_co ? (wbase + (size_t)rec * 64)[widx[n]] : u32x4{0u, 0u, 0u, 0u};
+      if (s + 1 < STEPS) {
+        const int tap = (s + 1) >> 1, kb = (s + 1) & 1;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+          anxt[i] = *reinterpret_cast<const u32x4*>(xl + (32 * i + tap * DIL) * PITCH + kb * 32);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+          bf16x8 av, bv;
+          __builtin_memcpy(&av, &acur[i], 16);
+          __builtin_memcpy(&bv, &bcur[n], 16);
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][n], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n = 0; n < WN; ++n) bcur[n] = bnxt[n];
+      if (s + 1 < STEPS) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) acur[i] = anxt[i];
+      }
+    }
+  }
+
+  // ---- epilogue: scale, round to bf16, store channels-last (32 lanes = 64 contiguous bytes) -------------
+  uint16_t* outb = p.out + (int64_t)b * L * Cout;
+  const float scale = p.scale;
+#pragma unroll
+  for (int n = 0; n < WN; ++n) {
+    const int co = 32 * (ntile0 + n) + l31;
+    if (co >= Cout) continue;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = t0 + trow0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (t < L) outb[(int64_t)t * Cout + co] = f2bf(acc[i][n][r] * scale);
+      }
+    }
+  }
+}
+
+template <int K, int DIL, int WM, int WN, int WVT, int WVC>
+int launch(const ov_conv1d_bf16_params* p, hipStream_t stream) {
+  constexpr int TT = 32 * WM * WVT;
+  dim3 grid((p->L + TT - 1) / TT, p->B);
+  hipLaunchKernelGGL((conv1d_bf16cl_kernel<K, DIL, WM, WN, WVT, WVC>), grid, dim3(64 * (4 + NLD)), 0, stream, *p);
+  return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
+}
+
+// wave layouts by output width: 256 -> 64 t x 256 co, 128 -> 128 t x 128 co, 64 -> 256 t x 64 co, 32 -> 256 t x 32 co
+template <int K, int DIL>
+int launch_by_width(const ov_conv1d_bf16_params* p, hipStream_t stream) {
+  if (p->Cout > 128) return launch<K, DIL, 2, 2, 1, 4>(p, stream);
+  if (p->Cout > 64) return launch<K, DIL, 2, 2, 2, 2>(p, stream);
+  if (p->Cout > 32) return launch<K, DIL, 2, 2, 4, 1>(p, stream);
+  return launch<K, DIL, 2, 1, 4, 1>(p, stream);
+}
+
+}  // namespace ovk16
+
+using namespace ovk16;
+
+extern "C" {
+
+size_t ov_conv1d_bf16_pack_size(int Cout, int Cin, int K) {
+  if (Cout <= 0 || Cin <= 0 || K <= 0 || Cin % CH != 0) return 0;
+  const size_t ntiles = (Cout + 31) / 32;
+  return (ntiles * (size_t)(Cin / CH) * K * 2 + 1) * 64 * 8;   // bf16 elements; + one zero record
+}
+
+int ov_conv1d_bf16_pack(const float* w, int Cout, int Cin, int K, uint16_t* dst) {
+  if (!w || !dst || Cout <= 0 || Cin <= 0 || K <= 0 || Cin % CH != 0) return OV_E_BADARG;
+  const int ntiles = (Cout + 31) / 32, nchunks = Cin / CH;
+  std::memset(dst, 0, ov_conv1d_bf16_pack_size(Cout, Cin, K) * sizeof(uint16_t));
+  auto to_bf16 = [](float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                            // round to nearest even
+    return (uint16_t)(u >> 16);
+  };
+  for (int nt = 0; nt < ntiles; ++nt)
+    for (int c = 0; c < nchunks; ++c)
+      for (int tap = 0; tap < K; ++tap)
+        for (int kb = 0; kb < 2; ++kb) {
+          uint16_t* rec = dst + ((((size_t)nt * nchunks + c) * K + tap) * 2 + kb) * 64 * 8;
+          for (int lane = 0; lane < 64; ++lane)
+            for (int i = 0; i < 8; ++i) {
+              const int co = 32 * nt + (lane & 31);
+              const int ci = c * CH + 16 * kb + 8 * (lane >> 5) + i;
+              if (co < Cout) rec[lane * 8 + i] = to_bf16(w[((size_t)co * Cin + ci) * K + tap]);
+            }
+        }
+  return OV_OK;
+}
+
+int ov_conv1d_bf16cl(const ov_conv1d_bf16_params* p, ov_stream_t stream) {
+  if (!p || !p->x || !p->w || !p->out) return OV_E_BADARG;
+  if (p->B <= 0 || p->L <= 0 || p->Cin <= 0 || p->Cout <= 0 || p->B > 65535) return OV_E_BADARG;
+  if (p->Cin % CH != 0 || p->Cout % 32 != 0 || p->Cout > 256) return OV_E_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(p->x) & 15) || (reinterpret_cast<uintptr_t>(p->w) & 15)) return OV_E_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define OV16_CASE(KK, DD) if (p->K == KK && p->dil == DD) return launch_by_width<KK, DD>(p, st);
+  OV16_CASE(3, 1) OV16_CASE(3, 3) OV16_CASE(3, 5)
+  OV16_CASE(7, 1) OV16_CASE(7, 3) OV16_CASE(7, 5)
+  OV16_CASE(11, 1) OV16_CASE(11, 3) OV16_CASE(11, 5)
+#undef OV16_CASE
+  return OV_E_UNSUPPORTED;
+}
+
+}  // extern "C"

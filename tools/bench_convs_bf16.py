@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Per-shape timing of the bf16 channels-last conv on the MRF shapes of BASELINE.json configs[4] (batch 64):
+achieved HBM GB/s (algorithmic bytes: x + out [+ res + add], 2 bytes per element) and matrix TF/s.  Measurement tool."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from openvoice_amd.bf16 import PackedConvBf16, launch_conv_bf16  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    dev, B = "cuda:0", args.batch
+    print(f"B={B}  (HBM peak 8000 GB/s spec, ~6300 achievable; bf16 MFMA peak 2500 TF/s)")
+    print(f"{'C':>4} {'L':>7} {'k':>2} {'d':>1} {'epi':>8} {'ms':>8} {'GB/s':>8} {'TF/s':>7}")
+    for c, L in [(256, 6888), (128, 55104), (64, 110208), (32, 220416)]:
+        x = torch.randn(B, L, c, device=dev).to(torch.bfloat16)
+        res, add = torch.randn_like(x), torch.randn_like(x)
+        out = torch.empty_like(x)
+        for k in (3, 7, 11):
+            for d, mode in ((1, "plain"), (5, "plain"), (1, "res+add")):
+                layer = PackedConvBf16(torch.randn(c, c, k) * (c * k) ** -0.5, torch.zeros(c), dev, dil=d)
+                kw = dict(in_slope=0.1)
+                passes = 2
+                if mode != "plain":
+                    kw.update(res=res, add=add, scale=1.0 / 3.0)
+                    passes = 4
+                for _ in range(2):
+                    launch_conv_bf16(layer, x, out, **kw)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.reps):
+                    launch_conv_bf16(layer, x, out, **kw)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / args.reps
+                gbs = passes * 2.0 * B * c * L / ms / 1e6
+                tf = 2.0 * c * c * k * L * B / ms / 1e9
+                print(f"{c:>4} {L:>7} {k:>2} {d:>1} {mode:>8} {ms:8.3f} {gbs:8.0f} {tf:7.1f}", flush=True)
+        del x, res, add, out
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
