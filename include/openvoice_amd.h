@@ -251,7 +251,10 @@ typedef struct ov_conv1d_bf16_params {
   uint16_t* out;        /* [B][L][Cout] bf16                                                              */
   const uint16_t* res;  /* residual, like out, or NULL                                                    */
   const uint16_t* add;  /* second addend (MRF running sum), like out, or NULL                             */
-  int32_t B, L, Cin, Cout, K, dil;   /* 'same' padding (K-1)*dil/2; Cin % 32 == 0, Cout % 32 == 0, <= 256 */
+  int32_t B, L, Cin, Cout, K, dil;   /* 'same' padding (K-1)*dil/2; Cin % 32 == 0, Cout % 32 == 0         */
+  int32_t phase_s;      /* > 1: ConvTranspose as a phase conv -- Cout = phase_s * C columns ordered
+                         * (phase, c); column (ph, c) of row t is written to out[b][t * phase_s + ph][c]    */
+  int32_t bias_bstride; /* elements between the bias vectors of consecutive batch items (0 = shared)     */
   float in_slope;       /* leaky-ReLU slope applied to x while staging (1.0f = identity)                  */
   float scale;          /* out = (conv + bias + res + add) * scale                                        */
 } ov_conv1d_bf16_params;
@@ -260,9 +263,14 @@ typedef struct ov_conv1d_bf16_params {
 size_t ov_conv1d_bf16_pack_size(int Cout, int Cin, int K);
 /* Round a dense HOST fp32 weight to bf16 and lay it out in MFMA B-fragment order (HOST dst). */
 int ov_conv1d_bf16_pack(const float* w, int Cout, int Cin, int K, uint16_t* dst);
-/* ResBlock conv of the generator in bf16: out = (conv1d(lrelu(x)) + bias [+ res] [+ add]) * scale
- * (reference openvoice/modules.py:296-306, models.py:280-286), k in {3,7,11}, dilation in {1,3,5}. */
+/* Generator convs in bf16: out = (conv1d(lrelu(x)) + bias [+ res] [+ add]) * scale -- the ResBlock convs
+ * (reference openvoice/modules.py:296-306, models.py:280-286; k in {3,7,11}, dilation in {1,3,5}), conv_pre (k7,
+ * per-utterance bias = dec.cond, models.py:273-275) and, with phase_s, the ConvTranspose ups (models.py:278-279). */
 int ov_conv1d_bf16cl(const ov_conv1d_bf16_params* p, ov_stream_t stream);
+/* leaky_relu + conv_post (C -> 1, no bias) + tanh on the bf16 channels-last tensor, fp32 output [B][L]
+ * (reference openvoice/models.py:287-289); w is the dense [C][K] fp32 DEVICE weight.  C = 32, K = 7. */
+int ov_conv_post_tanh_bf16(const uint16_t* x, const float* w, float* out, int B, int C, int L, int K, float in_slope,
+                           ov_stream_t stream);
 
 /* Library/ABI version (major*100 + minor). */
 int ov_version(void);

@@ -45,7 +45,8 @@ class ConvBf16Params(ctypes.Structure):
     """Mirror of ``ov_conv1d_bf16_params`` (include/openvoice_amd.h)."""
     _fields_ = [("x", _fp), ("w", _fp), ("bias", _fp), ("out", _fp), ("res", _fp), ("add", _fp),
                 ("B", ctypes.c_int32), ("L", ctypes.c_int32), ("Cin", ctypes.c_int32), ("Cout", ctypes.c_int32),
-                ("K", ctypes.c_int32), ("dil", ctypes.c_int32), ("in_slope", ctypes.c_float), ("scale", ctypes.c_float)]
+                ("K", ctypes.c_int32), ("dil", ctypes.c_int32), ("phase_s", ctypes.c_int32), ("bias_bstride", ctypes.c_int32),
+                ("in_slope", ctypes.c_float), ("scale", ctypes.c_float)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check every header symbol exists.
@@ -67,6 +68,7 @@ SIGNATURES = {
     "ov_conv1d_bf16_pack_size": (ctypes.c_size_t, [_i, _i, _i]),
     "ov_conv1d_bf16_pack": (ctypes.c_int, [_fp, _i, _i, _i, _fp]),
     "ov_conv1d_bf16cl": (ctypes.c_int, [ctypes.POINTER(ConvBf16Params), _fp]),
+    "ov_conv_post_tanh_bf16": (ctypes.c_int, [_fp, _fp, _fp, _i, _i, _i, _i, ctypes.c_float, _fp]),
     "ov_frame_hops_f32": (ctypes.c_int, [_fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
     "ov_embed_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, ctypes.c_float, _fp]),
     "ov_layernorm_ch_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, ctypes.c_float, _i, _fp]),

@@ -40,3 +40,109 @@ def launch_conv_bf16(layer, x, out, in_slope=1.0, scale=1.0, res=None, add=None)
     p.in_slope, p.scale = in_slope, scale
     stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(_lib.load().ov_conv1d_bf16cl(ctypes.byref(p), stream), "ov_conv1d_bf16cl")
+
+
+def _launch(layer, x, out, L, in_slope=1.0, scale=1.0, res=None, add=None, phase_s=0, bias=None, bias_bstride=0):
+    B = x.shape[0]
+    p = ConvBf16Params()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    bias = layer.bias if bias is None else bias
+    p.x, p.w, p.bias, p.out, p.res, p.add = vp(x), vp(layer.w), vp(bias), vp(out), vp(res), vp(add)
+    p.B, p.L, p.Cin, p.Cout, p.K, p.dil = B, L, layer.cin, layer.cout, layer.K, layer.dil
+    p.phase_s, p.bias_bstride, p.in_slope, p.scale = phase_s, bias_bstride, in_slope, scale
+    stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(_lib.load().ov_conv1d_bf16cl(ctypes.byref(p), stream), "ov_conv1d_bf16cl")
+
+
+class GeneratorBf16:
+    """HiFi-GAN generator (reference: openvoice/models.py:272-291) with bf16 activations in HBM, channels-last,
+    fp32 accumulation -- BASELINE.json configs[4].  Same load-time algebra as the fp32 engine (weight-norm folded,
+    ConvTranspose as a 3-tap phase conv, MRF mean folded into the last conv's scale); the residual and the MRF
+    running sum are added on the matrix pipe (identity rounds, csrc/conv1d_bf16.hip)."""
+
+    def __init__(self, state_dict, model_cfg, device):
+        from .engine import conv_transpose_as_conv
+        from .params import effective_weight
+        sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
+        cfg = dict(model_cfg.items()) if hasattr(model_cfg, "items") else dict(model_cfg)
+        self.cfg, self.device = cfg, torch.device(device)
+        dev = self.device
+        self.conv_pre = PackedConvBf16(sd["dec.conv_pre.weight"], sd["dec.conv_pre.bias"], dev)
+        self.cond_w = sd["dec.cond.weight"][:, :, 0].contiguous().to(dev)
+        self.cond_b = (sd["dec.cond.bias"] + sd["dec.conv_pre.bias"]).contiguous().to(dev)   # conv_pre bias folded in
+        self.ups, self.resblocks = [], []
+        ch = cfg["upsample_initial_channel"]
+        for i, (u, k) in enumerate(zip(cfg["upsample_rates"], cfg["upsample_kernel_sizes"])):
+            wc = conv_transpose_as_conv(effective_weight(sd, f"dec.ups.{i}"), u)      # rows co*u + ph
+            co = ch // 2
+            wc = wc.reshape(co, u, ch, 3).transpose(0, 1).reshape(u * co, ch, 3)       # rows ph*co + c
+            bias = sd[f"dec.ups.{i}.bias"].repeat(u)
+            self.ups.append(dict(conv=PackedConvBf16(wc, bias, dev), stride=u))
+            ch = co
+            stage = []
+            for j, (rk, rd) in enumerate(zip(cfg["resblock_kernel_sizes"], cfg["resblock_dilation_sizes"])):
+                rb = f"dec.resblocks.{i * len(cfg['resblock_kernel_sizes']) + j}"
+                stage.append([(PackedConvBf16(effective_weight(sd, f"{rb}.convs1.{n}"), sd[f"{rb}.convs1.{n}.bias"], dev, dil=d),
+                               PackedConvBf16(effective_weight(sd, f"{rb}.convs2.{n}"), sd[f"{rb}.convs2.{n}.bias"], dev, dil=1))
+                              for n, d in enumerate(rd)])
+            self.resblocks.append(stage)
+        self.final_channels = ch
+        self.post_w = sd["dec.conv_post.weight"][0].contiguous().to(dev)              # [C, 7] fp32
+        self._ws = {}
+
+    def _workspace(self, B, T):
+        key = (B, T)
+        if key not in self._ws:
+            self._ws.clear()
+            ch, L, biggest = self.cfg["upsample_initial_channel"], T, 0
+            for u in self.cfg["upsample_rates"]:
+                ch //= 2
+                L *= u
+                biggest = max(biggest, ch * L)
+            f = lambda n: torch.empty(n, dtype=torch.bfloat16, device=self.device)
+            self._ws[key] = dict(pre=f(B * T * self.cfg["upsample_initial_channel"]), dec=[f(B * biggest) for _ in range(5)])
+        return self._ws[key]
+
+    @torch.no_grad()
+    def decode(self, z, g):
+        """``z`` [B, inter, T] fp32 (channels-first, as the flow produces it), ``g`` [B or 1, gin, 1] ->
+        waveform [B, 1, T * prod(upsample_rates)] fp32."""
+        from .engine import FINAL_LRELU_SLOPE, LRELU_SLOPE
+        lib, dev = _lib.load(), self.device
+        B, C, T = z.shape
+        ws = self._workspace(B, T)
+        x = z.to(dev, torch.float32).transpose(1, 2).to(torch.bfloat16).contiguous()        # [B, T, C] bf16
+        g2 = g.to(dev, torch.float32).reshape(g.shape[0], -1)
+        cond = torch.addmm(self.cond_b, g2, self.cond_w.t()).expand(B, -1).contiguous()      # [B, 512] fp32, T = 1 GEMV
+        ch = self.cfg["upsample_initial_channel"]
+        pre = ws["pre"][: B * T * ch].view(B, T, ch)
+        _launch(self.conv_pre, x, pre, T, bias=cond, bias_bstride=ch)
+        cur_x, L = pre, T
+        free = list(ws["dec"])
+        nk = len(self.cfg["resblock_kernel_sizes"])
+        for i, up in enumerate(self.ups):
+            s = up["stride"]
+            cin, ch = ch, ch // 2
+            u = free.pop()[: B * L * s * ch].view(B, L * s, ch)
+            _launch(up["conv"], cur_x, u, L, in_slope=LRELU_SLOPE, phase_s=s)
+            L *= s
+            t1, ra, acc = (free.pop()[: B * L * ch].view(B, L, ch) for _ in range(3))
+            for j, pairs in enumerate(self.resblocks[i]):
+                cur = u
+                for n, (c1, c2) in enumerate(pairs):
+                    _launch(c1, cur, t1, L, in_slope=LRELU_SLOPE)
+                    last = n == len(pairs) - 1
+                    dst = acc if last else ra
+                    _launch(c2, t1, dst, L, in_slope=LRELU_SLOPE, res=cur, add=acc if (last and j > 0) else None,
+                            scale=1.0 / nk if (last and j == nk - 1) else 1.0)
+                    cur = dst
+            free = list(ws["dec"])
+            # keep the stage output out of the way of the next stage's scratch
+            free.remove(next(b for b in free if b.data_ptr() == acc.data_ptr()))
+            cur_x = acc
+        o = torch.empty(B, 1, L, dtype=torch.float32, device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.ov_conv_post_tanh_bf16(ctypes.c_void_p(cur_x.data_ptr()), ctypes.c_void_p(self.post_w.data_ptr()),
+                                              ctypes.c_void_p(o.data_ptr()), B, ch, L, self.post_w.shape[1],
+                                              FINAL_LRELU_SLOPE, st), "ov_conv_post_tanh_bf16")
+        return o

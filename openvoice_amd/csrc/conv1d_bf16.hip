@@ -62,30 +62,46 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
   bool is_loader = false;
 #pragma unroll
   for (int i = 0; i < NLD; ++i) is_loader |= (wave == 4 + i);
+  // rounds of the workgroup: the Cin/32 chunks of x (all taps), then -- instead of reading the residual and the
+  // MRF running sum element-wise into the accumulators (2-byte loads, 128 memory instructions per wave and tile:
+  // measured 5x slower than the conv itself) -- the Cout/32 chunks of `res` and of `add`, staged through the same
+  // LDS tile and added on the matrix pipe with an identity B fragment (exact: bf16 x 1.0 into fp32).
+  const int nco = (Cout + 31) / 32;
+  const int rounds_x = nchunks, rounds_res = p.res ? nco : 0, rounds_add = p.add ? nco : 0;
+  const int rounds = rounds_x + rounds_res + rounds_add;
   if (is_loader) {
-    const uint16_t* __restrict__ xb = p.x + (int64_t)b * L * Cin;
-    const float slope = p.in_slope;
     const int llane = (wave - 4) * 64 + lane;
-    for (int c = 0; c < nchunks; ++c) {
-      unsigned char* dst = xs + (c & 1) * BUF;
-      u32x4 stg[PER_LANE];
-      int ok[PER_LANE];
+    const float slope = p.in_slope;
+    u32x4 stg[PER_LANE];
+    int ok[PER_LANE];
+    // issue the 16-byte loads of round `rd` into registers (they stay in flight across the barrier)
+    auto issue = [&](int rd) {
+      const uint16_t* src;
+      int cw, c, rlo, rhi;
+      if (rd < rounds_x) { src = p.x + (int64_t)b * L * Cin; cw = Cin; c = rd; rlo = 0; rhi = R; }
+      else if (rd < rounds_x + rounds_res) { src = p.res + (int64_t)b * L * Cout; cw = Cout; c = rd - rounds_x; rlo = PAD; rhi = PAD + TT; }
+      else { src = p.add + (int64_t)b * L * Cout; cw = Cout; c = rd - rounds_x - rounds_res; rlo = PAD; rhi = PAD + TT; }
 #pragma unroll
       for (int i = 0; i < PER_LANE; ++i) {
         const int idx = i * (64 * NLD) + llane;
         const int row = idx >> 2, q = idx & 3;
         const int t = t0 - PAD + row;
-        ok[i] = (idx < NITEM && t >= 0 && t < L) ? 1 : 0;
-        const int64_t off = ok[i] ? ((int64_t)t * Cin + c * CH + q * 8) : 0;
-        stg[i] = *reinterpret_cast<const u32x4*>(xb + off);
+        ok[i] = (idx < NITEM && row >= rlo && row < rhi && t >= 0 && t < L) ? 1 : 0;
+        const int64_t off = ok[i] ? ((int64_t)t * cw + c * CH + q * 8) : 0;
+        stg[i] = *reinterpret_cast<const u32x4*>(src + off);
       }
+    };
+    issue(0);
+    for (int rd = 0; rd < rounds; ++rd) {
+      unsigned char* dst = xs + (rd & 1) * BUF;
+      const bool act = rd < rounds_x && slope != 1.f;
 #pragma unroll
       for (int i = 0; i < PER_LANE; ++i) {
         const int idx = i * (64 * NLD) + llane;
         if (idx < NITEM) {
           u32x4 v = stg[i];
           if (!ok[i]) v = u32x4{0u, 0u, 0u, 0u};
-          else if (slope != 1.f) {
+          else if (act) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
@@ -97,6 +113,7 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
           *reinterpret_cast<u32x4*>(dst + (idx >> 2) * PITCH + (idx & 3) * 16) = v;
         }
       }
+      if (rd + 1 < rounds) issue(rd + 1);   // next round's loads fly while the matrix waves work on this one
       __syncthreads();
     }
     return;
@@ -105,33 +122,20 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
   // ---------------------------------- matrix waves ---------------------------------------------------
   const int wt = wave / WVC, wc = wave % WVC;
   const int half = lane >> 5, l31 = lane & 31;
-  const int ntile0 = wc * WN;                               // first 32-channel output tile of this wave
+  const int ntile0 = (blockIdx.z * WVC + wc) * WN;          // first 32-column output tile of this wave
   const int trow0 = wt * (32 * WM);                         // first time row (within the workgroup tile)
   const int ntiles_co = (Cout + 31) / 32;
 
-  // accumulators start at bias (+ residual + running sum): nothing is read in the epilogue
+  // accumulators start at the bias; residual and running sum arrive as identity rounds (see above)
   f32x16 acc[WM][WN];
-  {
-    const uint16_t* resb = p.res ? p.res + (int64_t)b * L * Cout : nullptr;
-    const uint16_t* addb = p.add ? p.add + (int64_t)b * L * Cout : nullptr;
 #pragma unroll
-    for (int n = 0; n < WN; ++n) {
-      const int co = 32 * (ntile0 + n) + l31;
-      const float bv = (p.bias && co < Cout) ? p.bias[co] : 0.f;
+  for (int n = 0; n < WN; ++n) {
+    const int co = 32 * (ntile0 + n) + l31;
+    const float bv = (p.bias && co < Cout) ? p.bias[(int64_t)b * p.bias_bstride + co] : 0.f;
 #pragma unroll
-      for (int i = 0; i < WM; ++i) {
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int t = t0 + trow0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-          float v = bv;
-          if (t < L && co < Cout) {
-            if (resb) v += bf2f(resb[(int64_t)t * Cout + co]);
-            if (addb) v += bf2f(addb[(int64_t)t * Cout + co]);
-          }
-          acc[i][n][r] = v;
-        }
-      }
-    }
+      for (int r = 0; r < 16; ++r) acc[i][n][r] = bv;
   }
 
   // packed weights: record index ((nt * nchunks + c) * K + tap) * 2 + kb, 64 lanes x 16 bytes each
@@ -187,19 +191,53 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
     }
   }
 
+  // ---- identity rounds: acc += res, acc += add ----------------------------------------------------------
+  for (int rd = rounds_x; rd < rounds; ++rd) {
+    __syncthreads();
+    const int c = (rd - rounds_x) % nco;                    // 32-channel chunk of res / add staged this round
+    const unsigned char* xl = xs + (rd & 1) * BUF + xl_off + PAD * PITCH;
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+      if (c != ntile0 + n) continue;                        // only the wave that owns these 32 output channels
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        u32x4 idw;                                          // B[k][n] = 1 iff k-slot (kb, half, e) is channel n
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k0 = 16 * kb + 8 * half + 2 * e;
+          idw[e] = (k0 == l31 ? 0x3f80u : 0u) | (k0 + 1 == l31 ? 0x3f800000u : 0u);
+        }
+        bf16x8 bv;
+        __builtin_memcpy(&bv, &idw, 16);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+          const u32x4 a = *reinterpret_cast<const u32x4*>(xl + (32 * i) * PITCH + kb * 32);
+          bf16x8 av;
+          __builtin_memcpy(&av, &a, 16);
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][n], 0, 0, 0);
+        }
+      }
+    }
+  }
+
   // ---- epilogue: scale, round to bf16, store channels-last (32 lanes = 64 contiguous bytes) -------------
-  uint16_t* outb = p.out + (int64_t)b * L * Cout;
+  // ConvTranspose (phase_s > 1): column n = phase * C + c of the phase conv is channel c of output row
+  // t * phase_s + phase (a 32-column tile never straddles a phase because C % 32 == 0).
+  const int s_ph = p.phase_s > 1 ? p.phase_s : 1;
+  const int Creal = Cout / s_ph;
+  uint16_t* outb = p.out + (int64_t)b * L * Cout;           // L * s_ph rows of Creal channels
   const float scale = p.scale;
 #pragma unroll
   for (int n = 0; n < WN; ++n) {
-    const int co = 32 * (ntile0 + n) + l31;
-    if (co >= Cout) continue;
+    const int col = 32 * (ntile0 + n) + l31;
+    if (col >= Cout) continue;
+    const int ph = col / Creal, co = col - ph * Creal;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int t = t0 + trow0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (t < L) outb[(int64_t)t * Cout + co] = f2bf(acc[i][n][r] * scale);
+        if (t < L) outb[((int64_t)t * s_ph + ph) * Creal + co] = f2bf(acc[i][n][r] * scale);
       }
     }
   }
@@ -207,8 +245,8 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
 
 template <int K, int DIL, int WM, int WN, int WVT, int WVC>
 int launch(const ov_conv1d_bf16_params* p, hipStream_t stream) {
-  constexpr int TT = 32 * WM * WVT;
-  dim3 grid((p->L + TT - 1) / TT, p->B);
+  constexpr int TT = 32 * WM * WVT, NB = 32 * WN * WVC;
+  dim3 grid((p->L + TT - 1) / TT, p->B, (p->Cout + NB - 1) / NB);
   hipLaunchKernelGGL((conv1d_bf16cl_kernel<K, DIL, WM, WN, WVT, WVC>), grid, dim3(64 * (4 + NLD)), 0, stream, *p);
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
 }
@@ -220,6 +258,42 @@ int launch_by_width(const ov_conv1d_bf16_params* p, hipStream_t stream) {
   if (p->Cout > 64) return launch<K, DIL, 2, 2, 2, 2>(p, stream);
   if (p->Cout > 32) return launch<K, DIL, 2, 2, 4, 1>(p, stream);
   return launch<K, DIL, 2, 1, 4, 1>(p, stream);
+}
+
+// conv_post + tanh on the bf16 channels-last tensor (reference: openvoice/models.py:287-289):
+// out[b][t] = tanh(sum_{c, j} w[c][j] * lrelu(x[b][t + j - (K-1)/2][c], slope)), fp32 out.  One thread per sample,
+// the C * 2 bytes of a row are read as 16-byte vectors; HBM-bound (the last and largest tensor of the generator).
+template <int C, int K>
+__global__ __launch_bounds__(256) void conv_post_tanh_bf16_kernel(const uint16_t* __restrict__ x,
+                                                                  const float* __restrict__ w,
+                                                                  float* __restrict__ out, int L, float slope) {
+  __shared__ float wsm[C * K];
+  for (int i = threadIdx.x; i < C * K; i += 256) wsm[i] = w[i];
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= L) return;
+  const uint16_t* xb = x + (int64_t)b * L * C;
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const int tt = t + j - (K - 1) / 2;
+    if (tt < 0 || tt >= L) continue;
+    const u32x4* row = reinterpret_cast<const u32x4*>(xb + (int64_t)tt * C);
+#pragma unroll
+    for (int q = 0; q < C / 8; ++q) {
+      const u32x4 v = row[q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+        lo = lo > 0.f ? lo : lo * slope;
+        hi = hi > 0.f ? hi : hi * slope;
+        acc = fmaf(wsm[(8 * q + 2 * e) * K + j], lo, acc);
+        acc = fmaf(wsm[(8 * q + 2 * e + 1) * K + j], hi, acc);
+      }
+    }
+  }
+  out[(int64_t)b * L + t] = tanhf(acc);
 }
 
 }  // namespace ovk16
@@ -260,10 +334,24 @@ int ov_conv1d_bf16_pack(const float* w, int Cout, int Cin, int K, uint16_t* dst)
   return OV_OK;
 }
 
+int ov_conv_post_tanh_bf16(const uint16_t* x, const float* w, float* out, int B, int C, int L, int K, float in_slope,
+                           ov_stream_t stream) {
+  if (!x || !w || !out || B <= 0 || L <= 0 || B > 65535) return OV_E_BADARG;
+  if (C != 32 || K != 7) return OV_E_UNSUPPORTED;          // dec.conv_post of every released config
+  if (reinterpret_cast<uintptr_t>(x) & 15) return OV_E_ALIGN;
+  dim3 grid((L + 255) / 256, B);
+  hipLaunchKernelGGL((conv_post_tanh_bf16_kernel<32, 7>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, w,
+                     out, L, in_slope);
+  return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
+}
+
 int ov_conv1d_bf16cl(const ov_conv1d_bf16_params* p, ov_stream_t stream) {
   if (!p || !p->x || !p->w || !p->out) return OV_E_BADARG;
   if (p->B <= 0 || p->L <= 0 || p->Cin <= 0 || p->Cout <= 0 || p->B > 65535) return OV_E_BADARG;
-  if (p->Cin % CH != 0 || p->Cout % 32 != 0 || p->Cout > 256) return OV_E_UNSUPPORTED;
+  if (p->Cin % CH != 0 || p->Cout % 32 != 0) return OV_E_UNSUPPORTED;
+  if (p->phase_s > 1 && (p->Cout % p->phase_s != 0 || (p->Cout / p->phase_s) % 32 != 0 || p->res || p->add))
+    return OV_E_UNSUPPORTED;
+  if ((p->res || p->add) && p->Cout > 256) return OV_E_UNSUPPORTED;   // identity rounds assume one N-block
   if ((reinterpret_cast<uintptr_t>(p->x) & 15) || (reinterpret_cast<uintptr_t>(p->w) & 15)) return OV_E_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define OV16_CASE(KK, DD) if (p->K == KK && p->dil == DD) return launch_by_width<KK, DD>(p, st);

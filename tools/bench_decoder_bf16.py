@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4]: HiFi-GAN generator with bf16 activations, batch 64, 10 s utterances (T = 861), one
+MI355X -- time per batch, utterances/s, algorithmic HBM GB/s (every tensor pass of the launch sequence, 2 bytes per
+element) against the 8 TB/s spec / ~6.3 TB/s achievable, next to the fp32 generator on the same input.
+Measurement tool.   python tools/bench_decoder_bf16.py [--batch 64] [--steps 5]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def alg_bytes(cfg, B, T, esize):
+    """Tensor passes of the generator's launch sequence."""
+    ch, L = cfg["upsample_initial_channel"], T
+    total = B * T * (192 + ch) * esize                       # conv_pre: read z, write pre
+    nk, nd = len(cfg["resblock_kernel_sizes"]), 3
+    for u in cfg["upsample_rates"]:
+        total += B * L * ch * esize                          # ups reads
+        ch //= 2
+        L *= u
+        tensor = B * L * ch * esize
+        total += tensor                                      # ups writes
+        total += tensor * (nk * nd * (2 + 3) + (nk - 1))     # MRF: c1 r+w, c2 r+res+w, +running sum
+    total += B * L * ch * esize + B * L * 4                  # conv_post
+    return total
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--frames", type=int, default=861)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--no-fp32", action="store_true")
+    args = ap.parse_args()
+    from openvoice_amd.bf16 import GeneratorBf16
+    from openvoice_amd.engine import ConverterEngine
+    from openvoice_amd.params import synthetic_state_dict
+    from openvoice_amd.utils import CONVERTER_MODEL_CONFIG as CFG
+    dev, B, T = "cuda:0", args.batch, args.frames
+    sd = synthetic_state_dict(CFG, 513, seed=1234)
+    gen = torch.Generator().manual_seed(0)
+    z = torch.randn(B, 192, T, generator=gen).to(dev)
+    g = (0.3 * torch.randn(1, 256, 1, generator=gen)).to(dev)
+    dec = GeneratorBf16(sd, CFG, dev)
+
+    def timeit(fn):
+        for _ in range(2):
+            o = fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            o = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / args.steps, o
+
+    dt, o16 = timeit(lambda: dec.decode(z, g))
+    out = {"workload": f"HiFi-GAN generator, bf16 activations (channels-last), batch {B} x {T} frames (10 s), one MI355X",
+           "ms_per_batch": round(dt * 1e3, 3), "utterances_per_s": round(B / dt, 1),
+           "real_time_factor": round(B * T * 256 / 22050.0 / dt, 1),
+           "alg_hbm_GB": round(alg_bytes(CFG, B, T, 2) / 1e9, 2),
+           "alg_hbm_GBps": round(alg_bytes(CFG, B, T, 2) / dt / 1e9, 1), "hbm_peak_GBps": 8000, "hbm_achievable_GBps": 6300,
+           "frac_of_hbm_peak": round(alg_bytes(CFG, B, T, 2) / dt / 8e12, 3),
+           "alg_tflops": round(529.44e9 * B * T / 861 / dt / 1e12, 1), "bf16_mfma_peak_tflops": 2500}
+    if not args.no_fp32:
+        eng = ConverterEngine(sd, CFG, 513, dev, zero_g=False)
+        cond = eng._linear(g.reshape(1, -1), eng.dec_cond_w, eng.dec_cond_b)
+        dt32, o32 = timeit(lambda: eng.decode(z, cond))
+        err = (o16 - o32).abs()
+        out["fp32_generator_ms_per_batch"] = round(dt32 * 1e3, 3)
+        out["speedup_vs_fp32"] = round(dt32 / dt, 2)
+        out["max_abs_vs_fp32"] = round(float(err.max()), 4)
+        out["rel_rms_vs_fp32"] = round(float(err.pow(2).mean().sqrt() / o32.pow(2).mean().sqrt()), 4)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
