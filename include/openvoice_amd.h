@@ -255,6 +255,7 @@ typedef struct ov_conv1d_bf16_params {
   int32_t phase_s;      /* > 1: ConvTranspose as a phase conv -- Cout = phase_s * C columns ordered
                          * (phase, c); column (ph, c) of row t is written to out[b][t * phase_s + ph][c]    */
   int32_t bias_bstride; /* elements between the bias vectors of consecutive batch items (0 = shared)     */
+  int32_t layout;       /* 0 = dispatcher's wave layout; 1 = 64x64 wave tiles for Cout > 64 (measurement)  */
   float in_slope;       /* leaky-ReLU slope applied to x while staging (1.0f = identity)                  */
   float scale;          /* out = (conv + bias + res + add) * scale                                        */
 } ov_conv1d_bf16_params;

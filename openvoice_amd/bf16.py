@@ -26,7 +26,7 @@ class PackedConvBf16:
         self.bias = None if bias is None else bias.detach().float().contiguous().to(device)
 
 
-def launch_conv_bf16(layer, x, out, in_slope=1.0, scale=1.0, res=None, add=None):
+def launch_conv_bf16(layer, x, out, in_slope=1.0, scale=1.0, res=None, add=None, layout=0):
     """out = (conv1d(lrelu(x, in_slope)) + bias [+ res] [+ add]) * scale on torch's current stream.
     x (B, L, Cin), out / res / add (B, L, Cout), all contiguous bfloat16."""
     B, L, cin = x.shape
@@ -37,7 +37,7 @@ def launch_conv_bf16(layer, x, out, in_slope=1.0, scale=1.0, res=None, add=None)
     vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     p.x, p.w, p.bias, p.out, p.res, p.add = vp(x), vp(layer.w), vp(layer.bias), vp(out), vp(res), vp(add)
     p.B, p.L, p.Cin, p.Cout, p.K, p.dil = B, L, cin, layer.cout, layer.K, layer.dil
-    p.in_slope, p.scale = in_slope, scale
+    p.in_slope, p.scale, p.layout = in_slope, scale, layout
     stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(_lib.load().ov_conv1d_bf16cl(ctypes.byref(p), stream), "ov_conv1d_bf16cl")
 
@@ -136,9 +136,8 @@ class GeneratorBf16:
                     _launch(c2, t1, dst, L, in_slope=LRELU_SLOPE, res=cur, add=acc if (last and j > 0) else None,
                             scale=1.0 / nk if (last and j == nk - 1) else 1.0)
                     cur = dst
-            free = list(ws["dec"])
-            # keep the stage output out of the way of the next stage's scratch
-            free.remove(next(b for b in free if b.data_ptr() == acc.data_ptr()))
+            # every scratch buffer except the one holding this stage's output is free again
+            free = [buf for buf in ws["dec"] if buf.data_ptr() != acc.data_ptr()]
             cur_x = acc
         o = torch.empty(B, 1, L, dtype=torch.float32, device=dev)
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)

@@ -66,7 +66,10 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
   // MRF running sum element-wise into the accumulators (2-byte loads, 128 memory instructions per wave and tile:
   // measured 5x slower than the conv itself) -- the Cout/32 chunks of `res` and of `add`, staged through the same
   // LDS tile and added on the matrix pipe with an identity B fragment (exact: bf16 x 1.0 into fp32).
-  const int nco = (Cout + 31) / 32;
+  constexpr int NBT = WN * WVC;                             // 32-column tiles per workgroup (one N-block)
+  const int nco_all = (Cout + 31) / 32;
+  const int c_first = blockIdx.z * NBT;                     // first res / add chunk this N-block owns
+  const int nco = min(NBT, nco_all - c_first);
   const int rounds_x = nchunks, rounds_res = p.res ? nco : 0, rounds_add = p.add ? nco : 0;
   const int rounds = rounds_x + rounds_res + rounds_add;
   if (is_loader) {
@@ -79,8 +82,8 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
       const uint16_t* src;
       int cw, c, rlo, rhi;
       if (rd < rounds_x) { src = p.x + (int64_t)b * L * Cin; cw = Cin; c = rd; rlo = 0; rhi = R; }
-      else if (rd < rounds_x + rounds_res) { src = p.res + (int64_t)b * L * Cout; cw = Cout; c = rd - rounds_x; rlo = PAD; rhi = PAD + TT; }
-      else { src = p.add + (int64_t)b * L * Cout; cw = Cout; c = rd - rounds_x - rounds_res; rlo = PAD; rhi = PAD + TT; }
+      else if (rd < rounds_x + rounds_res) { src = p.res + (int64_t)b * L * Cout; cw = Cout; c = c_first + rd - rounds_x; rlo = PAD; rhi = PAD + TT; }
+      else { src = p.add + (int64_t)b * L * Cout; cw = Cout; c = c_first + rd - rounds_x - rounds_res; rlo = PAD; rhi = PAD + TT; }
 #pragma unroll
       for (int i = 0; i < PER_LANE; ++i) {
         const int idx = i * (64 * NLD) + llane;
@@ -145,6 +148,8 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
   for (int n = 0; n < WN; ++n) widx[n] = (uint32_t)(ntile0 + n) * (uint32_t)(nchunks * K * 2) * 64u + (uint32_t)lane;
   const bool wave_has_cols = ntile0 < ntiles_co;
 
+  // Weight fragments are requested one k-block ahead.  (Measured: a 4-deep request queue costs 24-40 VGPRs,
+  // drops a workgroup per CU and is slower overall -- 69 ms vs 61 ms per batch-64 generator.)
   u32x4 bcur[WN], bnxt[WN];
 #pragma unroll
   for (int n = 0; n < WN; ++n) bcur[n] = wave_has_cols && (ntile0 + n) < ntiles_co ? wbase[widx[n]] : u32x4{0u, 0u, 0u, 0u};
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
   // ---- identity rounds: acc += res, acc += add ----------------------------------------------------------
   for (int rd = rounds_x; rd < rounds; ++rd) {
     __syncthreads();
-    const int c = (rd - rounds_x) % nco;                    // 32-channel chunk of res / add staged this round
+    const int c = c_first + (rd - rounds_x) % nco;          // 32-channel chunk of res / add staged this round
     const unsigned char* xl = xs + (rd & 1) * BUF + xl_off + PAD * PITCH;
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
@@ -251,11 +256,14 @@ int launch(const ov_conv1d_bf16_params* p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
 }
 
-// wave layouts by output width: 256 -> 64 t x 256 co, 128 -> 128 t x 128 co, 64 -> 256 t x 64 co, 32 -> 256 t x 32 co
+// Wave layouts by output width.  Weights are streamed from L2 once per (wave, k-block) and reused for the WM time
+// sub-tiles of the wave; with a 64x64 wave tile (WM = 2) the four waves of a CU pull 64 B/clk of weights -- the
+// whole L1 fill rate -- so from 128 output columns up a wave owns 128 time rows x 32 columns (WM = 4, WN = 1):
+// half the weight traffic, twice the (cheap) LDS operand reads.  >= 128 columns: 128 t x 128 co per workgroup
+// (wider outputs in N-blocks); 64 -> 256 t x 64 co; 32 -> 256 t x 32 co (4 waves along time in both).
 template <int K, int DIL>
 int launch_by_width(const ov_conv1d_bf16_params* p, hipStream_t stream) {
-  if (p->Cout > 128) return launch<K, DIL, 2, 2, 1, 4>(p, stream);
-  if (p->Cout > 64) return launch<K, DIL, 2, 2, 2, 2>(p, stream);
+  if (p->Cout > 64) return p->layout == 1 ? launch<K, DIL, 2, 2, 2, 2>(p, stream) : launch<K, DIL, 4, 1, 1, 4>(p, stream);
   if (p->Cout > 32) return launch<K, DIL, 2, 2, 4, 1>(p, stream);
   return launch<K, DIL, 2, 1, 4, 1>(p, stream);
 }
@@ -351,7 +359,7 @@ int ov_conv1d_bf16cl(const ov_conv1d_bf16_params* p, ov_stream_t stream) {
   if (p->Cin % CH != 0 || p->Cout % 32 != 0) return OV_E_UNSUPPORTED;
   if (p->phase_s > 1 && (p->Cout % p->phase_s != 0 || (p->Cout / p->phase_s) % 32 != 0 || p->res || p->add))
     return OV_E_UNSUPPORTED;
-  if ((p->res || p->add) && p->Cout > 256) return OV_E_UNSUPPORTED;   // identity rounds assume one N-block
+
   if ((reinterpret_cast<uintptr_t>(p->x) & 15) || (reinterpret_cast<uintptr_t>(p->w) & 15)) return OV_E_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define OV16_CASE(KK, DD) if (p->K == KK && p->dil == DD) return launch_by_width<KK, DD>(p, st);

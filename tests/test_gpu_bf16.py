@@ -79,8 +79,8 @@ def test_conv_transpose_and_batch_bias_bf16():
 def test_generator_bf16_against_fp32_oracle(synth_sd, B, T, per_item):
     """The whole generator with bf16 activations against the fp32 oracle (reference: openvoice/models.py:272-291).
     bf16 keeps 8 significant bits per stored activation; over the ~80 layers of the generator the waveform
-    (|o| <= 1) lands within a few 1e-2 of the fp32 result.  Stated tolerance of this path: max-abs 6e-2 and
-    relative RMS error 3 %."""
+    (|o| <= 1) lands within a few 1e-2 of the fp32 result.  Measured: max-abs 0.007-0.011, relative RMS 0.6 %;
+    stated tolerance of this path: max-abs 3e-2, relative RMS error 1.5 %."""
     from openvoice_amd.bf16 import GeneratorBf16
     from openvoice_amd.utils import CONVERTER_MODEL_CONFIG as CFG
     from oracle import vc_oracle
@@ -96,4 +96,4 @@ def test_generator_bf16_against_fp32_oracle(synth_sd, B, T, per_item):
     err = (o.cpu() - ref).abs()
     rel_rms = (err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
     print(f"bf16 generator B={B} T={T}: max-abs {err.max().item():.4f}, rel RMS {rel_rms:.4f}, |ref|max {ref.abs().max().item():.3f}")
-    assert err.max().item() <= 6e-2 and rel_rms <= 3e-2
+    assert err.max().item() <= 3e-2 and rel_rms <= 1.5e-2

@@ -15,6 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--layouts", type=int, nargs="+", default=[0])
     args = ap.parse_args()
     dev, B = "cuda:0", args.batch
     print(f"B={B}  (HBM peak 8000 GB/s spec, ~6300 achievable; bf16 MFMA peak 2500 TF/s)")
@@ -31,18 +32,22 @@ def main():
                 if mode != "plain":
                     kw.update(res=res, add=add, scale=1.0 / 3.0)
                     passes = 4
-                for _ in range(2):
-                    launch_conv_bf16(layer, x, out, **kw)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(args.reps):
-                    launch_conv_bf16(layer, x, out, **kw)
-                e1.record()
-                torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1) / args.reps
-                gbs = passes * 2.0 * B * c * L / ms / 1e6
-                tf = 2.0 * c * c * k * L * B / ms / 1e9
-                print(f"{c:>4} {L:>7} {k:>2} {d:>1} {mode:>8} {ms:8.3f} {gbs:8.0f} {tf:7.1f}", flush=True)
+                for lay in args.layouts:
+                    if lay and c <= 64:
+                        continue
+                    kw["layout"] = lay
+                    for _ in range(2):
+                        launch_conv_bf16(layer, x, out, **kw)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(args.reps):
+                        launch_conv_bf16(layer, x, out, **kw)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1) / args.reps
+                    gbs = passes * 2.0 * B * c * L / ms / 1e6
+                    tf = 2.0 * c * c * k * L * B / ms / 1e9
+                    print(f"{c:>4} {L:>7} {k:>2} {d:>1} {mode:>8} lay{lay} {ms:8.3f} {gbs:8.0f} {tf:7.1f}", flush=True)
         del x, res, add, out
     print("done")
 
