@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0, help="utterance length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--bf16-generator", action="store_true",
+                    help="NOT the contract configuration: run the generator on the opt-in bf16 kernels "
+                         "(BASELINE.json configs[4]); the JSON line is marked accordingly")
     ap.add_argument("--pmc-calibration", action="store_true",
                     help="after the timed region, run three 1 GiB device-to-device copies (a known byte count) "
                          "so a rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass can be calibrated")
@@ -140,6 +143,8 @@ def main():
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
     engine = model.engine()
+    if args.bf16_generator:
+        engine.use_bf16_generator(True)
 
     B = args.batch
     samples = int(args.seconds * SAMPLE_RATE)
@@ -187,7 +192,12 @@ def main():
         rec[0] += 1
         rec[1] += flops
         rec[2] += e0.elapsed_time(e1) * 1e-3
-    n_mrf, f_mrf, t_mrf = by_tag["mrf"]
+    if args.bf16_generator:
+        from openvoice_amd.bf16 import generator_alg_bytes
+        n_mrf, f_mrf, t_mrf = by_tag["gen_bf16"][0], 0.0, by_tag["gen_bf16"][2]
+        gen_bytes = generator_alg_bytes(cfg, B, frames)
+    else:
+        n_mrf, f_mrf, t_mrf = by_tag["mrf"]
     achieved = f_mrf / t_mrf / 1e12
     traffic, traffic_rec = pmc_traffic()
     alg_bytes = mrf_alg_bytes_per_launch(cfg, B, frames)
@@ -211,7 +221,8 @@ def main():
             "unit": "x real-time (audio s / wall s)",
             "utterances_per_s": round(utt_s, 3),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (enc_q, flow) + bf16 generator, fp32 accumulation" if args.bf16_generator else "f32",
             "data": "synthetic",
             "config": {"workload": f"ToneColorConverter.convert path, {B} x {args.seconds:g} s @ 22.05 kHz per GPU "
                                    f"(T={frames} frames), fp32, calibrated random weights",
@@ -230,6 +241,12 @@ def main():
                          "whole_step_tflops": round(all_flops / (ms * 1e-3) / 1e12, 2)},
             "by_kernel_group_ms": {k: round(v[2] * 1e3, 3) for k, v in sorted(by_tag.items())},
         }
+        if args.bf16_generator:
+            out["roofline"] = {"bound": "hbm", "achieved": round(gen_bytes / t_mrf / 1e9, 1), "peak": 8000.0,
+                               "unit": "GB/s", "frac": round(gen_bytes / t_mrf / 8e12, 4), "traffic": None,
+                               "kernel": "ovk16::conv1d_bf16cl_kernel (whole bf16 generator, algorithmic bytes)",
+                               "generator_ms": round(t_mrf * 1e3, 3)}
+            out["note"] = "opt-in configuration (--bf16-generator), not the contract line"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, cfg, args.seconds, args.cpu_budget)
         print(json.dumps(out), flush=True)

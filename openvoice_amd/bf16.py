@@ -54,6 +54,21 @@ def _launch(layer, x, out, L, in_slope=1.0, scale=1.0, res=None, add=None, phase
     _lib.check(_lib.load().ov_conv1d_bf16cl(ctypes.byref(p), stream), "ov_conv1d_bf16cl")
 
 
+def generator_alg_bytes(cfg, B, T, esize=2, z_channels=192):
+    """Algorithmic HBM bytes of one generator pass: every tensor pass of the launch sequence (conv_pre; per stage
+    the ups read + write and the MRF's 9 x (conv1 r+w, conv2 r+res+w) + 2 running-sum reads; conv_post)."""
+    ch, L = cfg["upsample_initial_channel"], T
+    total = B * T * (z_channels + ch) * esize
+    nk, nd = len(cfg["resblock_kernel_sizes"]), len(cfg["resblock_dilation_sizes"][0])
+    for u in cfg["upsample_rates"]:
+        total += B * L * ch * esize
+        ch //= 2
+        L *= u
+        tensor = B * L * ch * esize
+        total += tensor + tensor * (nk * nd * (2 + 3) + (nk - 1))
+    return total + B * L * ch * esize + B * L * 4
+
+
 class GeneratorBf16:
     """HiFi-GAN generator (reference: openvoice/models.py:272-291) with bf16 activations in HBM, channels-last,
     fp32 accumulation -- BASELINE.json configs[4].  Same load-time algebra as the fp32 engine (weight-norm folded,

@@ -97,3 +97,30 @@ def test_generator_bf16_against_fp32_oracle(synth_sd, B, T, per_item):
     rel_rms = (err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
     print(f"bf16 generator B={B} T={T}: max-abs {err.max().item():.4f}, rel RMS {rel_rms:.4f}, |ref|max {ref.abs().max().item():.3f}")
     assert err.max().item() <= 3e-2 and rel_rms <= 1.5e-2
+
+
+def test_voice_conversion_with_the_opt_in_bf16_generator(synth_sd):
+    """engine.use_bf16_generator(): enc_q and flow stay fp32 (latents unchanged to fp32 round-off), only the generator
+    runs in bf16; the waveform stays within the bf16 path's stated tolerance of the fp32 oracle."""
+    from openvoice_amd.models import SynthesizerTrn
+    from openvoice_amd.utils import CONVERTER_MODEL_CONFIG as CFG
+    from oracle import vc_oracle
+    gen = torch.Generator().manual_seed(11)
+    B, T = 2, 50
+    spec = torch.rand(B, 513, T, generator=gen) * torch.linspace(3, 0.05, 513)[None, :, None]
+    g1, g2 = 0.3 * torch.randn(1, 256, 1, generator=gen), 0.3 * torch.randn(1, 256, 1, generator=gen)
+    noise = torch.randn(B, 192, T, generator=gen)
+    lengths = torch.tensor([T, 31])
+    with torch.no_grad():
+        o_r, _, (_, _, zh_r) = vc_oracle.voice_conversion(synth_sd, CFG, spec, lengths, g1, g2, 0.3, noise)
+    m = SynthesizerTrn(0, 513, n_speakers=0, **CFG)
+    m.load_state_dict(synth_sd, strict=True)
+    m = m.to(DEV).eval()
+    m.engine().use_bf16_generator(True)
+    o, _, (_, _, z_hat) = m.voice_conversion(spec.to(DEV), lengths.to(DEV), g1.to(DEV), g2.to(DEV), tau=0.3, noise=noise.to(DEV))
+    assert (z_hat.cpu() - zh_r).abs().max().item() <= 2e-4
+    err = (o.cpu() - o_r).abs().max().item()
+    assert 1e-5 < err <= 3e-2, err          # genuinely the bf16 generator, and within its tolerance
+    m.engine().use_bf16_generator(False)
+    o32 = m.voice_conversion(spec.to(DEV), lengths.to(DEV), g1.to(DEV), g2.to(DEV), tau=0.3, noise=noise.to(DEV))[0]
+    assert (o32.cpu() - o_r).abs().max().item() <= 1e-3

@@ -15,19 +15,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def alg_bytes(cfg, B, T, esize):
-    """Tensor passes of the generator's launch sequence."""
-    ch, L = cfg["upsample_initial_channel"], T
-    total = B * T * (192 + ch) * esize                       # conv_pre: read z, write pre
-    nk, nd = len(cfg["resblock_kernel_sizes"]), 3
-    for u in cfg["upsample_rates"]:
-        total += B * L * ch * esize                          # ups reads
-        ch //= 2
-        L *= u
-        tensor = B * L * ch * esize
-        total += tensor                                      # ups writes
-        total += tensor * (nk * nd * (2 + 3) + (nk - 1))     # MRF: c1 r+w, c2 r+res+w, +running sum
-    total += B * L * ch * esize + B * L * 4                  # conv_post
-    return total
+    from openvoice_amd.bf16 import generator_alg_bytes
+    return generator_alg_bytes(cfg, B, T, esize)
 
 
 def main():
