@@ -7,7 +7,8 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 (nproc; python -c "import os; print('cpu_count', os.cpu_count(), 'affinity', len(os.sched_getaffinity(0)))"; cat /sys/fs/cgroup/cpu.max 2>/dev/null; lscpu | grep -E "Model name|^CPU\(s\)|Socket") > gpurun_out/host_info.txt 2>&1
 echo "== kernel tests" ; timeout 400 python -m pytest tests/test_gpu_kernels.py -q -m gpu -x --timeout 120 2>&1 | tail -15 | tee gpurun_out/test_kernels.log
-echo "== e2e tests" ; timeout 300 python -m pytest tests/test_gpu_e2e.py -q -m gpu -s --timeout 200 2>&1 | tail -25 | tee gpurun_out/test_e2e.log
+echo "== e2e + tts + bf16 tests" ; timeout 400 python -m pytest tests/test_gpu_e2e.py tests/test_gpu_tts.py tests/test_gpu_bf16.py -q -m gpu --timeout 250 2>&1 | tail -6 | tee gpurun_out/test_e2e.log
+echo "== smoke" ; timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/smoke.log
 if [ "${SQ:-0}" = "1" ]; then
   echo "== SQ counters on the k=3 C=128 conv"
   (cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS -d "$OLDPWD/gpurun_out/pmc_sq" -o r1 --output-format csv -- python "$OLDPWD/tools/bench_convs.py" --channels 128 32 --kernels 3 11 --reps 2 > "$OLDPWD/gpurun_out/pmc_sq.log" 2>&1)

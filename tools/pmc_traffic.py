@@ -31,10 +31,11 @@ def read(d, counter):
     return rows
 
 
-def summarise(rows):
-    # conv_pre (k7 at frame rate) is the same template as the MRF convs; its grid is about half of
-    # the smallest MRF launch of the benchmark batch, so a grid-size floor separates them
-    mrf = [v for n, v, g in rows if MRF.search(n) and g >= 500000]
+def summarise(rows, floor_kib):
+    # conv_pre (k7 at frame rate) is the same template as the MRF convs and, now that large launches are
+    # persistent, grid size no longer tells them apart; traffic does: conv_pre moves 21 MB in / 56 MB out per batch,
+    # the smallest MRF launch (stage 0) 226 MB each way, so a per-counter floor separates them.
+    mrf = [v for n, v, g in rows if MRF.search(n) and v >= floor_kib]
     # the calibration copies: the three largest launches of a copy kernel
     copies = sorted((v for n, v, g in rows if "copyBuffer" in n or "copy_kernel" in n.lower()), reverse=True)[:3]
     return mrf, copies
@@ -42,8 +43,8 @@ def summarise(rows):
 
 def main():
     fetch_dir, write_dir = sys.argv[1], sys.argv[2]
-    f_mrf, f_cal = summarise(read(fetch_dir, "FETCH_SIZE"))
-    w_mrf, w_cal = summarise(read(write_dir, "WRITE_SIZE"))
+    f_mrf, f_cal = summarise(read(fetch_dir, "FETCH_SIZE"), 80000.0)     # raw FETCH_SIZE is half the bytes
+    w_mrf, w_cal = summarise(read(write_dir, "WRITE_SIZE"), 100000.0)
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), counters in KiB",
            "mrf_launches_fetch_pass": len(f_mrf), "mrf_launches_write_pass": len(w_mrf)}
     if f_mrf and w_mrf:
