@@ -1,0 +1,93 @@
+"""Load-time algebra of the engine, checked on CPU with plain PyTorch (no kernels involved): the rewrites that the
+HIP path relies on must be exact re-expressions of the reference ops."""
+import torch
+import torch.nn.functional as F
+
+from openvoice_amd.engine import conv_transpose_as_conv, gate_row_order, padded_frames
+from openvoice_amd.params import effective_weight
+
+
+def _rand(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def test_conv_transpose_equals_three_tap_phase_conv():
+    """ConvTranspose1d(k = 2s, stride s, pad s/2) (reference: openvoice/models.py:244-256) == a 3-tap stride-1 conv
+    whose row co*s + p is output phase p (engine.conv_transpose_as_conv), for every released (s, k)."""
+    for s, cin, cout in ((8, 12, 6), (2, 10, 4)):
+        x, w, b = _rand(2, cin, 23, seed=1), _rand(cin, cout, 2 * s, seed=2), _rand(cout, seed=3)
+        ref = F.conv_transpose1d(x, w, b, stride=s, padding=s // 2)
+        y = F.conv1d(x, conv_transpose_as_conv(w, s), b.repeat_interleave(s), padding=1)       # [B, cout*s, L]
+        got = y.reshape(2, cout, s, 23).permute(0, 1, 3, 2).reshape(2, cout, 23 * s)
+        assert torch.allclose(got, ref, atol=1e-5)
+        # (phase, channel) column order used by the bf16 path
+        wc = conv_transpose_as_conv(w, s).reshape(cout, s, cin, 3).transpose(0, 1).reshape(s * cout, cin, 3)
+        y2 = F.conv1d(x, wc, b.repeat(s), padding=1).reshape(2, s, cout, 23).permute(0, 2, 3, 1).reshape(2, cout, 23 * s)
+        assert torch.allclose(y2, ref, atol=1e-5)
+
+
+def test_gate_row_order_pairs_tanh_and_sigmoid_rows():
+    H = 192
+    order = gate_row_order(H)
+    assert sorted(order.tolist()) == list(range(2 * H))
+    for q in range(H // 32):
+        blk = order[64 * q: 64 * q + 64]
+        assert blk[:32].tolist() == list(range(32 * q, 32 * q + 32))                  # tanh rows of tile pair q
+        assert blk[32:].tolist() == list(range(H + 32 * q, H + 32 * q + 32))          # their sigmoid partners
+
+
+def test_flip_folds_into_channel_order_of_the_coupling_convs():
+    """Flip (reference: openvoice/modules.py:374-381) before a coupling == the same coupling with `pre` input
+    columns and `post` output rows reversed, applied to the un-flipped tensor with the x0 / x1 halves swapped --
+    the identity the engine uses so that no Flip is ever materialised (engine._flow)."""
+    C, H, T = 8, 6, 11
+    half = C // 2
+    x = _rand(2, C, T, seed=1)
+    w_pre, b_pre = _rand(H, half, 1, seed=2), _rand(H, seed=3)
+    w_post, b_post = _rand(half, H, 1, seed=4), _rand(half, seed=5)
+
+    def coupling(t, wp, bp, wq, bq, x0_first):
+        x0, x1 = (t[:, :half], t[:, half:]) if x0_first else (t[:, half:], t[:, :half])
+        m = F.conv1d(torch.tanh(F.conv1d(x0, wp, bp)), wq, bq)
+        x1n = m + x1
+        return torch.cat([x0, x1n], 1) if x0_first else torch.cat([x1n, x0], 1)
+
+    ref = torch.flip(coupling(torch.flip(x, [1]), w_pre, b_pre, w_post, b_post, True), [1])   # flip, couple, flip back
+    got = coupling(x, torch.flip(w_pre, [1]), b_pre, torch.flip(w_post, [0]), torch.flip(b_post, [0]), False)
+    assert torch.allclose(got, ref, atol=1e-6)
+
+
+def test_weight_norm_folding_matches_torch():
+    v, g = _rand(5, 3, 7, seed=1), _rand(5, 1, 1, seed=2).abs() + 0.1
+    sd = {"l.weight_v": v, "l.weight_g": g}
+    assert torch.allclose(effective_weight(sd, "l"), torch._weight_norm(v, g, 0), atol=1e-6)
+    # ConvTranspose layout: dim 0 is C_in, the norm still runs over every other dim
+    vt, gt = _rand(4, 6, 16, seed=3), _rand(4, 1, 1, seed=4).abs() + 0.1
+    assert torch.allclose(effective_weight({"u.weight_v": vt, "u.weight_g": gt}, "u"), torch._weight_norm(vt, gt, 0),
+                          atol=1e-6)
+    assert torch.equal(effective_weight({"p.weight": v}, "p"), v)
+
+
+def test_padded_frames_is_the_next_multiple_of_four():
+    assert [padded_frames(t) for t in (1, 4, 5, 861, 864)] == [4, 4, 8, 864, 864]
+
+
+def test_spectrogram_dft_weights_reproduce_torch_stft():
+    """The DFT-as-conv weights of the native spectrogram (hann * cos / -sin, 4 taps over 256 hop phases) evaluated
+    with F.conv1d on CPU equal torch.stft's magnitude: the K = 4 framing-conv formulation itself is exact."""
+    import math
+    n_fft, hop = 1024, 256
+    y = _rand(1, 256 * 9, seed=7) * 0.3
+    pad = (n_fft - hop) // 2
+    yp = F.pad(y[:, None], (pad, pad), mode="reflect")[:, 0]
+    T = (yp.shape[1] - n_fft) // hop + 1
+    n = torch.arange(n_fft, dtype=torch.float64)
+    win = 0.5 - 0.5 * torch.cos(2 * math.pi * n / n_fft)
+    f = torch.arange(n_fft // 2 + 1, dtype=torch.float64)[:, None]
+    re, im = win * torch.cos(2 * math.pi * f * n / n_fft), -win * torch.sin(2 * math.pi * f * n / n_fft)
+    hops = yp[:, : (T + 3) * hop].reshape(1, T + 3, hop).transpose(1, 2).double()             # [1, 256, U]
+    to_conv = lambda w: w.reshape(-1, n_fft // hop, hop).transpose(1, 2)                        # [rows, 256, 4]
+    mag = torch.sqrt(F.conv1d(hops, to_conv(re)) ** 2 + F.conv1d(hops, to_conv(im)) ** 2 + 1e-6)
+    ref = torch.stft(yp, n_fft, hop_length=hop, win_length=n_fft, window=torch.hann_window(n_fft), center=False,
+                     return_complex=True).abs().pow(2).add(1e-6).sqrt()
+    assert mag.shape == ref.shape and torch.allclose(mag.float(), ref, atol=2e-4)
