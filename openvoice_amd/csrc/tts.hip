@@ -26,44 +26,58 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
   out[((int64_t)b * H + h) * ld + t] = t < len[b] ? emb[id * H + h] * scale : 0.f;
 }
 
-// LayerNorm over channels of (B, C, T), one thread per (b, t), lanes along t (coalesced rows):
+// LayerNorm over channels of (B, C, T):
 //   v = x (+ res);  v = relu(v) if PRE_RELU;  y = (v - mean) * rstd * gamma[c] + beta[c];
 //   y = gelu_erf(y) if POST_GELU;  y += res2 if res2;  y *= mask[b][t] if mask.
+// A workgroup = 32 time columns x 8 channel groups (256 threads): lanes along t (coalesced rows), each thread
+// reduces C/8 channels, the 8 partial sums meet in LDS.  Token-rate tensors have only ~10^3 columns, so one thread
+// per column (the first version) left the GPU 99 % idle and cost ~130 us per call; the second and third pass
+// re-read L2-hot data.  Two-pass variance, as ATen's CPU kernel.
 // reference: openvoice/modules.py:17-29 (LayerNorm), attentions.py:114-119, models.py:91-98, modules.py:121-129.
-__global__ __launch_bounds__(128) void layernorm_ch_kernel(const float* __restrict__ x, const float* __restrict__ res,
+__global__ __launch_bounds__(256) void layernorm_ch_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
                                                            const float* __restrict__ res2,
                                                            const float* __restrict__ mask, float* __restrict__ out,
                                                            int C, int T, int ld, float eps, int flags) {
+  __shared__ float part[8][33];
   const int b = blockIdx.y;
-  const int t = blockIdx.x * 128 + threadIdx.x;
-  if (t >= T) return;
-  const int64_t base = (int64_t)b * C * ld + t;
+  const int tl = threadIdx.x & 31, cg = threadIdx.x >> 5;          // column within the tile, channel group
+  const int t = blockIdx.x * 32 + tl;
+  const bool live = t < T;
+  const int64_t base = (int64_t)b * C * ld + (live ? t : 0);
   const bool relu = flags & OV_LN_PRE_RELU;
+  auto value = [&](int c) {
+    float v = x[base + (int64_t)c * ld];
+    if (res) v += res[base + (int64_t)c * ld];
+    return relu ? fmaxf(v, 0.f) : v;
+  };
   float s = 0.f;
-  for (int c = 0; c < C; ++c) {
-    float v = x[base + (int64_t)c * ld];
-    if (res) v += res[base + (int64_t)c * ld];
-    if (relu) v = fmaxf(v, 0.f);
-    s += v;
-  }
-  const float mean = s / C;
+  if (live)
+    for (int c = cg; c < C; c += 8) s += value(c);
+  part[cg][tl] = s;
+  __syncthreads();
+  float mean = 0.f;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) mean += part[g][tl];
+  mean /= C;
+  __syncthreads();
   float var = 0.f;
-  for (int c = 0; c < C; ++c) {
-    float v = x[base + (int64_t)c * ld];
-    if (res) v += res[base + (int64_t)c * ld];
-    if (relu) v = fmaxf(v, 0.f);
-    const float d = v - mean;
-    var = fmaf(d, d, var);
-  }
+  if (live)
+    for (int c = cg; c < C; c += 8) {
+      const float d = value(c) - mean;
+      var = fmaf(d, d, var);
+    }
+  part[cg][tl] = var;
+  __syncthreads();
+  var = 0.f;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) var += part[g][tl];
+  if (!live) return;
   const float rstd = 1.f / sqrtf(var / C + eps);
   const float mk = mask ? mask[(int64_t)b * ld + t] : 1.f;
-  for (int c = 0; c < C; ++c) {
-    float v = x[base + (int64_t)c * ld];
-    if (res) v += res[base + (int64_t)c * ld];
-    if (relu) v = fmaxf(v, 0.f);
-    float y = (v - mean) * rstd * gamma[c] + beta[c];
+  for (int c = cg; c < C; c += 8) {
+    float y = (value(c) - mean) * rstd * gamma[c] + beta[c];
     if (flags & OV_LN_POST_GELU) y = 0.5f * y * (1.f + erff(y * 0.70710678118654752440f));
     if (res2) y += res2[base + (int64_t)c * ld];
     out[base + (int64_t)c * ld] = y * mk;
@@ -415,8 +429,8 @@ int ov_layernorm_ch_f32(const float* x, const float* res, const float* gamma, co
                         const float* mask, float* out, int B, int C, int T, int ld, float eps, int flags,
                         ov_stream_t stream) {
   if (!x || !gamma || !beta || !out || B <= 0 || C <= 0 || T <= 0 || ld < T || B > 65535) return OV_E_BADARG;
-  dim3 grid((T + 127) / 128, B);
-  hipLaunchKernelGGL(layernorm_ch_kernel, grid, dim3(128), 0, static_cast<hipStream_t>(stream), x, res, gamma, beta,
+  dim3 grid((T + 31) / 32, B);
+  hipLaunchKernelGGL(layernorm_ch_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, res, gamma, beta,
                      res2, mask, out, C, T, ld, eps, flags);
   return OV_LAUNCH_OK();
 }
