@@ -83,3 +83,47 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.ov_sequence_mask_f32(None, None, 1, 1, 0, None) == -1
     assert lib.ov_conv1d_pack_f32(None, 1, 1, 1, None) == -1
     assert lib.ov_conv1d_pack_size(0, 1, 1) == 0
+
+
+def test_bf16_params_struct_matches_header_field_order():
+    header = open(os.path.join(REPO, "include", "openvoice_amd.h")).read()
+    body = header[header.index("typedef struct ov_conv1d_bf16_params {"):header.index("} ov_conv1d_bf16_params;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        first, *rest = decl.split(",")
+        names.append(re.findall(r"(\w+)$", first.strip())[0])
+        names += [r.strip() for r in rest]
+    assert names == [f[0] for f in _lib.ConvBf16Params._fields_]
+
+
+@pytest.mark.parametrize("cout,cin,k", [(32, 32, 3), (64, 96, 7), (96, 64, 1), (256, 32, 11)])
+def test_bf16_weight_packer_layout_and_rounding(cout, cin, k):
+    """Record ((nt * chunks + c) * K + tap) * 2 + kb, lane l, element i holds bf16(W[32nt + (l&31)][32c + 16kb +
+    8(l>>5) + i][tap]), rounded to nearest even exactly like torch.bfloat16."""
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(cout + cin + k)
+    w = torch.randn(cout, cin, k, generator=gen)
+    n = lib.ov_conv1d_bf16_pack_size(cout, cin, k)
+    ntiles, chunks = (cout + 31) // 32, cin // 32
+    assert n == (ntiles * chunks * k * 2 + 1) * 512
+    dst = torch.full((n,), -1, dtype=torch.int16)
+    assert lib.ov_conv1d_bf16_pack(w.data_ptr(), cout, cin, k, dst.data_ptr()) == 0
+    got = dst.view(torch.bfloat16).float().reshape(ntiles * chunks * k * 2 + 1, 64, 8)
+    want = torch.zeros(ntiles * 32, cin, k)
+    want[:cout] = w.to(torch.bfloat16).float()
+    lane = torch.arange(64)
+    for nt in range(ntiles):
+        for c in range(chunks):
+            for tap in range(k):
+                for kb in range(2):
+                    rec = got[((nt * chunks + c) * k + tap) * 2 + kb]
+                    for i in range(8):
+                        exp = want[32 * nt + (lane & 31), 32 * c + 16 * kb + 8 * (lane >> 5) + i, tap]
+                        assert torch.equal(rec[:, i], exp), (nt, c, tap, kb, i)
+    assert torch.all(got[-1] == 0)                         # the zero record that ends the stream
+    assert lib.ov_conv1d_bf16_pack_size(32, 40, 3) == 0     # Cin must be a multiple of 32
+    assert lib.ov_conv1d_bf16cl(None, None) == -1
