@@ -146,13 +146,12 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
   uint32_t widx[WN];
 #pragma unroll
   for (int n = 0; n < WN; ++n) widx[n] = (uint32_t)(ntile0 + n) * (uint32_t)(nchunks * K * 2) * 64u + (uint32_t)lane;
-  const bool wave_has_cols = ntile0 < ntiles_co;
 
   // Weight fragments are requested one k-block ahead.  (Measured: a 4-deep request queue costs 24-40 VGPRs,
   // drops a workgroup per CU and is slower overall -- 69 ms vs 61 ms per batch-64 generator.)
   u32x4 bcur[WN], bnxt[WN];
 #pragma unroll
-  for (int n = 0; n < WN; ++n) bcur[n] = wave_has_cols && (ntile0 + n) < ntiles_co ? wbase[widx[n]] : u32x4{0u, 0u, 0u, 0u};
+  for (int n = 0; n < WN; ++n) bcur[n] = (ntile0 + n) < ntiles_co ? wbase[widx[n]] : u32x4{0u, 0u, 0u, 0u};
   // per-lane LDS byte offset of the A operand: row (trow0 + lane & 31), k-slot half
   const int xl_off = (trow0 + l31) * PITCH + half * 16;
 

@@ -56,7 +56,7 @@ __host__ __device__ inline int packed_units(int cin) { return ((cin + UNIT - 1) 
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
-// ---- epilogue: accumulators -> global, shared by every tile shape --------------------------------
+// ---- epilogue: accumulators (= bias + conv [+ res + add], see conv_preload) -> global ------------------
 // C/D fragment: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 // Addressing: 64-bit per-utterance base pointers stay scalar; a lane carries ONE 32-bit offset
 // (its column + its half's row offset) and the 16 per-register row offsets are scalar multiples of
@@ -72,9 +72,7 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
   const uint32_t Cout = (uint32_t)p.Cout;
   const float scale = p.scale;
   const float* mrow = p.mask ? p.mask + (int64_t)b * p.mask_bstride : nullptr;
-  const float* __restrict__ bias = p.bias;
-  const float* __restrict__ bias_b = p.bias_b ? p.bias_b + (int64_t)b * p.bias_b_bstride : nullptr;
-  float* outb = p.out + (int64_t)b * p.out_bstride;
+  float* outb = p.out + (int64_t)b * p.out_bstride;   // bias (+ bias_b) is already in acc: see conv_preload
   const uint32_t col0 = (uint32_t)tcol0 + ((uint32_t)lane & 31u);
 
   if constexpr (EPI == OV_EPI_MAGNITUDE) {
