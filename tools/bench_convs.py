@@ -19,6 +19,27 @@ from openvoice_amd.engine import PackedConv, launch_conv  # noqa: E402
 PEAK = 157.3
 
 
+def timed(fn, reps, warm_ms):
+    """Average ms per call of fn, measured with the clocks already ramped: the GPU is kept busy for ~warm_ms
+    right before (and with no host sync between warm-up and) the timed launches.  With two warm-up launches
+    only -- what this tool did until profiles/r01_s36 -- the first shapes after every host-side weight pack ran
+    10-20 % below their steady-state rate (62 % vs 79 % of peak on k = 3, C = 128), an artefact of the
+    power-state ramp, not of the kernel."""
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); fn(); e1.record()
+    torch.cuda.synchronize()
+    n = max(2, int(warm_ms / max(e0.elapsed_time(e1), 1e-3)))
+    for _ in range(n):
+        fn()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tpw", type=int, nargs="+", default=[0])
@@ -27,6 +48,7 @@ def main():
     ap.add_argument("--chunks", type=int, nargs="+", default=[0])
     ap.add_argument("--channels", type=int, nargs="+", default=[256, 128, 64, 32])
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--warm-ms", type=float, default=100.0, help="GPU-busy time before each timed region")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--kernels", type=int, nargs="+", default=[3, 7, 11])
     ap.add_argument("--wn", action="store_true", help="also time the WaveNet k5 gate conv and the 1x1 res/skip conv")
@@ -54,17 +76,10 @@ def main():
                     if mode != "plain":
                         kw.update(res=res, res_bs=c * L, add=add, add_bs=c * L, scale=1.0 / 3.0)
                     try:
-                        for _ in range(2):
-                            launch_conv(layer, x, 0, c * L, out, 0, c * L, B, L, **kw)
+                        ms = timed(lambda: launch_conv(layer, x, 0, c * L, out, 0, c * L, B, L, **kw), args.reps,
+                                   args.warm_ms)
                     except OvError:
                         continue
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(args.reps):
-                        launch_conv(layer, x, 0, c * L, out, 0, c * L, B, L, **kw)
-                    e1.record()
-                    torch.cuda.synchronize()
-                    ms = e0.elapsed_time(e1) / args.reps
                     tf = 2.0 * c * c * k * L * B / ms / 1e9
                     print(f"{c:>4} {L:>7} {k:>2} {d:>1} {mode:>8} {tile:>4} {nld:>3} {chunk:>2} {tpw:>3} {ms:8.3f} {tf:7.1f} "
                           f"{100 * tf / PEAK:6.1f}", flush=True)
@@ -92,17 +107,9 @@ def main():
                                            loaders=n))):
                 for nld in args.loaders:
                     try:
-                        for _ in range(2):
-                            fn(nld)
+                        ms = timed(lambda: fn(nld), 10, args.warm_ms)
                     except OvError:
                         continue
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(10):
-                        fn(nld)
-                    e1.record()
-                    torch.cuda.synchronize()
-                    ms = e0.elapsed_time(e1) / 10
                     print(f"{name:>14} ld={ld} nld={nld} {ms:8.4f} ms {fl / ms / 1e9:7.1f} TF/s "
                           f"{100 * fl / ms / 1e9 / PEAK:6.1f} %", flush=True)
     print("done")

@@ -8,7 +8,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from openvoice_amd.bf16 import PackedConvBf16, launch_conv_bf16  # noqa: E402
+from bench_convs import timed  # noqa: E402
 
 
 def main():
@@ -36,15 +38,7 @@ def main():
                     if lay and c <= 64:
                         continue
                     kw["layout"] = lay
-                    for _ in range(2):
-                        launch_conv_bf16(layer, x, out, **kw)
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(args.reps):
-                        launch_conv_bf16(layer, x, out, **kw)
-                    e1.record()
-                    torch.cuda.synchronize()
-                    ms = e0.elapsed_time(e1) / args.reps
+                    ms = timed(lambda: launch_conv_bf16(layer, x, out, **kw), args.reps, 100.0)   # clocks ramped
                     gbs = passes * 2.0 * B * c * L / ms / 1e6
                     tf = 2.0 * c * c * k * L * B / ms / 1e9
                     print(f"{c:>4} {L:>7} {k:>2} {d:>1} {mode:>8} lay{lay} {ms:8.3f} {gbs:8.0f} {tf:7.1f}", flush=True)

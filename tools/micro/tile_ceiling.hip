@@ -4,14 +4,21 @@
 // switch, RES = read a residual fragment at tile start.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <bool STORE, bool RES, int K, int NCH>
-__global__ __launch_bounds__(256) void tile(const f32x4* __restrict__ w, float* __restrict__ out,
-                                            const float* __restrict__ res, int L) {
-  __shared__ float xs[2 * 32 * 160];
-  for (int i = threadIdx.x; i < 2 * 32 * 160; i += 256) xs[i] = (float)i * 1e-3f;
+struct BigArgs { const f32x4* w; float* out; const float* res; int L; int pad[53]; };   // 240 bytes, like ov_conv1d_params
+
+template <bool STORE, bool RES, int K, int NCH, int WAVES, int XS, int XOFF>
+__global__ __launch_bounds__(64 * WAVES) void tile(const BigArgs a) {
+  if (threadIdx.x >= 256) return;   // WAVES = 6: two waves that leave immediately (the loaders of an OV_EXP=1 build)
+  const f32x4* __restrict__ w = a.w;
+  float* __restrict__ out = a.out;
+  const float* __restrict__ res = a.res;
+  const int L = a.L;
+  __shared__ float xs[2 * 32 * XS + 8];
+  for (int i = threadIdx.x; i < 2 * 32 * XS; i += 256) xs[i] = ((i * 2654435761u) >> 9) * 1e-7f - 0.4f;   // scrambled mantissas
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
@@ -30,7 +37,7 @@ __global__ __launch_bounds__(256) void tile(const f32x4* __restrict__ w, float* 
   int rec = 0;
   constexpr int STEPS = 4 * 4 * K;
   for (int ch = 0; ch < NCH; ++ch) {
-    const float* xl = xs + (ch & 1) * 32 * 160 + half * 160 + wn * 64 + (lane & 31);
+    const float* xl = xs + (ch & 1) * 32 * XS + half * XS + wn * 64 + (lane & 31) + XOFF;
     float bcur[2], bnxt[2];
     bcur[0] = xl[0]; bcur[1] = xl[32];
 #pragma unroll
@@ -40,7 +47,7 @@ __global__ __launch_bounds__(256) void tile(const f32x4* __restrict__ w, float* 
       if (sa + 1 < STEPS) {
         const int uu = (sa + 1) / (4 * K), sn = (sa + 1) - uu * (4 * K);
         const int pp = sn / K, tap = sn - pp * K;
-        bnxt[0] = xl[(uu * 8 + 2 * pp) * 160 + tap]; bnxt[1] = xl[(uu * 8 + 2 * pp) * 160 + 32 + tap];
+        bnxt[0] = xl[(uu * 8 + 2 * pp) * XS + tap]; bnxt[1] = xl[(uu * 8 + 2 * pp) * XS + 32 + tap];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -64,23 +71,36 @@ __global__ __launch_bounds__(256) void tile(const f32x4* __restrict__ w, float* 
   }
 }
 
-template <bool STORE, bool RES, int K, int NCH>
+template <bool STORE, bool RES, int K, int NCH, int WAVES = 4, int XS = 160, int XOFF = 0>
 void run(const f32x4* w, float* out, const float* res, int L) {
+  BigArgs args{w, out, res, L, {0}};
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int wgs = 431 * 32;
-  tile<STORE, RES, K, NCH><<<wgs, 256>>>(w, out, res, L);
+  // LDS_PAD_KB: extra dynamic LDS per workgroup, to cap resident workgroups per CU (40 KB static + pad of 160 KB)
+  const size_t pad = getenv("LDS_PAD_KB") ? (size_t)atoi(getenv("LDS_PAD_KB")) * 1024 : 0;
+  tile<STORE, RES, K, NCH, WAVES, XS, XOFF><<<wgs, 64 * WAVES, pad>>>(args);
   hipEventRecord(e0);
-  for (int i = 0; i < 3; ++i) tile<STORE, RES, K, NCH><<<wgs, 256>>>(w, out, res, L);
+  for (int i = 0; i < 3; ++i) tile<STORE, RES, K, NCH, WAVES, XS, XOFF><<<wgs, 64 * WAVES, pad>>>(args);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
   const double flops = (double)wgs * 4 * NCH * (16.0 * K) * 4 * 4096.0;   // 16K k-steps x 4 MFMAs per wave and chunk
-  printf("K=%d chunks=%d store=%d res=%d  %.3f ms  %.1f %% of peak\n", K, NCH, STORE, RES, ms, flops / ms / 1e9 / 157.3 * 100);
+  printf("pad=%zuK xs=%d+%d waves=%d K=%d chunks=%d store=%d res=%d  %.3f ms  %.1f %% of peak\n", pad / 1024, XS, XOFF, WAVES, K, NCH, STORE, RES, ms, flops / ms / 1e9 / 157.3 * 100);
 }
 
 int main() {
   const int L = 55104;
   f32x4* w; float *out, *res;
-  hipMalloc(&w, 4 * 200 * 64 * sizeof(f32x4)); hipMemset(w, 0, 4 * 200 * 64 * sizeof(f32x4));
+  const size_t wn = (size_t)4 * 200 * 64 * 4;
+  hipMalloc(&w, wn * sizeof(float));
+  {   // RANDOM=1: weights with realistic mantissas instead of zeros (data-dependent power -> clocks)
+    float* hw = (float*)malloc(wn * sizeof(float));
+    const bool rnd = getenv("RANDOM_DATA") != nullptr;
+    unsigned s = 12345u;
+    for (size_t i = 0; i < wn; ++i) { s = s * 1664525u + 1013904223u; hw[i] = rnd ? ((int)(s >> 8) % 20001 - 10000) * 1e-5f : 0.f; }
+    hipMemcpy(w, hw, wn * sizeof(float), hipMemcpyHostToDevice);
+    free(hw);
+    printf("weights: %s\n", rnd ? "random" : "zero");
+  }
   hipMalloc(&out, (size_t)32 * 128 * L * 4); hipMalloc(&res, (size_t)32 * 128 * L * 4);
   hipMemset(res, 0, (size_t)32 * 128 * L * 4);
   run<false, false, 3, 4>(w, out, res, L);
@@ -89,5 +109,17 @@ int main() {
   run<false, false, 11, 4>(w, out, res, L);
   run<true, false, 11, 4>(w, out, res, L);
   run<true, false, 3, 8>(w, out, res, L);
+  run<false, false, 3, 4, 6>(w, out, res, L);
+  run<true, false, 3, 4, 6>(w, out, res, L);
+  run<true, false, 11, 4, 6>(w, out, res, L);
+  // LDS row stride of the real kernel: 136 (k3 d1, k7 d1), 144 (k3 d5, k11 d1), 160 (k7 d5); column offset PADA - PAD
+  run<false, false, 3, 4, 6, 136, 3>(w, out, res, L);
+  run<false, false, 3, 4, 6, 136, 0>(w, out, res, L);
+  run<false, false, 3, 4, 6, 144, 3>(w, out, res, L);
+  run<false, false, 3, 4, 6, 160, 3>(w, out, res, L);
+  run<false, false, 3, 4, 6, 168, 0>(w, out, res, L);
+  run<false, false, 3, 4, 6, 192, 0>(w, out, res, L);
+  run<true, false, 3, 4, 6, 136, 3>(w, out, res, L);
+  run<false, false, 11, 4, 6, 144, 3>(w, out, res, L);
   return 0;
 }
