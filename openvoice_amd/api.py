@@ -180,6 +180,15 @@ class ToneColorConverter(OpenVoiceBaseClass):
             except ImportError:
                 print("wavmark is not installed: watermarking disabled")
         self.version = getattr(self.hps, "_version_", "v1")
+        self.use_graphs = False
+
+    def enable_graphs(self, enable=True):
+        """Replay conversions of an already-seen (batch, frames, tau) shape from a captured HIP graph: one
+        ``hipGraphLaunch`` instead of ~330 launches through Python.  Pays at small batches (a single file is
+        launch-bound in eager mode); each distinct shape costs one capture and keeps its workspace resident
+        (the 4 most recent shapes are kept).  Off by default."""
+        self.use_graphs = bool(enable)
+        return self
 
     # ---- spectrogram helpers ---------------------------------------------------------------------
     def _spec(self, y):
@@ -229,8 +238,13 @@ class ToneColorConverter(OpenVoiceBaseClass):
             y = torch.as_tensor(waveforms, dtype=torch.float32).to(self.device)
             spec = self._spec(y)
             spec_lengths = torch.full((spec.shape[0],), spec.shape[2], dtype=torch.int64, device=self.device)
-        o_hat = self.model.voice_conversion(spec, spec_lengths, sid_src=src_se, sid_tgt=tgt_se, tau=tau,
-                                            noise=noise)[0]
+        if self.use_graphs:
+            # the graph's outputs are static buffers: hand the caller its own copy
+            o_hat = self.model.voice_conversion(spec, spec_lengths, sid_src=src_se, sid_tgt=tgt_se, tau=tau,
+                                                noise=noise, graph=True)[0].clone()
+        else:
+            o_hat = self.model.voice_conversion(spec, spec_lengths, sid_src=src_se, sid_tgt=tgt_se, tau=tau,
+                                                noise=noise)[0]
         return o_hat, spec_lengths * hop
 
     def convert(self, audio_src_path, src_se, tgt_se, output_path=None, tau=0.3, message="default"):

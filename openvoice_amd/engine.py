@@ -361,6 +361,19 @@ class ConverterEngine:
         outs = tuple(t[:, :, :T].contiguous() for t in (z, z_p, z_hat))
         return o_hat, mask[:, :T].unsqueeze(1).contiguous(), outs
 
+    def graphed(self, B, T, tau, src_rows=1, tgt_rows=1, max_cached=4):
+        """``voice_conversion`` for one fixed (B, T, tau) as a captured HIP graph (see ``GraphedConversion``);
+        the most recent ``max_cached`` shapes stay resident."""
+        key = (int(B), int(T), float(tau), int(src_rows), int(tgt_rows), bool(getattr(self, "_bf16_on", False)))
+        cache = self.__dict__.setdefault("_graphs", {})
+        g = cache.pop(key, None)
+        if g is None:
+            g = GraphedConversion(self, B, T, tau, src_rows, tgt_rows)
+            while len(cache) >= max_cached:
+                cache.pop(next(iter(cache)))
+        cache[key] = g     # re-inserted last: the dict is the LRU order
+        return g
+
     def use_bf16_generator(self, enable=True):
         """Route ``voice_conversion``'s generator through the bf16 kernels (BASELINE.json configs[4]).  Off by
         default: the fp32 path is the one held to the 1e-3 parity bar."""
@@ -449,3 +462,53 @@ class ConverterEngine:
         h = torch.empty(N, H, dtype=torch.float32, device=dev)
         _lib.check(lib.ov_gru_f32(_ptr(gi), _ptr(re["whh_t"]), _ptr(re["bhh"]), _ptr(h), N, H, T, st), "ov_gru_f32")
         return self._linear(h, re["proj_w"], re["proj_b"])
+
+
+class GraphedConversion:
+    """One conversion shape -- (B, T frames, tau, rows of src/tgt speaker embedding) -- captured once into a HIP graph
+    and replayed.  The path is ~330 kernel launches with no host sync and no data-dependent control flow, so a
+    replay is one ``hipGraphLaunch``: at batch 1 (what ``ToneColorConverter.convert`` issues per file) the eager
+    path is bound by the ~10 us of Python/ctypes per launch, not by the GPU.
+
+    Inputs are copied into static device buffers, outputs are static too: **they are overwritten by the next
+    replay** -- clone what must outlive it (``ToneColorConverter.convert_batch`` does).  The engine's workspace of
+    this shape is pinned for the life of the graph.  Reference contract unchanged: openvoice/models.py:492-499."""
+
+    def __init__(self, engine, B, T, tau, src_rows=1, tgt_rows=1):
+        dev = engine.device
+        self.engine, self.B, self.T, self.tau = engine, int(B), int(T), float(tau)
+        f = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+        self.spec = f(B, engine.spec_channels, padded_frames(T))[:, :, :T]      # 16-byte aligned rows
+        self.lengths = torch.full((B,), T, dtype=torch.int64, device=dev)
+        self.g_src, self.g_tgt = f(src_rows, engine.gin, 1), f(tgt_rows, engine.gin, 1)
+        self.noise = f(B, engine.inter, T)
+        run = lambda: engine.voice_conversion(self.spec, self.lengths, self.g_src, self.g_tgt, tau=self.tau,
+                                              noise=self.noise)
+        saved, engine.profile = engine.profile, None       # event records are not capturable
+        try:
+            side = torch.cuda.Stream(dev)                      # torch's rule: warm up off the default stream
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                run()                                          # allocates the workspace, fills the occupancy caches
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self.workspace = engine._workspace(B, T)           # keep it alive if the engine moves to another shape
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = run()
+        finally:
+            engine.profile = saved
+
+    @torch.no_grad()
+    def __call__(self, spec, spec_lengths, sid_src, sid_tgt, noise=None):
+        if tuple(spec.shape) != (self.B, self.engine.spec_channels, self.T):
+            raise _lib.OvError(f"graph captured for spec {(self.B, self.engine.spec_channels, self.T)}, got {tuple(spec.shape)}")
+        self.spec.copy_(spec)
+        self.lengths.copy_(spec_lengths)
+        self.g_src.copy_(sid_src.reshape(self.g_src.shape))
+        self.g_tgt.copy_(sid_tgt.reshape(self.g_tgt.shape))
+        if noise is None:
+            self.noise.normal_()
+        else:
+            self.noise.copy_(noise)
+        self.graph.replay()
+        return self.out

@@ -95,12 +95,17 @@ class SynthesizerTrn(nn.Module):
             self._engine_key = key
         return self._engine
 
-    def voice_conversion(self, y, y_lengths, sid_src, sid_tgt, tau=1.0, noise=None):
+    def voice_conversion(self, y, y_lengths, sid_src, sid_tgt, tau=1.0, noise=None, graph=False):
         """reference: openvoice/models.py:492-499; ``noise`` is the explicit form of the
-        reference's ``randn_like`` draw (optional)."""
+        reference's ``randn_like`` draw (optional).  ``graph=True`` replays the launch sequence of this
+        (B, T, tau) shape from a captured HIP graph (``engine.GraphedConversion``); the returned tensors are
+        then static buffers, valid until the next graphed call of the same shape."""
         eng = self.engine()
         if self.n_speakers != 0:
             eng = eng.core      # a TTS checkpoint also carries enc_q / flow / dec
+        if graph:
+            g = eng.graphed(y.shape[0], y.shape[2], tau, sid_src.shape[0], sid_tgt.shape[0])
+            return g(y, y_lengths, sid_src, sid_tgt, noise=noise)
         return eng.voice_conversion(y, y_lengths, sid_src, sid_tgt, tau=tau, noise=noise)
 
     def infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1., sdp_ratio=0.2,

@@ -202,3 +202,38 @@ def test_voice_conversion_matches_reference_at_benchmark_length(golden_dir, synt
     print("T=861 vs reference: o_hat err", err)
     assert (z_hat.cpu().sum(2) - rec["z_hat_sum"]).abs().max().item() <= 5e-3
     assert err <= O_HAT_TOL
+
+
+@pytest.mark.gpu
+def test_graph_replay_is_bit_identical_to_eager_launches(synth_sd):
+    """HIP-graph replay of the conversion (engine.GraphedConversion) = the same kernels with the same arguments:
+    outputs must equal the eager path's bit for bit, on a second set of inputs too (static buffers refreshed),
+    with ragged lengths and per-item speaker embeddings, and after the engine has moved on to another shape."""
+    model = _model(synth_sd, zero_g=False)
+    B, T = 3, 70
+    gen = torch.Generator().manual_seed(77)
+
+    def inputs(seed_shift):
+        spec = (torch.rand(B, 513, T, generator=gen) * torch.linspace(3, 0.05, 513)[None, :, None]).to(DEV)
+        lengths = torch.tensor([T, T - 9 - seed_shift, T - 30], dtype=torch.long, device=DEV)
+        g_src, g_tgt = (0.3 * torch.randn(B, 256, 1, generator=gen)).to(DEV), (0.3 * torch.randn(1, 256, 1, generator=gen)).to(DEV)
+        return spec, lengths, g_src, g_tgt, torch.randn(B, 192, T, generator=gen).to(DEV)
+
+    a, b = inputs(0), inputs(4)
+    eager = [model.voice_conversion(*x[:4], tau=0.3, noise=x[4]) for x in (a, b)]
+    eager = [(o.clone(), m.clone(), [t.clone() for t in lat]) for o, m, lat in eager]
+    for x, (o_e, m_e, lat_e) in zip((a, b, a), eager + eager[:1]):
+        o_g, m_g, lat_g = model.voice_conversion(*x[:4], tau=0.3, noise=x[4], graph=True)
+        torch.cuda.synchronize()
+        assert torch.equal(o_g, o_e) and torch.equal(m_g, m_e)
+        assert all(torch.equal(g, e) for g, e in zip(lat_g, lat_e))
+    # another shape evicts the engine's workspace of (B, T); the captured graph keeps its own alive
+    model.voice_conversion(a[0][:1, :, :33].contiguous(), torch.tensor([33], device=DEV), a[2][:1], a[3], tau=0.3,
+                           noise=a[4][:1, :, :33].contiguous())
+    o_g = model.voice_conversion(*b[:4], tau=0.3, noise=b[4], graph=True)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(o_g, eager[1][0])
+    eng = model.engine()
+    assert len(eng._graphs) == 1
+    with pytest.raises(RuntimeError):
+        eng.graphed(B, T, 0.3, B, 1)(a[0][:, :, :T - 1], a[1], a[2], a[3])
