@@ -505,18 +505,19 @@ int conv1d_launch(const ov_conv1d_params* p, hipStream_t stream) {
   const int ntiles = (p->L + N_BLK - 1) / N_BLK;
   const int mblocks = (p->M + M_BLK - 1) / M_BLK;
   // Persistent launch: one workgroup per resident slot, each strides over the work list -- when every slot
-  // gets >= 16 tiles, so that the +-1 tile imbalance stays under ~6 %; smaller launches (stage 0 of the
-  // generator: 6.75 tiles per slot, the frame-rate layers) use one workgroup per tile and leave the balancing
-  // to the hardware dispatcher (measured, profiles/r01_s20: persistent +2-5 % at 27 tiles per slot, -5-8 % at
-  // 6.75).  A positive tiles_per_wg forces ceil(total / tiles_per_wg) workgroups (tests, A/B measurements).
+  // gets >= 16 tiles, so that the +-1 tile imbalance stays under ~6 %, and the conv has no residual operand:
+  // a persistent workgroup reads the residual fragment of its next tile with nothing else of its own to run,
+  // while one-tile workgroups leave that wait to be covered by whichever workgroup the dispatcher starts next
+  // (measured with the clocks ramped, profiles/r01_s39: conv2 launches 2-5 % faster non-persistent at C = 64 / 32,
+  // +-1 % at C = 128; conv1 launches 0-4 % faster persistent).  Smaller launches (stage 0 of the generator: 6.75
+  // tiles per slot, the frame-rate layers) use one workgroup per tile and leave the balancing to the hardware
+  // dispatcher.  A positive tiles_per_wg forces ceil(total / tiles_per_wg) workgroups (tests, A/B measurements).
   const long total = (long)ntiles * mblocks * p->B;
   auto kernel = conv1d_mfma_kernel<K, DIL, WM, WN, WVM, WVN, CHUNK, VEC, EPI, NLD>;
   static int slots = 0;   // per kernel instance (this function is instantiated once per variant)
   if (slots == 0) slots = query_resident_workgroups(reinterpret_cast<const void*>(kernel), 64 * (4 + NLD));
-  // below the persistent threshold, stage 0 of the generator (M >= 256: 54 tiles x 2 M-blocks per utterance)
-  // measured 5 % faster with two tiles per workgroup than with one (profiles/r01_s16)
-  const int tpw = p->tiles_per_wg > 0 ? p->tiles_per_wg : (p->M >= 256 && total >= 2L * slots ? 2 : 1);
-  long nwg = (p->tiles_per_wg <= 0 && total >= 16L * slots) ? (long)slots : (total + tpw - 1) / tpw;
+  const int tpw = p->tiles_per_wg > 0 ? p->tiles_per_wg : 1;
+  long nwg = (p->tiles_per_wg <= 0 && p->res == nullptr && total >= 16L * slots) ? (long)slots : (total + tpw - 1) / tpw;
   if (nwg > total) nwg = total;
   hipLaunchKernelGGL(kernel, dim3((unsigned)nwg), dim3(64 * (4 + NLD)), 0, stream, *p);
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;

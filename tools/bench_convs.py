@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--warm-ms", type=float, default=100.0, help="GPU-busy time before each timed region")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--kernels", type=int, nargs="+", default=[3, 7, 11])
+    ap.add_argument("--modes", nargs="+", default=["plain1", "plain5", "res+add"],
+                    help="plain1 / plain5 = conv1 with dilation 1 / 5, res+add = conv2 with residual and MRF sum")
     ap.add_argument("--wn", action="store_true", help="also time the WaveNet k5 gate conv and the 1x1 res/skip conv")
     args = ap.parse_args()
     dev = "cuda:0"
@@ -68,6 +70,8 @@ def main():
         out = torch.empty(B, c, L, device=dev)
         for k in args.kernels:
             for d, mode in ((1, "plain"), (5, "plain"), (1, "res+add")):
+                if (mode + str(d) if mode == "plain" else mode) not in args.modes:
+                    continue
                 w = torch.randn(c, c, k) * (c * k) ** -0.5
                 layer = PackedConv(w, torch.zeros(c), dev, K=k, dil=d)
                 import itertools
