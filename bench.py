@@ -181,6 +181,33 @@ def main():
         elapsed = tmax.item()
     assert o_hat.shape == (B, 1, frames * engine.total_upsample) and bool(torch.isfinite(o_hat).all())
 
+    # PCIe-inclusive rate, reported beside `value` (never as it): the same step with the waveforms coming from
+    # pinned host memory and the converted audio returned to pinned host memory, as a caller holding host buffers
+    # sees it.  Two steps, after the timed region; any failure here leaves the contract line untouched.
+    pcie = None
+    try:
+        host_in = wave.cpu().pin_memory()
+        host_out = torch.empty(o_hat.shape, dtype=o_hat.dtype).pin_memory()
+        dev_wave = wave
+
+        def pcie_step():
+            dev_wave.copy_(host_in, non_blocking=True)
+            o, _ = step()
+            host_out.copy_(o, non_blocking=True)
+
+        pcie_step()
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(2):
+            pcie_step()
+        torch.cuda.synchronize()
+        pcie_ms = (time.perf_counter() - tp) / 2 * 1e3
+        pcie = {"ms_per_step": round(pcie_ms, 3), "value": round(B * args.seconds / (pcie_ms * 1e-3), 2),
+                "host_bytes_per_step": int(host_in.numel() * 4 + host_out.numel() * 4),
+                "note": "per rank; pinned host -> HBM -> convert -> pinned host, copies on the compute stream"}
+    except Exception as exc:   # noqa: BLE001 -- diagnostics only
+        pcie = {"error": repr(exc)[:200]}
+
     # ---- roofline of the dominant kernel: the MFMA conv family on the 72 MRF (ResBlock) convs ----
     engine.profile = []
     step()
@@ -240,6 +267,7 @@ def main():
                          "all_conv_ms_per_step": round(all_conv_s * 1e3, 2),
                          "whole_step_tflops": round(all_flops / (ms * 1e-3) / 1e12, 2)},
             "by_kernel_group_ms": {k: round(v[2] * 1e3, 3) for k, v in sorted(by_tag.items())},
+            "pcie_inclusive": pcie,
         }
         if args.bf16_generator:
             out["roofline"] = {"bound": "hbm", "achieved": round(gen_bytes / t_mrf / 1e9, 1), "peak": 8000.0,
