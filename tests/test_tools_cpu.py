@@ -1,0 +1,57 @@
+"""The rocprofv3 post-processing tools (measurement infrastructure behind profiles/ and bench.py's `traffic`) on
+synthetic counter CSVs with hand-computable answers.  CPU only."""
+import csv
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = ["Dispatch_Id", "Grid_Size", "Kernel_Name", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
+MRF = "void ovk::conv1d_mfma_kernel<11, 1, 2, 2, 2, 2, 32, true, 0, 2>(ov_conv1d_params)"
+PRE = "void ovk::conv1d_mfma_kernel<7, 1, 2, 2, 2, 2, 32, true, 0, 2>(ov_conv1d_params)"
+COPY = "__amd_rocclr_copyBuffer"
+
+
+def _write(path, rows):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(HDR)
+        w.writerows(rows)
+
+
+def _run(tool, *args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), *args], capture_output=True, text=True,
+                         check=True)
+    return out.stdout
+
+
+def test_mfma_busy_fraction_and_clock_from_sq_counters(tmp_path):
+    # one kernel: 155 200 MFMAs x 64 cycles on the pipe, 10 M shader cycles long (SQ_BUSY_CYCLES is summed over the
+    # 32 shader engines), 4.0 ms dispatch -> busy = 155200 * 64 / (1024 * 1e7) = 0.00097; clock = 1e7 / 4e6 ns = 2.5 GHz
+    rows = [[1, 512, MRF, "SQ_VALU_MFMA_BUSY_CYCLES", 0.9 * 1024 * 1e7, 1000, 4001000],
+            [1, 512, MRF, "SQ_BUSY_CYCLES", 32 * 1e7, 1000, 4001000],
+            [1, 512, MRF, "SQ_WAVE_CYCLES", 4e9, 1000, 4001000],
+            [1, 512, MRF, "SQ_WAIT_INST_LDS", 4e7, 1000, 4001000]]
+    _write(str(tmp_path / "p" / "r1_counter_collection.csv"), rows)
+    out = _run("pmc_mfma_busy.py", str(tmp_path / "p"))
+    line = [l for l in out.splitlines() if l.startswith("conv k=11 linear tile 128x128 chunk 32 nld 2")][0].split()
+    assert line[-3] == "0.900" and line[-2] == "0.010" and line[-1] == "2.50"
+    assert "ALL KERNELS" in out
+
+
+def test_pmc_traffic_applies_guide_factors_and_separates_conv_pre(tmp_path):
+    # MRF launch: FETCH_SIZE 500 000 KiB (x2 per the guide's gfx950 correction), WRITE_SIZE 900 000 KiB;
+    # conv_pre (same template, tiny traffic) must not dilute the mean; 1 GiB calibration copies: fetch counts half.
+    gib_kib = float(1 << 20)
+    fetch = [[1, 512, MRF, "FETCH_SIZE", 500000.0, 0, 1], [2, 512, MRF, "FETCH_SIZE", 500000.0, 0, 1],
+             [3, 512, PRE, "FETCH_SIZE", 10000.0, 0, 1]] + [[10 + i, 1, COPY, "FETCH_SIZE", gib_kib / 2, 0, 1] for i in range(3)]
+    write = [[1, 512, MRF, "WRITE_SIZE", 900000.0, 0, 1], [2, 512, MRF, "WRITE_SIZE", 900000.0, 0, 1],
+             [3, 512, PRE, "WRITE_SIZE", 50000.0, 0, 1]] + [[10 + i, 1, COPY, "WRITE_SIZE", gib_kib, 0, 1] for i in range(3)]
+    _write(str(tmp_path / "f" / "r1_counter_collection.csv"), fetch)
+    _write(str(tmp_path / "w" / "r1_counter_collection.csv"), write)
+    rec = json.loads(_run("pmc_traffic.py", str(tmp_path / "f"), str(tmp_path / "w")))
+    assert rec["mrf_launches_fetch_pass"] == 2 and rec["mrf_launches_write_pass"] == 2
+    assert rec["nominal"]["bytes_per_launch"] == (2 * 500000 + 900000) * 1024
+    assert abs(rec["calibrated"]["read_factor"] - 2.0) < 1e-6 and abs(rec["calibrated"]["write_factor"] - 1.0) < 1e-6
