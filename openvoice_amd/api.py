@@ -69,6 +69,12 @@ class BaseSpeakerTTS(OpenVoiceBaseClass):
     @classmethod
     def get_text(cls, text, hps, is_symbol):
         """reference: openvoice/api.py:48-54."""
+        if cls.text_to_sequence is None and is_symbol:
+            # already-cleaned (IPA / symbol) text needs no third-party cleaner: plain symbol lookup
+            text_norm = utils.cleaned_text_to_sequence(text, hps.symbols)
+            if hps.data.add_blank:
+                text_norm = intersperse(text_norm, 0)
+            return torch.LongTensor(text_norm)
         if cls.text_to_sequence is None:
             raise RuntimeError("no text front end registered: set BaseSpeakerTTS.text_to_sequence to a "
                                "text_to_sequence(text, symbols, cleaner_names) callable (e.g. the reference's "

@@ -109,3 +109,10 @@ def default_converter_hparams(version="v2"):
         cfg["_version_"] = "v2"
         model["zero_g"] = True
     return HParams(**cfg)
+
+
+def cleaned_text_to_sequence(cleaned_text, symbols):
+    """Symbol ids of an already-cleaned string; characters outside ``symbols`` are dropped
+    (reference: openvoice/text/__init__.py:34-43)."""
+    symbol_to_id = {s: i for i, s in enumerate(symbols)}
+    return [symbol_to_id[ch] for ch in cleaned_text if ch in symbol_to_id]

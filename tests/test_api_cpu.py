@@ -155,3 +155,11 @@ def test_tts_text_front_end_is_a_hook():
         assert api.BaseSpeakerTTS.get_text("abc", hps, False).tolist() == [0, 1, 0, 2, 0, 3, 0]
     finally:
         api.BaseSpeakerTTS.text_to_sequence = None
+
+
+def test_cleaned_symbol_text_needs_no_front_end():
+    """is_symbol=True (already-cleaned text): plain symbol lookup, unknown characters dropped
+    (reference: openvoice/text/__init__.py:34-43), blanks interspersed per the config."""
+    hps = utils.HParams(symbols=list("_abc"), data=dict(text_cleaners=["x"], add_blank=True))
+    assert api.BaseSpeakerTTS.get_text("a?cb", hps, True).tolist() == [0, 1, 0, 3, 0, 2, 0]
+    assert utils.cleaned_text_to_sequence("cab!", list("_abc")) == [3, 1, 2]
