@@ -283,9 +283,18 @@ __device__ __forceinline__ bool conv_preload(const ov_conv1d_params& p, f32x16 (
 // staging items of a chunk are dealt round-robin to them, so NLD x LB x 64 loads are in flight).
 // The gate epilogue lands at 130 VGPRs on its own; it is held to 128 (4 waves per SIMD, 1-2 VGPRs
 // spilled in the epilogue) because the third workgroup per CU is worth more than the spill costs.
-template <int K, int DIL, int WM, int WN, int WVM, int WVN, int CHUNK, bool VEC, int EPI, int NLD>
+// Staging kinds (template argument VEC): how the loader waves bring a chunk into LDS.
+constexpr int STAGE_SCALAR = 0;   // 4-byte loads through registers (rows not 16-byte aligned)
+constexpr int STAGE_VEC = 1;      // 16-byte loads through registers, leaky-ReLU applied on the way in
+constexpr int STAGE_DMA = 2;      // global_load_lds_dwordx4: global -> LDS without registers; leaky-ReLU is applied by
+                                  // the matrix waves to each B operand after its ds_read
+
+template <int K, int DIL, int WM, int WN, int WVM, int WVN, int CHUNK, int VEC, int EPI, int NLD>
 __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_CONVT_S8 || EPI == EPI_CONVT_S2) ? 4 : 1) void conv1d_mfma_kernel(const ov_conv1d_params p) {
   static_assert(WVM * WVN == 4, "4 matrix waves per workgroup");
+  static_assert(VEC == STAGE_SCALAR || VEC == STAGE_VEC || VEC == STAGE_DMA, "staging kind");
+  constexpr bool DMA = VEC == STAGE_DMA;
+  static_assert(!DMA || K % 2 == 1, "LDS-DMA staging: odd K only (whole 16-byte vectors are valid or not)");
   static_assert(CHUNK % UNIT == 0 && (CHUNK / UNIT == 2 || CHUNK / UNIT == 4), "chunk = 2 or 4 units");
   constexpr int UPC = CHUNK / UNIT;
   constexpr int N_BLK = 32 * WN * WVN;
@@ -296,8 +305,10 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
   constexpr int PADA = (PAD + 3) / 4 * 4;
   constexpr int XS = N_BLK + PADA + (PADR + 3) / 4 * 4;  // LDS row stride (floats), multiple of 4
   constexpr int XS4 = XS / 4;
-  constexpr int BUF = CHUNK * XS;       // floats per LDS buffer
   constexpr int NITEM = VEC ? CHUNK * XS4 : CHUNK * XS;
+  // LDS-DMA writes whole wave-instructions (64 lanes x 16 bytes = 1 KiB): the buffer is rounded up to that
+  constexpr int NDMA = (CHUNK * XS4 + 63) / 64;
+  constexpr int BUF = DMA ? NDMA * 256 : CHUNK * XS;       // floats per LDS buffer
   // loads in flight per loader lane: the whole chunk in one batch when that needs <= LB_MAX of them
   constexpr int PER_LANE = (NITEM + 64 * NLD - 1) / (64 * NLD);
   constexpr int LB = PER_LANE < LB_MAX ? PER_LANE : LB_MAX;
@@ -341,8 +352,30 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
       const float* __restrict__ xb = p.x + (int64_t)(wid / (ntiles * mblocks)) * p.x_bstride;
       for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
         float* dst = xs + (it & 1) * BUF;
+        if constexpr (DMA) {
+          // The LDS image of a chunk is linear in 16-byte items (row * XS + 4 * c4 == 4 * idx), which is exactly
+          // what global_load_lds writes: wave-uniform base + lane * 16.  Per-lane SOURCE addresses do the tiling;
+          // items outside the tensor (halo beyond [0, L), channel rows >= Cin, the round-up of the last
+          // wave-instruction) read the all-zero record the weight packer leaves after the last real one.
+          // Requires L % 4 == 0 (a vector is wholly inside or outside a row) -- checked by the dispatcher.
+          const float* zsrc = p.w + (size_t)nunits * K * REC;
+#pragma unroll
+          for (int i = 0; i < (OV_EXP ? 0 : (NDMA + NLD - 1) / NLD); ++i) {
+            const int blk = i * NLD + (wave - 4);            // wave-uniform
+            if (blk < NDMA) {
+              const int idx = blk * 64 + lane;
+              const int row = idx / XS4, c4 = idx - row * XS4;
+              const int ci = chunk * CHUNK + row;
+              const int t = t0 - PADA + 4 * c4;
+              const bool ok = idx < NITEM && ci < Cin && t >= 0 && t < Lin;
+              const float* src = ok ? xb + ((uint32_t)ci * ldx + (uint32_t)t) : zsrc;
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                               (__attribute__((address_space(3))) void*)(dst + 4 * idx), 16, 0, 0);
+            }
+          }
+        }
 #pragma unroll 1   // one batch of LB loads per lane in flight at a time: bounds the loader's VGPRs
-        for (int bt = 0; bt < (OV_EXP ? 0 : NBATCH); ++bt) {
+        for (int bt = 0; bt < ((OV_EXP || DMA) ? 0 : NBATCH); ++bt) {
           if constexpr (VEC) {
             f32x4 stg[LB];
             int nval[LB];   // valid leading elements of each vector (0 = zero fill); a VGPR count,
@@ -433,8 +466,23 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
       // consumes it and the wave eats the LDS latency every k-step (-15...35 % on MI355X).
       constexpr int STEPS = UPC * 4 * K;
       float bcur[WN], bnxt[WN];
+      // LDS-DMA staging leaves the raw input in LDS: the leaky-ReLU prologue is applied here, to each B operand
+      // after its ds_read (max(v, slope * v) == lrelu(v) for 0 < slope <= 1, enforced by the dispatcher);
+      // two VALU ops per operand that issue under the MFMAs of the k-step in flight.
+      const float bslope = p.in_slope;
+      // (inline v_max_f32: through fmaxf / fmed3f hipcc adds a NaN-quieting v_max v, v, v per operand)
+      auto bact = [&](float v) {
+        if constexpr (DMA) {
+          float r;
+          const float t = v * bslope;
+          asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(t));
+          return r;
+        } else {
+          return v;
+        }
+      };
 #pragma unroll
-      for (int j = 0; j < WN; ++j) bcur[j] = xl[32 * j];   // k-step 0: unit 0, pair 0, tap 0
+      for (int j = 0; j < WN; ++j) bcur[j] = bact(xl[32 * j]);   // k-step 0: unit 0, pair 0, tap 0
 #pragma unroll
       for (int sa = 0; sa < STEPS; ++sa) {
         const int u = sa & 3;
@@ -459,7 +507,7 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
         __builtin_amdgcn_sched_barrier(0);
         if (sa + 1 < STEPS) {
 #pragma unroll
-          for (int j = 0; j < WN; ++j) bcur[j] = bnxt[j];
+          for (int j = 0; j < WN; ++j) bcur[j] = bact(bnxt[j]);
         }
         if (u == 3) {
 #pragma unroll
@@ -499,7 +547,7 @@ inline int query_resident_workgroups(const void* kernel, int block_threads) {
 
 typedef int (*conv_launch_fn)(const ov_conv1d_params*, hipStream_t);
 
-template <int K, int DIL, int WM, int WN, int WVM, int WVN, int CHUNK, bool VEC, int EPI, int NLD>
+template <int K, int DIL, int WM, int WN, int WVM, int WVN, int CHUNK, int VEC, int EPI, int NLD>
 int conv1d_launch(const ov_conv1d_params* p, hipStream_t stream) {
   constexpr int M_BLK = 32 * WM * WVM, N_BLK = 32 * WN * WVN;
   const int ntiles = (p->L + N_BLK - 1) / N_BLK;
@@ -541,11 +589,11 @@ struct ConvVariant {
 // OV_DEFINE_VARIANTS(table, LIST) emits the explicit kernel instantiations (seen by the host and the
 // device pass) and the host-side dispatch table `table` / `table##Count`.
 #define OV_X_INST(K, DIL, TILE, CHUNK, VEC, EPI, NLD)                                                        \
-  template __global__ void conv1d_mfma_kernel<K, DIL, OV_TILE_##TILE, CHUNK, (VEC) != 0, EPI, NLD>(           \
+  template __global__ void conv1d_mfma_kernel<K, DIL, OV_TILE_##TILE, CHUNK, VEC, EPI, NLD>(                  \
       const ov_conv1d_params);
 #define OV_X_ROW(K, DIL, TILE, CHUNK, VEC, EPI, NLD)                                                         \
   {K, DIL, TILE_##TILE, CHUNK, VEC, EPI, NLD,                                                                \
-   conv1d_launch<K, DIL, OV_TILE_##TILE, CHUNK, (VEC) != 0, EPI, NLD>},
+   conv1d_launch<K, DIL, OV_TILE_##TILE, CHUNK, VEC, EPI, NLD>},
 #if defined(__HIP_DEVICE_COMPILE__)
 #define OV_DEFINE_VARIANTS(table, LIST) LIST(OV_X_INST)
 #else
@@ -566,5 +614,6 @@ OV_DECLARE_VARIANTS(kVariantsD)
 OV_DECLARE_VARIANTS(kVariantsE)
 OV_DECLARE_VARIANTS(kVariantsS)
 OV_DECLARE_VARIANTS(kVariantsW)
+OV_DECLARE_VARIANTS(kVariantsG)
 
 }  // namespace ovk

@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HDR = ["Dispatch_Id", "Grid_Size", "Kernel_Name", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
 MRF = "void ovk::conv1d_mfma_kernel<11, 1, 2, 2, 2, 2, 32, true, 0, 2>(ov_conv1d_params)"
-PRE = "void ovk::conv1d_mfma_kernel<7, 1, 2, 2, 2, 2, 32, true, 0, 2>(ov_conv1d_params)"
+PRE = "void ovk::conv1d_mfma_kernel<7, 1, 2, 2, 2, 2, 32, 1, 0, 2>(ov_conv1d_params)"      # name after r01 s40 (int staging kind)
 COPY = "__amd_rocclr_copyBuffer"
 
 

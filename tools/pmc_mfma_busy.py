@@ -20,7 +20,7 @@ import re
 import sys
 from collections import defaultdict
 
-CONV = re.compile(r"conv1d_mfma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (\d+), (\d+)>")
+CONV = re.compile(r"conv1d_mfma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false|\d+), (\d+), (\d+)>")   # staging kind: bool before r01 s40, int after
 EPI = {0: "linear", 1: "gate", 2: "resskip", 3: "couple", 4: "posterior", 5: "convT", 6: "magnitude", 16: "convT s8",
        17: "convT s2"}
 
@@ -29,9 +29,9 @@ def family(name):
     m = CONV.search(name)
     if not m:
         return name.split("(")[0][-60:]
-    k, d, wm, wn, wvm, wvn, chunk, _, epi, nld = (int(x) if x.isdigit() else x for x in m.groups())
+    k, d, wm, wn, wvm, wvn, chunk, stage, epi, nld = (int(x) if x.isdigit() else x for x in m.groups())
     tile = f"{32 * wm * wvm}x{32 * wn * wvn}"
-    return f"conv k={k} {EPI.get(epi, epi)} tile {tile} chunk {chunk} nld {nld}"
+    return f"conv k={k} {EPI.get(epi, epi)} tile {tile} chunk {chunk} nld {nld}" + (" lds-dma" if stage == 2 else "")
 
 
 def main():

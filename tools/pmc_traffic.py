@@ -16,7 +16,7 @@ import os
 import re
 import sys
 
-MRF = re.compile(r"conv1d_mfma_kernel<(3|7|11), (1|3|5), \d+, \d+, \d+, \d+, \d+, true, 0, \d+>")
+MRF = re.compile(r"conv1d_mfma_kernel<(3|7|11), (1|3|5), \d+, \d+, \d+, \d+, \d+, (?:true|1|2), 0, \d+>")
 GIB = float(1 << 30)
 
 
