@@ -1,6 +1,8 @@
 """NOT COLLECTED by pytest (file name): checks for the LDS-DMA staging variant of the MRF convs
-(openvoice_amd/csrc/conv1d_inst_g.hip, selected with loaders = OV_LOADERS_LDS_DMA = -1), written after the last GPU
-session of round 1 and therefore not yet run on hardware.  First thing to do with GPU time:
+(openvoice_amd/csrc/conv1d_inst_g.hip, selected with loaders = OV_LOADERS_LDS_DMA = -1), written after the last full GPU
+session of round 1.  The kernels themselves HAVE run on an MI355X through tools/micro/dma_check.hip (bit-identical to
+the register-staged variant on six ragged shapes, 1-7 points slower: profiles/r01_s40_lds_dma_variant_check.txt);
+these pytest checks have not.  With GPU time:
 
     python -m pytest tests/pending_gpu_lds_dma.py -q -m gpu -x          # (explicit path: pytest then collects it)
     python tools/bench_convs.py --loaders 0 -1 --modes plain1 res+add   # A/B against the shipped loaders
