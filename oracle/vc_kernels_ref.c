@@ -1,0 +1,91 @@
+/* ORACLE (test infrastructure, never the product path): plain-C, loop-level restatement of the three operations
+ * that carry 98 % of the converter's arithmetic, as the reference evaluates them.  No SIMD, no blocking, fp32
+ * accumulation in the textbook order -- the independent check of oracle/vc_oracle.py (which restates the path in
+ * terms of torch CPU operators) and, through it, of the HIP kernels.  Built by oracle/Makefile into
+ * oracle/_build/libvc_kernels_ref.so; loaded by oracle/c_kernels.py; used by tests/test_oracle_c_kernels.py only. */
+#include <math.h>
+#include <stddef.h>
+
+static float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+/* y[b][co][t] = bias[co] + sum_{ci, j} w[co][ci][j] * lrelu(x[b][ci][t + j*dil - pad], slope),  pad = (K*dil - dil)/2
+ * reference: ResBlock1.forward, openvoice/modules.py:296-306 (F.leaky_relu(x, LRELU_SLOPE) then c1 / c2),
+ * "same" padding get_padding, openvoice/commons.py:12-13; also Generator.conv_pre (models.py:273, slope = 1),
+ * WN.in_layers (modules.py:166-172) and every 1x1 conv of the path (K = 1).  Zero padding outside [0, L). */
+void ref_conv1d_f32(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int L, int K,
+                    int dil, float slope) {
+  const int pad = (K * dil - dil) / 2;
+  for (int b = 0; b < B; ++b)
+    for (int co = 0; co < Cout; ++co)
+      for (int t = 0; t < L; ++t) {
+        float acc = bias ? bias[co] : 0.f;
+        for (int ci = 0; ci < Cin; ++ci)
+          for (int j = 0; j < K; ++j) {
+            const int tt = t + j * dil - pad;
+            if (tt >= 0 && tt < L)
+              acc += w[((size_t)co * Cin + ci) * K + j] * lrelu(x[((size_t)b * Cin + ci) * L + tt], slope);
+          }
+        y[((size_t)b * Cout + co) * L + t] = acc;
+      }
+}
+
+/* torch.nn.ConvTranspose1d(Cin, Cout, K, stride, padding = pad) applied to lrelu(x, slope):
+ * y[b][co][u] = bias[co] + sum_{ci, t, j : t*stride - pad + j == u} w[ci][co][j] * lrelu(x[b][ci][t]),  L_out = (L-1)*stride - 2*pad + K
+ * reference: Generator.ups, openvoice/models.py:244-256 (k = 2 * stride, pad = (k - stride) / 2 so L_out = stride * L)
+ * and the leaky_relu in front of it, models.py:278-279. */
+void ref_conv_transpose1d_f32(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout,
+                              int L, int K, int stride, int pad, float slope) {
+  const int Lout = (L - 1) * stride - 2 * pad + K;
+  for (int b = 0; b < B; ++b)
+    for (int co = 0; co < Cout; ++co) {
+      float* row = y + ((size_t)b * Cout + co) * Lout;
+      for (int u = 0; u < Lout; ++u) row[u] = bias ? bias[co] : 0.f;
+      for (int ci = 0; ci < Cin; ++ci)
+        for (int t = 0; t < L; ++t) {
+          const float v = lrelu(x[((size_t)b * Cin + ci) * L + t], slope);
+          for (int j = 0; j < K; ++j) {
+            const int u = t * stride - pad + j;
+            if (u >= 0 && u < Lout) row[u] += w[((size_t)ci * Cout + co) * K + j] * v;
+          }
+        }
+    }
+}
+
+/* acts[b][c][t] = tanh(x_in[b][c][t] + g[b][c]) * sigmoid(x_in[b][H + c][t] + g[b][H + c]),  c < H
+ * reference: fused_add_tanh_sigmoid_multiply, openvoice/commons.py:100-107, as called by WN.forward
+ * (modules.py:194-200) with g_l the per-layer slice of cond_layer(g) (T = 1, broadcast over t). */
+void ref_gate_f32(const float* x_in, const float* g, float* acts, int B, int H, int T) {
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < H; ++c)
+      for (int t = 0; t < T; ++t) {
+        const float a = x_in[((size_t)b * 2 * H + c) * T + t] + (g ? g[(size_t)b * 2 * H + c] : 0.f);
+        const float s = x_in[((size_t)b * 2 * H + H + c) * T + t] + (g ? g[(size_t)b * 2 * H + H + c] : 0.f);
+        acts[((size_t)b * H + c) * T + t] = tanhf(a) * (1.f / (1.f + expf(-s)));
+      }
+}
+
+/* One WaveNet layer as WN.forward evaluates it (openvoice/modules.py:192-209), in place on x and output:
+ *   x_in = in_layer(x); acts = gate(x_in, g_l); rs = res_skip(acts);
+ *   not last: x = (x + rs[:H]) * mask; output += rs[H:]        last: output += rs
+ * w_in [2H][H][K], w_rs [2H or H][H][1]; mask [B][T]; scratch holds 2H*T + H*T + 2H*T floats. */
+void ref_wn_layer_f32(float* x, float* output, const float* w_in, const float* b_in, const float* w_rs, const float* b_rs,
+                      const float* g, const float* mask, int B, int H, int T, int K, int dil, int last, float* scratch) {
+  for (int b = 0; b < B; ++b) {
+    float* x_in = scratch;
+    float* acts = x_in + (size_t)2 * H * T;
+    float* rs = acts + (size_t)H * T;
+    ref_conv1d_f32(x + (size_t)b * H * T, w_in, b_in, x_in, 1, H, 2 * H, T, K, dil, 1.f);
+    ref_gate_f32(x_in, g ? g + (size_t)b * 2 * H : NULL, acts, 1, H, T);
+    const int R = last ? H : 2 * H;
+    ref_conv1d_f32(acts, w_rs, b_rs, rs, 1, H, R, T, 1, 1, 1.f);
+    for (int c = 0; c < H; ++c)
+      for (int t = 0; t < T; ++t) {
+        const size_t i = ((size_t)b * H + c) * T + t;
+        if (last) output[i] += rs[(size_t)c * T + t];
+        else {
+          x[i] = (x[i] + rs[(size_t)c * T + t]) * mask[(size_t)b * T + t];
+          output[i] += rs[(size_t)(H + c) * T + t];
+        }
+      }
+  }
+}
