@@ -190,6 +190,8 @@ def main():
     # sees it.  Two steps, after the timed region; any failure here leaves the contract line untouched.
     pcie = None
     try:
+        if world > 1:       # N = 1 only: a one-sided failure here must never strand the other ranks in a collective
+            raise RuntimeError("measured at --gpus 1 only")
         host_in = wave.cpu().pin_memory()
         host_out = torch.empty(o_hat.shape, dtype=o_hat.dtype).pin_memory()
         dev_wave = wave
