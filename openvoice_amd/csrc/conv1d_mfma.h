@@ -500,14 +500,25 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
         // Pin the prefetches here: without this hipcc sinks the loads next to their first use.
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < WM; ++i)
+        for (int m = 0; m < WM * WN; ++m) {
+          const int i = m / WN, j = m % WN;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][u], bcur[j], acc[i][j], 0, 0, 0);
+          if constexpr (DMA) {
+            // activate the NEXT k-step's operands halfway through this k-step's MFMAs: their ds_read was issued
+            // >= 128 matrix cycles ago, and the two VALU ops per operand retire under the remaining MFMAs instead
+            // of sitting on the dependency path between two k-steps
+            if (m == (WM * WN) / 2 - 1 && sa + 1 < STEPS) {
+              __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < WN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][u], bcur[j], acc[i][j], 0, 0, 0);
+              for (int jj = 0; jj < WN; ++jj) bnxt[jj] = bact(bnxt[jj]);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (sa + 1 < STEPS) {
 #pragma unroll
-          for (int j = 0; j < WN; ++j) bcur[j] = bact(bnxt[j]);
+          for (int j = 0; j < WN; ++j) bcur[j] = bnxt[j];
         }
         if (u == 3) {
 #pragma unroll
