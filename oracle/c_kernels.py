@@ -19,7 +19,8 @@ def load():
         if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
             subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
         _lib = ctypes.CDLL(_SO)
-        for name in ("ref_conv1d_f32", "ref_conv_transpose1d_f32", "ref_gate_f32", "ref_wn_layer_f32"):
+        for name in ("ref_conv1d_f32", "ref_conv_transpose1d_f32", "ref_gate_f32", "ref_wn_layer_f32",
+                     "ref_rq_spline_inverse_f32"):
             getattr(_lib, name).restype = None
     return _lib
 
@@ -69,3 +70,15 @@ def wn_layer(x, output, w_in, b_in, w_rs, b_rs, g, mask, dil, last):
     scratch = torch.empty(5 * H * T)
     load().ref_wn_layer_f32(_p(x), _p(output), _p(w_in), _p(b_in), _p(w_rs), _p(b_rs), _p(g), _p(mask), B, H, T,
                             w_in.shape[2], dil, 1 if last else 0, _p(scratch))
+
+
+def rq_spline_inverse(y, uw, uh, ud, tail_bound=5.0, min_w=1e-3, min_h=1e-3, min_d=1e-3):
+    """Element-wise inverse rational-quadratic spline with linear tails (transforms.py:50-188); ``y`` [...],
+    ``uw`` / ``uh`` [..., bins], ``ud`` [..., bins - 1]."""
+    y, uw, uh, ud = _f(y), _f(uw), _f(uh), _f(ud)
+    nb = uw.shape[-1]
+    x = torch.empty_like(y)
+    load().ref_rq_spline_inverse_f32(_p(y), _p(uw), _p(uh), _p(ud), _p(x), ctypes.c_long(y.numel()), nb,
+                                     ctypes.c_float(tail_bound), ctypes.c_float(min_w), ctypes.c_float(min_h),
+                                     ctypes.c_float(min_d))
+    return x

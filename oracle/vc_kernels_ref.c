@@ -89,3 +89,48 @@ void ref_wn_layer_f32(float* x, float* output, const float* w_in, const float* b
       }
   }
 }
+
+/* Inverse of the unconstrained rational-quadratic spline with linear tails, one element:
+ *   reference: unconstrained_rational_quadratic_spline, openvoice/transforms.py:50-97 (tails: identity outside
+ *   [-tail, tail]; derivative logits padded with log(exp(1 - min_d) - 1) so that both edge derivatives are 1),
+ *   rational_quadratic_spline(inverse=True), openvoice/transforms.py:100-188 (softmax widths/heights floored at
+ *   min_w / min_h, cumulative knots rescaled to [-tail, tail] with the two ends pinned, bin search on the heights
+ *   with the last edge nudged by 1e-6, quadratic root 2c / (-b - sqrt(b^2 - 4ac))).
+ * uw, uh: NB logits each (already divided by sqrt(filter_channels), modules.py:499-502); ud: NB - 1 logits. */
+#define RQ_MAX_BINS 32
+static void rq_knots(const float* u, int nb, float minv, float tail, float* cum /* nb + 1 */) {
+  float mx = u[0], sum = 0.f, e[RQ_MAX_BINS];
+  for (int i = 1; i < nb; ++i) mx = u[i] > mx ? u[i] : mx;
+  for (int i = 0; i < nb; ++i) { e[i] = expf(u[i] - mx); sum += e[i]; }
+  float run = 0.f;
+  cum[0] = -tail;
+  for (int i = 0; i < nb; ++i) {
+    run += minv + (1.f - minv * nb) * (e[i] / sum);
+    cum[i + 1] = run * 2.f * tail - tail;
+  }
+  cum[nb] = tail;
+}
+static float softplus(float v) { return v > 20.f ? v : log1pf(expf(v)); }   /* torch.nn.functional.softplus threshold */
+
+void ref_rq_spline_inverse_f32(const float* y, const float* uw, const float* uh, const float* ud, float* x, long n, int nb,
+                               float tail, float min_w, float min_h, float min_d) {
+  const float edge = logf(expf(1.f - min_d) - 1.f);
+  for (long e = 0; e < n; ++e) {
+    const float yv = y[e];
+    if (!(yv >= -tail && yv <= tail)) { x[e] = yv; continue; }          /* linear tails: identity */
+    float cw[RQ_MAX_BINS + 1], ch[RQ_MAX_BINS + 1];
+    rq_knots(uw + e * nb, nb, min_w, tail, cw);
+    rq_knots(uh + e * nb, nb, min_h, tail, ch);
+    int b = 0;                                                          /* searchsorted on the heights */
+    for (int i = 0; i <= nb; ++i) b += yv >= (i == nb ? ch[i] + 1e-6f : ch[i]);
+    b = b - 1 < 0 ? 0 : (b - 1 > nb - 1 ? nb - 1 : b - 1);
+    const float* de = ud + e * (nb - 1);
+    const float d0 = min_d + softplus(b == 0 ? edge : de[b - 1]);
+    const float d1 = min_d + softplus(b == nb - 1 ? edge : de[b]);
+    const float bw = cw[b + 1] - cw[b], bh = ch[b + 1] - ch[b], delta = bh / bw;
+    const float dy = yv - ch[b], s = d0 + d1 - 2.f * delta;
+    const float a = dy * s + bh * (delta - d0), bq = bh * d0 - dy * s, c = -delta * dy;
+    const float root = (2.f * c) / (-bq - sqrtf(bq * bq - 4.f * a * c));
+    x[e] = root * bw + cw[b];
+  }
+}

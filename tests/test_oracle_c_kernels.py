@@ -65,3 +65,20 @@ def test_c_wavenet_matches_python_oracle(synth_sd):
                                g_all[:, 2 * H * i: 2 * H * (i + 1)].contiguous(), mask[:, 0], 1, i == ENC_Q_LAYERS - 1)
         got = out * mask
     _close(got, ref, rel=5e-5)
+
+
+def test_c_rq_spline_inverse_matches_torch_oracle_and_inverts_the_forward_spline():
+    """transforms.py:50-188 in C == oracle/tts_oracle.py (torch, pinned to the reference's TTS goldens), inside the
+    spline, exactly on knots / the tail bound, and in the linear tails."""
+    from oracle import tts_oracle
+    gen = torch.Generator().manual_seed(11)
+    n, nb = 4096, 10
+    uw, uh = torch.randn(n, nb, generator=gen), torch.randn(n, nb, generator=gen)
+    ud = 2.0 * torch.randn(n, nb - 1, generator=gen)
+    y = 7.0 * (2 * torch.rand(n, generator=gen) - 1)            # ~29 % of the elements land in the tails
+    y[:4] = torch.tensor([5.0, -5.0, 0.0, 5.0000005])
+    ref = tts_oracle.rq_spline_inverse(y, uw, uh, ud)
+    got = c_kernels.rq_spline_inverse(y, uw, uh, ud)
+    assert torch.equal(got[y.abs() > 5.0], y[y.abs() > 5.0])
+    _close(got, ref, rel=3e-5)
+    assert bool(((got >= -5.0) & (got <= 5.0))[y.abs() <= 5.0].all())
