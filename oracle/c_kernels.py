@@ -20,7 +20,7 @@ def load():
             subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
         _lib = ctypes.CDLL(_SO)
         for name in ("ref_conv1d_f32", "ref_conv_transpose1d_f32", "ref_gate_f32", "ref_wn_layer_f32",
-                     "ref_rq_spline_inverse_f32"):
+                     "ref_rq_spline_inverse_f32", "ref_rel_attention_f32"):
             getattr(_lib, name).restype = None
     return _lib
 
@@ -82,3 +82,14 @@ def rq_spline_inverse(y, uw, uh, ud, tail_bound=5.0, min_w=1e-3, min_h=1e-3, min
                                      ctypes.c_float(tail_bound), ctypes.c_float(min_w), ctypes.c_float(min_h),
                                      ctypes.c_float(min_d))
     return x
+
+
+def rel_attention(q, k, v, emb_rel_k, emb_rel_v, mask, n_heads, window):
+    """Attention core of ``MultiHeadAttention`` with relative keys / values (attentions.py:264-329); ``q``/``k``/``v``
+    [B, C, T] straight out of conv_q / conv_k / conv_v, ``emb_rel_*`` [2 * window + 1, C // n_heads], ``mask`` [B, T]."""
+    q, k, v, ek, ev, mask = (_f(t) for t in (q, k, v, emb_rel_k, emb_rel_v, mask))
+    B, C, T = q.shape
+    out, row = torch.empty_like(q), torch.empty(T)
+    load().ref_rel_attention_f32(_p(q), _p(k), _p(v), _p(ek), _p(ev), _p(mask), _p(out), B, n_heads, C // n_heads, T,
+                                 window, _p(row))
+    return out

@@ -1,5 +1,6 @@
-/* ORACLE (test infrastructure, never the product path): plain-C, loop-level restatement of the three operations
- * that carry 98 % of the converter's arithmetic, as the reference evaluates them.  No SIMD, no blocking, fp32
+/* ORACLE (test infrastructure, never the product path): plain-C, loop-level restatement of the operations that
+ * carry the arithmetic of the path (convs: 98 % of the converter's FLOPs; the WaveNet gate; and the two TTS-side kernels
+ * north_star names: the inverse rational-quadratic spline and relative-position attention), as the reference evaluates them.  No SIMD, no blocking, fp32
  * accumulation in the textbook order -- the independent check of oracle/vc_oracle.py (which restates the path in
  * terms of torch CPU operators) and, through it, of the HIP kernels.  Built by oracle/Makefile into
  * oracle/_build/libvc_kernels_ref.so; loaded by oracle/c_kernels.py; used by tests/test_oracle_c_kernels.py only. */
@@ -133,4 +134,47 @@ void ref_rq_spline_inverse_f32(const float* y, const float* uw, const float* uh,
     const float root = (2.f * c) / (-bq - sqrtf(bq * bq - 4.f * a * c));
     x[e] = root * bw + cw[b];
   }
+}
+
+/* Self-attention core with a +-window band of relative-position keys and values, one (batch, head) at a time:
+ *   scores[t][s] = (q[t] / sqrt(dk)) . k[s] + (|s - t| <= w ? (q[t] / sqrt(dk)) . ek[s - t + w] : 0)
+ *   scores[t][s] = -1e4 where mask[t] * mask[s] == 0;  p = softmax_s(scores)
+ *   out[t] = sum_s p[t][s] v[s] + sum_{|r| <= w, 0 <= t + r < T} p[t][t + r] ev[r + w]
+ * reference: MultiHeadAttention.attention, openvoice/attentions.py:264-329 (the relative logits are built there by
+ * padding / reshaping a [T, 2T-1] tensor, _relative_position_to_absolute_position :331-345 and back :347-360; only the
+ * 2w + 1 diagonals are ever non-zero, which is what is evaluated here).
+ * q, k, v, out: [B][heads * dk][T] (the conv_q / conv_k / conv_v outputs as the reference lays them out);
+ * ek, ev: [2w + 1][dk] (heads_share = True); mask [B][T]; row: scratch of T floats. */
+void ref_rel_attention_f32(const float* q, const float* k, const float* v, const float* ek, const float* ev,
+                           const float* mask, float* out, int B, int heads, int dk, int T, int w, float* row) {
+  const float scale = 1.f / sqrtf((float)dk);
+  for (int b = 0; b < B; ++b)
+    for (int h = 0; h < heads; ++h) {
+      const size_t base = ((size_t)b * heads + h) * dk * T;
+      for (int t = 0; t < T; ++t) {
+        float mx = -INFINITY;
+        for (int s = 0; s < T; ++s) {
+          float acc = 0.f;
+          for (int d = 0; d < dk; ++d) acc += q[base + (size_t)d * T + t] * scale * k[base + (size_t)d * T + s];
+          const int r = s - t;
+          if (r >= -w && r <= w) {
+            float rel = 0.f;
+            for (int d = 0; d < dk; ++d) rel += q[base + (size_t)d * T + t] * scale * ek[(size_t)(r + w) * dk + d];
+            acc += rel;
+          }
+          if (mask && mask[(size_t)b * T + t] * mask[(size_t)b * T + s] == 0.f) acc = -1e4f;
+          row[s] = acc;
+          mx = acc > mx ? acc : mx;
+        }
+        float sum = 0.f;
+        for (int s = 0; s < T; ++s) { row[s] = expf(row[s] - mx); sum += row[s]; }
+        for (int d = 0; d < dk; ++d) {
+          float acc = 0.f;
+          for (int s = 0; s < T; ++s) acc += row[s] * v[base + (size_t)d * T + s];
+          for (int r = -w; r <= w; ++r)
+            if (t + r >= 0 && t + r < T) acc += row[t + r] * ev[(size_t)(r + w) * dk + d];
+          out[base + (size_t)d * T + t] = acc / sum;
+        }
+      }
+    }
 }

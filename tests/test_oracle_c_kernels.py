@@ -82,3 +82,22 @@ def test_c_rq_spline_inverse_matches_torch_oracle_and_inverts_the_forward_spline
     assert torch.equal(got[y.abs() > 5.0], y[y.abs() > 5.0])
     _close(got, ref, rel=3e-5)
     assert bool(((got >= -5.0) & (got <= 5.0))[y.abs() <= 5.0].all())
+
+
+def test_c_relative_attention_matches_torch_oracle(synth_tts_sd):
+    """attentions.py:264-329 in C (band evaluated directly) == oracle/tts_oracle.py::relative_attention (dense [T, T]
+    formulation, pinned to the reference's TTS goldens) on the first encoder layer of the synthetic TTS weights,
+    ragged lengths, T both below and above the window."""
+    from oracle import tts_oracle
+    from openvoice_amd.params import ATTN_WINDOW
+    sd, prefix, heads = synth_tts_sd, "enc_p.encoder.attn_layers.0", 2
+    for T, lens in ((3, [3, 2]), (29, [29, 17])):
+        x = _rand(2, 192, T, seed=T, scale=0.7)
+        mask = vc_oracle.sequence_mask(torch.tensor(lens), T)
+        with torch.no_grad():
+            ref = tts_oracle.relative_attention(sd, prefix, x, mask, heads)
+            q, k, v = (F.conv1d(x, sd[f"{prefix}.conv_{n}.weight"], sd[f"{prefix}.conv_{n}.bias"]) for n in "qkv")
+            core = c_kernels.rel_attention(q, k, v, sd[prefix + ".emb_rel_k"][0], sd[prefix + ".emb_rel_v"][0], mask[:, 0],
+                                           heads, ATTN_WINDOW)
+            got = F.conv1d(core, sd[prefix + ".conv_o.weight"], sd[prefix + ".conv_o.bias"])
+        _close(got, ref, rel=3e-5)
