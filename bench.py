@@ -114,8 +114,6 @@ def main():
     ap.add_argument("--bf16-generator", action="store_true",
                     help="NOT the contract configuration: run the generator on the opt-in bf16 kernels "
                          "(BASELINE.json configs[4]); the JSON line is marked accordingly")
-    ap.add_argument("--lds-dma", action="store_true",
-                    help="A/B knob: run the MRF convs on the LDS-DMA staging variant (conv1d_inst_g.hip)")
     ap.add_argument("--pmc-calibration", action="store_true",
                     help="after the timed region, run three 1 GiB device-to-device copies (a known byte count) "
                          "so a rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass can be calibrated")
@@ -147,8 +145,6 @@ def main():
     engine = model.engine()
     if args.bf16_generator:
         engine.use_bf16_generator(True)
-    if args.lds_dma:
-        engine.mrf_loaders = -1
 
     B = args.batch
     samples = int(args.seconds * SAMPLE_RATE)
@@ -260,7 +256,6 @@ def main():
             "config": {"workload": f"ToneColorConverter.convert path, {B} x {args.seconds:g} s @ 22.05 kHz per GPU "
                                    f"(T={frames} frames), fp32, calibrated random weights",
                        "batch_per_gpu": B, "global_batch": B * world, "utterance_s": args.seconds,
-                       **({"mrf_staging": "lds-dma (A/B knob, not the default)"} if args.lds_dma else {}),
                        "parallelism": f"dp{world} (utterance sharding, RCCL broadcast of src/tgt se)"},
             "per_batch_latency_rtf": round(args.seconds / (ms * 1e-3), 2),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,

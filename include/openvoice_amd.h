@@ -75,11 +75,6 @@ enum {
  * >= L; columns >= L are never read as data and never written).  The forward-aligned even-K conv reads
  * L + (K-1)*dil input columns (x_ld must cover them) and writes L.  16-byte staging loads are used
  * when x, x_bstride and x_ld are 16-byte aligned -- L itself may be ragged. */
-/* ov_conv1d_params.loaders: stage the input tile with LDS-DMA (global_load_lds_dwordx4, no staging registers;
-   the leaky-ReLU prologue is applied by the matrix waves).  Needs 16-byte aligned rows, L % 4 == 0, odd K,
-   0 < in_slope <= 1, OV_EPI_LINEAR; otherwise OV_E_UNSUPPORTED. */
-#define OV_LOADERS_LDS_DMA (-1)
-
 typedef struct ov_conv1d_params {
   const float* x;        /* [B][>=Cin][L]; channel offset already applied to the pointer        */
   const float* w;        /* packed weights from ov_conv1d_pack_f32                              */
@@ -105,12 +100,12 @@ typedef struct ov_conv1d_params {
   int32_t K, dil;        /* taps, dilation; odd K: 'same' padding (K-1)*dil/2; even K: taps t .. t+(K-1)*dil,
                           * no left padding (the framing conv of the spectrogram)                   */
   int32_t epi, flags, split, phase_s;
-  int32_t tiles_per_wg;  /* 0 = persistent launch (one workgroup per resident slot, striding over the tiles);
-                          * n > 0 = ceil(tiles / n) workgroups (1: one tile each) -- tests / measurement     */
+  int32_t tiles_per_wg;  /* 0 = the dispatcher's launch rule (persistent -- one workgroup per resident slot, striding
+                          * over the tiles -- for large launches, else one tile per workgroup);
+                          * n > 0 = ceil(tiles / n) workgroups; n < 0 = persistent, forced -- tests / measurement */
   int32_t tile;          /* 0 = chosen by the dispatcher; else 1 + tile id (128x128, 64x256,
                           * 32x512, 32x256) -- tuning / measurement knob                         */
-  int32_t loaders;       /* loader waves per workgroup: 0 = chosen by the dispatcher, else 1/2/4, or
-                            OV_LOADERS_LDS_DMA = one loader wave staging with global_load_lds (MRF convs only) */
+  int32_t loaders;       /* loader waves per workgroup: 0 = chosen by the dispatcher, else 1/2/4            */
   int32_t chunk;         /* input channels per LDS fill: 0 = default (32 for 1x1, else 16), or 16/32 */
   float in_slope;        /* leaky-ReLU slope applied to x while staging (1.0f = identity)        */
   float scale;

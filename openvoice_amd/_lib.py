@@ -14,7 +14,6 @@ OV_OK = 0
 OV_ERRORS = {-1: "OV_E_BADARG", -2: "OV_E_UNSUPPORTED", -3: "OV_E_ALIGN", -4: "OV_E_LAUNCH"}
 
 EPI_LINEAR, EPI_GATE, EPI_RESSKIP, EPI_COUPLE, EPI_POSTERIOR, EPI_CONVT, EPI_MAGNITUDE = range(7)
-LOADERS_LDS_DMA = -1    # ov_conv1d_params.loaders: OV_LOADERS_LDS_DMA (include/openvoice_amd.h)
 F_MASK_V = 1
 F_OUT2_INIT = 2
 

@@ -182,30 +182,20 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
 #pragma unroll
             for (int r = 0; r < 16; ++r) (outb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff] = v[r] * scale;
           } else if constexpr (EPI == OV_EPI_RESSKIP) {
+            // h / skip are already inside the accumulators (conv_preload)
             if (mt * 32u < (uint32_t)p.split) {        // residual rows: h = (h + v) * mask, in place
-#pragma unroll
-              for (int r = 0; r < 16; ++r) v[r] += (outb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff];
 #pragma unroll
               for (int r = 0; r < 16; ++r) (outb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff] = v[r] * mk;
             } else {                                   // skip rows: accumulate (or initialise)
               float* o2 = p.out2 + (int64_t)b * p.out2_bstride;
               const uint32_t voff2 = voff - (uint32_t)p.split * LD;
-              if (!(p.flags & OV_F_OUT2_INIT)) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] += (o2 + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff2];
-              }
 #pragma unroll
               for (int r = 0; r < 16; ++r) (o2 + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff2] = v[r];
             }
-          } else {  // OV_EPI_COUPLE: out is x1, in place
-            f32x16 x1;
+          } else {  // OV_EPI_COUPLE: out is x1, in place; the accumulators hold m + x1 (forward) / m - x1 (reverse)
+            const float sg = scale > 0.f ? mk : -mk;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) x1[r] = (outb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float m = v[r] * mk;
-              (outb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff] = scale > 0.f ? m + x1[r] * mk : (x1[r] - m) * mk;
-            }
+            for (int r = 0; r < 16; ++r) (outb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff] = v[r] * sg;
           }
         }
       }
@@ -214,19 +204,84 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
 }
 
 // ---- accumulator initialisation -------------------------------------------------------------------
-// LINEAR with a residual (and the MRF running sum): the accumulators START as res (+ add) instead of
-// zero, so the epilogue has nothing to read.  The loads are issued at the top of the tile, where the
-// wave is about to wait an HBM round trip for the loaders' first chunk anyway; read in the epilogue
-// they cost one exposed round trip per 32x32 fragment with the matrix pipe idle (measured: +8...25 %
-// on the conv2 launches).  fp32 addition order changes (res first instead of last): ~1 ulp.
-// Returns true when res/add are now in `acc` (uniform across the workgroup).
+// The accumulators START at everything the epilogue would otherwise have to read back from memory and add:
+//   every kind      bias[row] (+ bias_b[b][row])
+//   LINEAR          + res (+ add)                 the ResBlock residual and the MRF running sum
+//   RESSKIP         + h (residual rows) / + skip (skip rows, unless OV_F_OUT2_INIT)
+//   COUPLE          + x1 (forward) / - x1 (reverse; the epilogue negates)
+// so that the epilogue only scales / masks and stores.  All of these loads -- 16 x WM x WN per lane -- are issued
+// back to back as ONE batch at the top of the tile, straight into the accumulator registers (no temporaries, no
+// branches: out-of-range columns and padding rows are clamped to a valid address and simply never stored), where
+// the wave is about to wait an HBM round trip for the loaders' first chunk anyway.  Round 1 issued them one 32x32
+// fragment at a time behind per-fragment branches: 4-8 serialised HBM round trips per tile, which is what made
+// every conv2 (residual) launch of the MRF 0.2 ms slower than its conv1 twin whatever the tap count.
+// fp32 addition order changes (operands first instead of last): ~1 ulp.
+// Returns true when the epilogue's operands are now in `acc` (uniform across the workgroup).
 template <int EPI, int WM, int WN>
 __device__ __forceinline__ bool conv_preload(const ov_conv1d_params& p, f32x16 (&acc)[WM][WN], int b, int tcol0,
                                              int mtile0, int lane) {
-  // Every epilogue wants v = acc + bias[row] (+ bias_b[b][row]): the accumulators start there, so the
-  // epilogue issues no bias loads (they used to cost one exposed L2 round trip per 32x32 fragment, ~1 us
-  // x WM*WN per tile with the matrix pipe idle).  Rows of padding tiles are left at zero and never stored.
   const uint32_t half = (uint32_t)lane >> 5;
+  const uint32_t L = (uint32_t)p.L, LD = (uint32_t)p.out_ld;
+  const uint32_t col0 = (uint32_t)tcol0 + ((uint32_t)lane & 31u);
+  constexpr bool kOperands = EPI == OV_EPI_LINEAR || EPI == OV_EPI_RESSKIP || EPI == OV_EPI_COUPLE;
+  bool preloaded = false;
+  if constexpr (kOperands) {
+    const float* src = nullptr;          // batch base of the tensor the accumulators start from
+    int64_t src_bs = 0;
+    if constexpr (EPI == OV_EPI_LINEAR) {
+      if (p.res && !(p.flags & OV_F_MASK_V)) { src = p.res; src_bs = p.res_bstride; }   // v*mask + res keeps the epilogue order
+    } else {
+      src = p.out; src_bs = p.out_bstride;
+    }
+    preloaded = src != nullptr;
+    if (preloaded) {
+      const uint32_t nfrag = (uint32_t)p.Cout / 32u;     // whole fragments of real rows (dispatcher: Cout % 32 == 0)
+      const float* srcb = src + (int64_t)b * src_bs;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const uint32_t mt = min((uint32_t)(mtile0 + i), nfrag - 1u);   // padding fragments read a real one, never stored
+        const float* rowb = srcb;
+        uint32_t mrow = mt * 32u;
+        bool zero = false;
+        if constexpr (EPI == OV_EPI_RESSKIP) {
+          if (mrow >= (uint32_t)p.split) {               // skip rows live in out2, first row = split
+            rowb = p.out2 + (int64_t)b * p.out2_bstride;
+            mrow -= (uint32_t)p.split;
+            zero = (p.flags & OV_F_OUT2_INIT) != 0;      // first layer: the accumulator is being initialised
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const uint32_t col = min(col0 + 32u * j, L - 1u);
+          const uint32_t voff = (mrow + 4u * half) * LD + col;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = (rowb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff];
+          if constexpr (EPI == OV_EPI_RESSKIP) {
+            if (zero) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+          }
+          if constexpr (EPI == OV_EPI_COUPLE) {
+            if (!(p.scale > 0.f)) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[i][j][r] = -acc[i][j][r];
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!preloaded) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+  // bias (+ per-utterance bias): L2-resident vectors, one value per accumulator row.  Rows of padding tiles get no
+  // bias and are never stored.
   {
     const float* __restrict__ bias = p.bias;
     const float* __restrict__ bias_b = p.bias_b ? p.bias_b + (int64_t)b * p.bias_b_bstride : nullptr;
@@ -236,45 +291,42 @@ __device__ __forceinline__ bool conv_preload(const ov_conv1d_params& p, f32x16 (
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       const uint32_t rbase = (uint32_t)(mtile0 + i) * 32u + 4u * half;
-      f32x16 bv;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) bv[r] = 0.f;
       if (EPI != OV_EPI_MAGNITUDE && (uint32_t)(mtile0 + i) * 32u < row_limit) {
+        f32x16 bv;
 #pragma unroll
         for (int r = 0; r < 16; ++r) bv[r] = bias[rbase + (r & 3) + 8 * (r >> 2)];
         if (bias_b) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) bv[r] += bias_b[rbase + (r & 3) + 8 * (r >> 2)];
         }
-      }
 #pragma unroll
-      for (int j = 0; j < WN; ++j) acc[i][j] = bv;
-    }
-  }
-  if constexpr (EPI != OV_EPI_LINEAR) return false;
-  if (!p.res || (p.flags & OV_F_MASK_V)) return false;   // v*mask + res keeps the epilogue order
-  const uint32_t L = (uint32_t)p.L, LD = (uint32_t)p.out_ld;
-  const float* resb = p.res + (int64_t)b * p.res_bstride;
-  const float* addb = p.add ? p.add + (int64_t)b * p.add_bstride : nullptr;
-  const uint32_t col0 = (uint32_t)tcol0 + ((uint32_t)lane & 31u);
-#pragma unroll
-  for (int i = 0; i < WM; ++i) {
-    const uint32_t mt = (uint32_t)(mtile0 + i);
-    if (mt * 32u >= (uint32_t)p.Cout) continue;
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      const uint32_t col = col0 + 32u * j;
-      if (col >= L) continue;
-      const uint32_t voff = (mt * 32u + 4u * half) * LD + col;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] += (resb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff];
-      if (addb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] += (addb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff];
+        for (int j = 0; j < WN; ++j) acc[i][j] += bv;
       }
     }
   }
-  return true;
+  if constexpr (EPI == OV_EPI_LINEAR) {
+    // second addend (the MRF running sum; 8 of the 72 MRF launches): one fragment's 16 loads at a time, so that
+    // the temporaries stay at 16 registers
+    if (preloaded && p.add) {
+      const uint32_t nfrag = (uint32_t)p.Cout / 32u;
+      const float* addb = p.add + (int64_t)b * p.add_bstride;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const uint32_t mt = min((uint32_t)(mtile0 + i), nfrag - 1u);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const uint32_t col = min(col0 + 32u * j, L - 1u);
+          const uint32_t voff = (mt * 32u + 4u * half) * LD + col;
+          f32x16 av;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) av[r] = (addb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff];
+          __builtin_amdgcn_sched_barrier(0);   // all 16 loads issued before the first add (hipcc otherwise pairs them off)
+          acc[i][j] += av;
+        }
+      }
+    }
+  }
+  return preloaded;
 }
 
 // K taps, dilation DIL; wave tile = (32*WM) x (32*WN); WVM x WVN matrix waves per workgroup;
@@ -286,15 +338,11 @@ __device__ __forceinline__ bool conv_preload(const ov_conv1d_params& p, f32x16 (
 // Staging kinds (template argument VEC): how the loader waves bring a chunk into LDS.
 constexpr int STAGE_SCALAR = 0;   // 4-byte loads through registers (rows not 16-byte aligned)
 constexpr int STAGE_VEC = 1;      // 16-byte loads through registers, leaky-ReLU applied on the way in
-constexpr int STAGE_DMA = 2;      // global_load_lds_dwordx4: global -> LDS without registers; leaky-ReLU is applied by
-                                  // the matrix waves to each B operand after its ds_read
 
 template <int K, int DIL, int WM, int WN, int WVM, int WVN, int CHUNK, int VEC, int EPI, int NLD>
 __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_CONVT_S8 || EPI == EPI_CONVT_S2) ? 4 : 1) void conv1d_mfma_kernel(const ov_conv1d_params p) {
   static_assert(WVM * WVN == 4, "4 matrix waves per workgroup");
-  static_assert(VEC == STAGE_SCALAR || VEC == STAGE_VEC || VEC == STAGE_DMA, "staging kind");
-  constexpr bool DMA = VEC == STAGE_DMA;
-  static_assert(!DMA || K % 2 == 1, "LDS-DMA staging: odd K only (whole 16-byte vectors are valid or not)");
+  static_assert(VEC == STAGE_SCALAR || VEC == STAGE_VEC, "staging kind");
   static_assert(CHUNK % UNIT == 0 && (CHUNK / UNIT == 2 || CHUNK / UNIT == 4), "chunk = 2 or 4 units");
   constexpr int UPC = CHUNK / UNIT;
   constexpr int N_BLK = 32 * WN * WVN;
@@ -306,9 +354,7 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
   constexpr int XS = N_BLK + PADA + (PADR + 3) / 4 * 4;  // LDS row stride (floats), multiple of 4
   constexpr int XS4 = XS / 4;
   constexpr int NITEM = VEC ? CHUNK * XS4 : CHUNK * XS;
-  // LDS-DMA writes whole wave-instructions (64 lanes x 16 bytes = 1 KiB): the buffer is rounded up to that
-  constexpr int NDMA = (CHUNK * XS4 + 63) / 64;
-  constexpr int BUF = DMA ? NDMA * 256 : CHUNK * XS;       // floats per LDS buffer
+  constexpr int BUF = CHUNK * XS;       // floats per LDS buffer
   // loads in flight per loader lane: the whole chunk in one batch when that needs <= LB_MAX of them
   constexpr int PER_LANE = (NITEM + 64 * NLD - 1) / (64 * NLD);
   constexpr int LB = PER_LANE < LB_MAX ? PER_LANE : LB_MAX;
@@ -352,30 +398,8 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
       const float* __restrict__ xb = p.x + (int64_t)(wid / (ntiles * mblocks)) * p.x_bstride;
       for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
         float* dst = xs + (it & 1) * BUF;
-        if constexpr (DMA) {
-          // The LDS image of a chunk is linear in 16-byte items (row * XS + 4 * c4 == 4 * idx), which is exactly
-          // what global_load_lds writes: wave-uniform base + lane * 16.  Per-lane SOURCE addresses do the tiling;
-          // items outside the tensor (halo beyond [0, L), channel rows >= Cin, the round-up of the last
-          // wave-instruction) read the all-zero record the weight packer leaves after the last real one.
-          // Requires L % 4 == 0 (a vector is wholly inside or outside a row) -- checked by the dispatcher.
-          const float* zsrc = p.w + (size_t)nunits * K * REC;
-#pragma unroll
-          for (int i = 0; i < (OV_EXP ? 0 : (NDMA + NLD - 1) / NLD); ++i) {
-            const int blk = i * NLD + (wave - 4);            // wave-uniform
-            if (blk < NDMA) {
-              const int idx = blk * 64 + lane;
-              const int row = idx / XS4, c4 = idx - row * XS4;
-              const int ci = chunk * CHUNK + row;
-              const int t = t0 - PADA + 4 * c4;
-              const bool ok = idx < NITEM && ci < Cin && t >= 0 && t < Lin;
-              const float* src = ok ? xb + ((uint32_t)ci * ldx + (uint32_t)t) : zsrc;
-              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                               (__attribute__((address_space(3))) void*)(dst + 4 * idx), 16, 0, 0);
-            }
-          }
-        }
 #pragma unroll 1   // one batch of LB loads per lane in flight at a time: bounds the loader's VGPRs
-        for (int bt = 0; bt < ((OV_EXP || DMA) ? 0 : NBATCH); ++bt) {
+        for (int bt = 0; bt < (OV_EXP ? 0 : NBATCH); ++bt) {
           if constexpr (VEC) {
             f32x4 stg[LB];
             int nval[LB];   // valid leading elements of each vector (0 = zero fill); a VGPR count,
@@ -466,23 +490,8 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
       // consumes it and the wave eats the LDS latency every k-step (-15...35 % on MI355X).
       constexpr int STEPS = UPC * 4 * K;
       float bcur[WN], bnxt[WN];
-      // LDS-DMA staging leaves the raw input in LDS: the leaky-ReLU prologue is applied here, to each B operand
-      // after its ds_read (max(v, slope * v) == lrelu(v) for 0 < slope <= 1, enforced by the dispatcher);
-      // two VALU ops per operand that issue under the MFMAs of the k-step in flight.
-      const float bslope = p.in_slope;
-      // (inline v_max_f32: through fmaxf / fmed3f hipcc adds a NaN-quieting v_max v, v, v per operand)
-      auto bact = [&](float v) {
-        if constexpr (DMA) {
-          float r;
-          const float t = v * bslope;
-          asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(t));
-          return r;
-        } else {
-          return v;
-        }
-      };
 #pragma unroll
-      for (int j = 0; j < WN; ++j) bcur[j] = bact(xl[32 * j]);   // k-step 0: unit 0, pair 0, tap 0
+      for (int j = 0; j < WN; ++j) bcur[j] = xl[32 * j];   // k-step 0: unit 0, pair 0, tap 0
 #pragma unroll
       for (int sa = 0; sa < STEPS; ++sa) {
         const int u = sa & 3;
@@ -503,17 +512,6 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
         for (int m = 0; m < WM * WN; ++m) {
           const int i = m / WN, j = m % WN;
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][u], bcur[j], acc[i][j], 0, 0, 0);
-          if constexpr (DMA) {
-            // activate the NEXT k-step's operands halfway through this k-step's MFMAs: their ds_read was issued
-            // >= 128 matrix cycles ago, and the two VALU ops per operand retire under the remaining MFMAs instead
-            // of sitting on the dependency path between two k-steps
-            if (m == (WM * WN) / 2 - 1 && sa + 1 < STEPS) {
-              __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-              for (int jj = 0; jj < WN; ++jj) bnxt[jj] = bact(bnxt[jj]);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (sa + 1 < STEPS) {
@@ -570,13 +568,15 @@ int conv1d_launch(const ov_conv1d_params* p, hipStream_t stream) {
   // (measured with the clocks ramped, profiles/r01_s39: conv2 launches 2-5 % faster non-persistent at C = 64 / 32,
   // +-1 % at C = 128; conv1 launches 0-4 % faster persistent).  Smaller launches (stage 0 of the generator: 6.75
   // tiles per slot, the frame-rate layers) use one workgroup per tile and leave the balancing to the hardware
-  // dispatcher.  A positive tiles_per_wg forces ceil(total / tiles_per_wg) workgroups (tests, A/B measurements).
+  // dispatcher.  A positive tiles_per_wg forces ceil(total / tiles_per_wg) workgroups, a negative one the persistent
+  // launch (tests, A/B measurements).
   const long total = (long)ntiles * mblocks * p->B;
   auto kernel = conv1d_mfma_kernel<K, DIL, WM, WN, WVM, WVN, CHUNK, VEC, EPI, NLD>;
   static int slots = 0;   // per kernel instance (this function is instantiated once per variant)
   if (slots == 0) slots = query_resident_workgroups(reinterpret_cast<const void*>(kernel), 64 * (4 + NLD));
   const int tpw = p->tiles_per_wg > 0 ? p->tiles_per_wg : 1;
-  long nwg = (p->tiles_per_wg <= 0 && p->res == nullptr && total >= 16L * slots) ? (long)slots : (total + tpw - 1) / tpw;
+  const bool persistent = p->tiles_per_wg < 0 || (p->tiles_per_wg == 0 && p->res == nullptr && total >= 16L * slots);
+  long nwg = persistent ? (long)slots : (total + tpw - 1) / tpw;
   if (nwg > total) nwg = total;
   hipLaunchKernelGGL(kernel, dim3((unsigned)nwg), dim3(64 * (4 + NLD)), 0, stream, *p);
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
@@ -625,6 +625,5 @@ OV_DECLARE_VARIANTS(kVariantsD)
 OV_DECLARE_VARIANTS(kVariantsE)
 OV_DECLARE_VARIANTS(kVariantsS)
 OV_DECLARE_VARIANTS(kVariantsW)
-OV_DECLARE_VARIANTS(kVariantsG)
 
 }  // namespace ovk

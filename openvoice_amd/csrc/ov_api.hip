@@ -126,10 +126,9 @@ __global__ __launch_bounds__(256) void frame_hops_kernel(const float* __restrict
 }
 
 static conv_launch_fn find_variant(int K, int dil, int tile, int chunk, int vec, int epi, int nld) {
-  const ConvVariant* tabs[] = {kVariantsA, kVariantsB, kVariantsC, kVariantsD, kVariantsE, kVariantsS, kVariantsW,
-                               kVariantsG};
+  const ConvVariant* tabs[] = {kVariantsA, kVariantsB, kVariantsC, kVariantsD, kVariantsE, kVariantsS, kVariantsW};
   const int ns[] = {kVariantsACount, kVariantsBCount, kVariantsCCount, kVariantsDCount,
-                    kVariantsECount, kVariantsSCount, kVariantsWCount, kVariantsGCount};
+                    kVariantsECount, kVariantsSCount, kVariantsWCount};
   for (unsigned t = 0; t < sizeof(ns) / sizeof(ns[0]); ++t)
     for (int i = 0; i < ns[t]; ++i) {
       const ConvVariant& v = tabs[t][i];
@@ -227,7 +226,7 @@ int ov_conv1d_f32(const ov_conv1d_params* pin, ov_stream_t stream) {
   if ((reinterpret_cast<uintptr_t>(p->w) & 15)) return OV_E_ALIGN;
   if (p->chunk != 0 && p->chunk != 16 && p->chunk != 32) return OV_E_BADARG;
   if (p->tile < 0 || p->tile > 4 ||
-      (p->loaders != 0 && p->loaders != 1 && p->loaders != 2 && p->loaders != 4 && p->loaders != OV_LOADERS_LDS_DMA))
+      (p->loaders != 0 && p->loaders != 1 && p->loaders != 2 && p->loaders != 4))
     return OV_E_BADARG;
   int tile = TILE_128x128;
   if (p->tile > 0) tile = p->tile - 1;
@@ -236,18 +235,6 @@ int ov_conv1d_f32(const ov_conv1d_params* pin, ov_stream_t stream) {
   const bool can_vec = (p->x_ld % 4 == 0) && !(reinterpret_cast<uintptr_t>(p->x) & 15) && (p->x_bstride % 4 == 0);
   int pref[3];
   conv_launch_fn fn = nullptr;
-  if (p->loaders == OV_LOADERS_LDS_DMA) {
-    // LDS-DMA staging (conv1d_inst_g.hip): whole 16-byte vectors are copied global -> LDS, so rows must be 16-byte
-    // aligned AND L a multiple of 4; the activation moves to the matrix waves as max(v, slope * v), which is the
-    // leaky ReLU only for 0 < slope <= 1.  Exact match or OV_E_UNSUPPORTED -- never a silent fallback.
-    if (!can_vec || p->L % 4 != 0 || p->K % 2 == 0 || !(p->in_slope > 0.f && p->in_slope <= 1.f) || epi != OV_EPI_LINEAR)
-      return OV_E_UNSUPPORTED;
-    int dtile = p->tile > 0 ? tile : (p->M <= 32 ? (int)TILE_32x256 : (p->M <= 64 ? (int)TILE_64x256 : (int)TILE_128x128));
-    const int dchunk = p->chunk ? p->chunk : (dtile == TILE_128x128 ? 32 : 16);
-    fn = find_variant(p->K, p->dil, dtile, dchunk, STAGE_DMA, epi, 1);
-    if (!fn) return OV_E_UNSUPPORTED;
-    return fn(p, static_cast<hipStream_t>(stream));
-  }
   // ConvTranspose: phase counts 8 and 2 have their own instances (compile-time store pattern)
   const int kernel_epi = epi != OV_EPI_CONVT ? epi : (p->phase_s == 8 ? EPI_CONVT_S8 : (p->phase_s == 2 ? EPI_CONVT_S2 : epi));
   // forced tile / loader count / chunk: exact match or OV_E_UNSUPPORTED (measurement knobs must not silently

@@ -223,9 +223,6 @@ class ConverterEngine:
         # ~1e-2 of the fp32 path instead of ~1e-5).  Built lazily by use_bf16_generator().
         self._state_dict_for_bf16 = sd
         self.generator_bf16 = None
-        # loader kind of the MRF (ResBlock) convs: 0 = the dispatcher's choice, _lib.LOADERS_LDS_DMA = the LDS-DMA
-        # staging variant (A/B knob until that variant has been measured, see tests/pending_gpu_lds_dma.py)
-        self.mrf_loaders = 0
 
     # ---- launch helpers --------------------------------------------------------------------------
     def _stream(self):
@@ -418,12 +415,12 @@ class ConverterEngine:
             for j, pairs in enumerate(self.resblocks[i]):
                 cur = u
                 for n, (c1, c2) in enumerate(pairs):
-                    self._conv(c1, cur, 0, bs, t1, 0, bs, B, L, in_slope=LRELU_SLOPE, loaders=self.mrf_loaders, tag="mrf")
+                    self._conv(c1, cur, 0, bs, t1, 0, bs, B, L, in_slope=LRELU_SLOPE, tag="mrf")
                     last = n == len(pairs) - 1
                     dst = acc if last else ra
                     self._conv(c2, t1, 0, bs, dst, 0, bs, B, L, in_slope=LRELU_SLOPE, res=cur, res_bs=bs,
                                add=acc if (last and j > 0) else None, add_bs=bs,
-                               scale=1.0 / nk if (last and j == nk - 1) else 1.0, loaders=self.mrf_loaders, tag="mrf")
+                               scale=1.0 / nk if (last and j == nk - 1) else 1.0, tag="mrf")
                     cur = dst
             free += [u, t1, ra]
             x = acc

@@ -4,6 +4,7 @@
 
     python tools/bench_convs.py [--tpw 0 2] [--loaders 0 1 2 4] [--tiles 0 3 4] [--reps 5]
 
+--tpw: 0 = the dispatcher's launch rule, n > 0 = n tiles per workgroup, -1 = force the persistent launch.
 tile ids: 0 = dispatcher's choice, 1..4 = 128x128, 64x256, 32x512, 32x256; a (tile, loaders)
 combination that is not instantiated for a shape is skipped.
 """
@@ -51,8 +52,9 @@ def main():
     ap.add_argument("--warm-ms", type=float, default=100.0, help="GPU-busy time before each timed region")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--kernels", type=int, nargs="+", default=[3, 7, 11])
-    ap.add_argument("--modes", nargs="+", default=["plain1", "plain5", "res+add"],
-                    help="plain1 / plain5 = conv1 with dilation 1 / 5, res+add = conv2 with residual and MRF sum")
+    ap.add_argument("--modes", nargs="+", default=["plain1", "plain5", "res", "res+add"],
+                    help="plain1 / plain5 = conv1 with dilation 1 / 5, res = conv2 with the residual (16 of the 18 conv2 "
+                         "launches of a stage), res+add = conv2 with residual and MRF running sum (the other 2)")
     ap.add_argument("--wn", action="store_true", help="also time the WaveNet k5 gate conv and the 1x1 res/skip conv")
     args = ap.parse_args()
     dev = "cuda:0"
@@ -69,7 +71,7 @@ def main():
         add = torch.randn(B, c, L, device=dev)
         out = torch.empty(B, c, L, device=dev)
         for k in args.kernels:
-            for d, mode in ((1, "plain"), (5, "plain"), (1, "res+add")):
+            for d, mode in ((1, "plain"), (5, "plain"), (1, "res"), (1, "res+add")):
                 if (mode + str(d) if mode == "plain" else mode) not in args.modes:
                     continue
                 w = torch.randn(c, c, k) * (c * k) ** -0.5
@@ -77,7 +79,9 @@ def main():
                 import itertools
                 for tile, nld, tpw, chunk in itertools.product(args.tiles, args.loaders, args.tpw, args.chunks):
                     kw = dict(in_slope=0.1, tiles_per_wg=tpw, tile=tile, loaders=nld, chunk=chunk)
-                    if mode != "plain":
+                    if mode == "res":
+                        kw.update(res=res, res_bs=c * L)
+                    elif mode == "res+add":
                         kw.update(res=res, res_bs=c * L, add=add, add_bs=c * L, scale=1.0 / 3.0)
                     try:
                         ms = timed(lambda: launch_conv(layer, x, 0, c * L, out, 0, c * L, B, L, **kw), args.reps,

@@ -31,7 +31,7 @@ def family(name):
         return name.split("(")[0][-60:]
     k, d, wm, wn, wvm, wvn, chunk, stage, epi, nld = (int(x) if x.isdigit() else x for x in m.groups())
     tile = f"{32 * wm * wvm}x{32 * wn * wvn}"
-    return f"conv k={k} {EPI.get(epi, epi)} tile {tile} chunk {chunk} nld {nld}" + (" lds-dma" if stage == 2 else "")
+    return f"conv k={k} {EPI.get(epi, epi)} tile {tile} chunk {chunk} nld {nld}"
 
 
 def main():
