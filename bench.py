@@ -45,14 +45,22 @@ def mrf_alg_bytes_per_launch(cfg, B, frames):
 
 
 def pmc_traffic():
-    """HBM bytes per MRF launch measured with rocprofv3 PMC counters in a separate run of this same
-    command (scripts/gpu_session.sh, tools/pmc_traffic.py); None when no summary is committed."""
+    """HBM bytes per MRF launch measured with rocprofv3 PMC counters in a separate run of this same command
+    (scripts/gpu_session.sh, tools/pmc_traffic.py).  Reported only when the record was taken from the SAME kernel
+    sources and launch sequence as the running tree (``kernel_source_digest``); otherwise None plus the reason --
+    a stale figure is not a measurement of this code."""
+    from openvoice_amd.hostinfo import kernel_source_digest
     try:
         with open(PMC_TRAFFIC_FILE) as fh:
             rec = json.load(fh)
-        return rec.get("calibrated", rec["nominal"])["bytes_per_launch"], rec
+        have, want = rec.get("kernel_source_digest"), kernel_source_digest()
+        if have != want:
+            return None, f"profiles/pmc_traffic_latest.json was measured on kernel sources {have}, this tree is {want}"
+        return rec.get("calibrated", rec["nominal"])["bytes_per_launch"], f"PMC passes of kernel sources {have}"
     except (OSError, KeyError, ValueError):
-        return None, None
+        return None, "no PMC record committed"
+
+
 SAMPLE_RATE = 22050
 
 
@@ -69,37 +77,91 @@ def synth_wave(batch, samples, seed, device):
     return wave.to(device)
 
 
-def cpu_baseline(sd, cfg, seconds, budget_s=20.0):
-    """The oracle (CPU restatement of the reference path, 'port') on this box's host cores:
-    B = 1 utterances of the same length, repeated until ~budget_s of CPU work."""
+def _reference_model(sd, cfg):
+    """The UNMODIFIED reference ``SynthesizerTrn`` (weight-norm left in place, re-evaluated every forward, as the
+    reference runs it: openvoice/models.py:492-499) with our synthetic weights -- only where /root/reference exists
+    (the build container; the GPU box has no copy).  Returns None when it cannot be imported."""
+    try:
+        from oracle.make_golden import REFERENCE, import_reference
+        if not os.path.isdir(REFERENCE):
+            return None
+        import warnings
+        warnings.filterwarnings("ignore")
+        ref_models, ref_spectrogram = import_reference()
+        model = ref_models.SynthesizerTrn(0, 513, n_speakers=0, **cfg).eval()
+        model.load_state_dict(sd, strict=True)
+        model.zero_g = True
+        return model, ref_spectrogram
+    except Exception:   # noqa: BLE001 -- any import problem means "not available here"
+        return None
+
+
+def cpu_baseline(sd, cfg, seconds, budget_s=20.0, want_reference=True):
+    """CPU fp32 baseline on this box's host cores: the unmodified
+    reference (``kind = "reference"``) where /root/reference is importable, else the oracle -- the CPU restatement
+    of the same path in the same torch operators (``kind = "port"``; pinned to reference outputs by
+    tests/test_oracle_golden.py).  Bounded sample: B = 1 utterances on all usable threads for ~budget_s (the
+    headline ``value``), then one B = 1 run on ONE thread and one B = 32 run on all threads."""
     from oracle import vc_oracle
-    from openvoice_amd.hostinfo import usable_cpus
+    from openvoice_amd.hostinfo import cpu_model, usable_cpus
     cores = usable_cpus(32)
-    torch.set_num_threads(cores)
     samples = int(seconds * SAMPLE_RATE)
-    wave = synth_wave(1, samples, 7, "cpu")
     gen = torch.Generator().manual_seed(8)
     g_src, g_tgt = 0.1 * torch.randn(1, 256, 1, generator=gen), 0.1 * torch.randn(1, 256, 1, generator=gen)
+    ref = _reference_model(sd, cfg) if want_reference else None
+    kind = "reference" if ref is not None else "port"
 
-    def one():
+    def convert(wave):
         with torch.no_grad():
+            if ref is not None:
+                model, ref_spectrogram = ref
+                spec = ref_spectrogram(wave, 1024, SAMPLE_RATE, 256, 1024, center=False)
+                lengths = torch.full((wave.shape[0],), spec.shape[2], dtype=torch.int64)
+                return model.voice_conversion(spec, lengths, g_src, g_tgt, tau=0.3)[0]
             spec = vc_oracle.spectrogram(wave)
-            noise = torch.randn(1, cfg["inter_channels"], spec.shape[2], generator=gen)
-            lengths = torch.tensor([spec.shape[2]])
+            noise = torch.randn(wave.shape[0], cfg["inter_channels"], spec.shape[2], generator=gen)
+            lengths = torch.full((wave.shape[0],), spec.shape[2], dtype=torch.int64)
             return vc_oracle.voice_conversion(sd, cfg, spec, lengths, g_src, g_tgt, 0.3, noise, zero_g=True)[0]
 
-    one()  # warm-up (also folds nothing: the oracle re-folds weight-norm per call like the reference)
+    wave1 = synth_wave(1, samples, 7, "cpu")
+    torch.set_num_threads(cores)
+    convert(wave1)   # warm-up (weight-norm is re-evaluated per call by both the reference and the port)
     n, t0 = 0, time.perf_counter()
     while True:
-        one()
+        convert(wave1)
         n += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or n >= 16:
+        if el >= budget_s * 0.45 or n >= 16:
             break
-    return dict(value=round(n * seconds / el, 3), unit="x real-time (audio s / wall s)", cores=cores, kind="port",
-                utterances_per_s=round(n / el, 4),
-                sample=f"{n} x (B=1, {seconds:g} s utterance) oracle voice_conversion incl. spectrogram, "
-                       f"torch CPU fp32, {cores} threads, {el:.1f} s wall")
+    out = dict(value=round(n * seconds / el, 3), unit="x real-time (audio s / wall s)", cores=cores, kind=kind,
+               cpu_model=cpu_model(), utterances_per_s=round(n / el, 4))
+    sample = [f"{n} x (B=1, {seconds:g} s) on {cores} threads, {el:.1f} s wall"]
+    # one thread, B = 1
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    convert(wave1)
+    el1 = time.perf_counter() - t0
+    out["one_thread"] = dict(value=round(seconds / el1, 3), utterances_per_s=round(1.0 / el1, 4), cores=1)
+    sample.append(f"1 x (B=1) on 1 thread, {el1:.1f} s")
+    # the benchmark batch, B = 32 (skipped when the B = 1 rate says it would blow the budget)
+    torch.set_num_threads(cores)
+    est32 = 32.0 * el / n
+    if est32 <= max(30.0, 2.0 * budget_s):
+        wave32 = synth_wave(32, samples, 9, "cpu")
+        t0 = time.perf_counter()
+        convert(wave32)
+        el32 = time.perf_counter() - t0
+        out["batch32"] = dict(value=round(32 * seconds / el32, 3), utterances_per_s=round(32.0 / el32, 4), cores=cores)
+        sample.append(f"1 x (B=32) on {cores} threads, {el32:.1f} s")
+    else:
+        out["batch32"] = None
+        sample.append(f"B=32 skipped (estimated {est32:.0f} s)")
+    what = ("UNMODIFIED reference SynthesizerTrn.voice_conversion + spectrogram_torch imported from /root/reference"
+            if kind == "reference" else
+            "oracle voice_conversion (CPU restatement of the reference in the same torch ops; /root/reference is not "
+            "on this box)")
+    out["sample"] = f"{what}, torch CPU fp32, weight-norm re-evaluated per call: " + "; ".join(sample)
+    return out
 
 
 def main():
@@ -228,7 +290,7 @@ def main():
     else:
         n_mrf, f_mrf, t_mrf = by_tag["mrf"]
     achieved = f_mrf / t_mrf / 1e12
-    traffic, traffic_rec = pmc_traffic()
+    traffic, traffic_note = pmc_traffic()
     alg_bytes = mrf_alg_bytes_per_launch(cfg, B, frames)
     all_flops = sum(r[1] for r in by_tag.values())
     all_conv_s = sum(r[2] for r in by_tag.values())
@@ -261,6 +323,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "HBM bytes per MRF launch (rocprofv3 PMC, profiles/pmc_traffic_latest.json)",
+                         "traffic_source": traffic_note,
                          "alg_bytes_per_launch": round(alg_bytes),
                          "kernel": "ovk::conv1d_mfma_kernel on the MRF ResBlock convs",
                          "launches_per_step": n_mrf, "avg_launch_ms": round(t_mrf / n_mrf * 1e3, 4),

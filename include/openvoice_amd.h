@@ -54,9 +54,14 @@ enum {
    * m = tile 2q, logs = tile 2q+1): out = (m*mask + res*scale*exp(logs*mask))*mask,
    * res = noise, scale = tau                                                                   */
   OV_EPI_POSTERIOR = 4,
-  /* ConvTranspose1d written as a 3-tap conv over stride-many output phases, reference
-   * openvoice/models.py:279 (weights packed with row = cout*phase_s + phase):
-   * out[b][cout][phase_s*t + phase] = v                                                        */
+  /* ConvTranspose1d (k = 2*phase_s, padding phase_s/2) written as a 3-tap conv over stride-many output phases,
+   * reference openvoice/models.py:279 (weights packed with row = cout*phase_s + phase):
+   * out[b][cout][phase_s*t + phase] = v.
+   * Every phase has exactly two non-zero taps: x[t-1], x[t] for phase < phase_s/2 and x[t], x[t+1] above.  With
+   * OV_F_CONVT_GROUPED (phase_s 8 or 2 only) the rows are packed by phase group instead -- 32-row tile 2q = the
+   * phases < phase_s/2, tile 2q+1 the phases >= phase_s/2 of the same output channels (phase_s 8: row-in-tile =
+   * 4*(cout % 8) + phase % 4 for channels 8q..8q+7; phase_s 2: row-in-tile = cout % 32 for channels 32q..32q+31)
+   * -- and the kernel skips the all-zero tap of each tile: 2/3 of the matrix work.                          */
   OV_EPI_CONVT = 5,
   /* Spectrogram magnitude, reference openvoice/mel_processing.py:61-74: rows paired like OV_EPI_GATE
    * (tile 2q = real parts of bins 32q.., tile 2q+1 = imaginary parts): out[b][f][t] = sqrt(re^2 + im^2 + scale)
@@ -66,7 +71,8 @@ enum {
 
 enum {
   OV_F_MASK_V = 1,    /* LINEAR: multiply v by mask[b][t] before the residual add */
-  OV_F_OUT2_INIT = 2  /* RESSKIP: out2 = v instead of out2 += v (first WaveNet layer) */
+  OV_F_OUT2_INIT = 2, /* RESSKIP: out2 = v instead of out2 += v (first WaveNet layer) */
+  OV_F_CONVT_GROUPED = 4 /* CONVT, phase_s 8 / 2: rows packed by phase group (see OV_EPI_CONVT); M % 64 == 0 */
 };
 
 /* One Conv1d launch.  Input length == output length L ('same' padding, stride 1), as every conv

@@ -16,6 +16,7 @@ OV_ERRORS = {-1: "OV_E_BADARG", -2: "OV_E_UNSUPPORTED", -3: "OV_E_ALIGN", -4: "O
 EPI_LINEAR, EPI_GATE, EPI_RESSKIP, EPI_COUPLE, EPI_POSTERIOR, EPI_CONVT, EPI_MAGNITUDE = range(7)
 F_MASK_V = 1
 F_OUT2_INIT = 2
+F_CONVT_GROUPED = 4
 
 _fp = ctypes.c_void_p
 _i = ctypes.c_int

@@ -75,7 +75,41 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
   float* outb = p.out + (int64_t)b * p.out_bstride;   // bias (+ bias_b) is already in acc: see conv_preload
   const uint32_t col0 = (uint32_t)tcol0 + ((uint32_t)lane & 31u);
 
-  if constexpr (EPI == OV_EPI_MAGNITUDE) {
+  if constexpr (EPI == EPI_CONVT_S8 || EPI == EPI_CONVT_S2) {
+    // Grouped row order (OV_F_CONVT_GROUPED, engine.convt_row_order): packed tile 2q holds the output phases
+    // p < s/2 (taps x[t-1], x[t]), tile 2q+1 the phases p >= s/2 (taps x[t], x[t+1]) of the same output channels --
+    // 8 channels x 4 phases per tile for s = 8, 32 channels x 1 phase for s = 2 -- so that the all-zero third tap
+    // of each tile is skipped in the main loop.  q = pair index (mtile0 / 2).
+    static_assert(WM == 2, "grouped ConvTranspose pairs two 32-row tiles per wave");
+    const uint32_t Lout = LD;   // row stride of the upsampled output (>= L * s)
+    if ((uint32_t)q * 64u >= Cout * (uint32_t)p.phase_s) return;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const uint32_t col = col0 + 32u * j;
+      if (col >= L) continue;
+      if constexpr (EPI == EPI_CONVT_S8) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const f32x16 v = acc[i][j];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {       // channel 8q + 2c + half, phases 4i .. 4i+3: 16 contiguous bytes
+            f32x4 o = {v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
+            *reinterpret_cast<f32x4*>(outb + (size_t)((uint32_t)q * 8u + 2u * c + half) * Lout +
+                                      (8u * col + 4u * i)) = o;
+          }
+        }
+      } else {
+        const f32x16 v0 = acc[0][j], v1 = acc[1][j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {        // channel 32q + row-in-tile, phases 0 and 1: 8 contiguous bytes
+          const uint32_t co = (uint32_t)q * 32u + 4u * half + (r & 3) + 8 * (r >> 2);
+          f32x2 o = {v0[r], v1[r]};
+          *reinterpret_cast<f32x2*>(outb + (co * Lout + 2u * col)) = o;
+        }
+      }
+    }
+    return;
+  } else if constexpr (EPI == OV_EPI_MAGNITUDE) {
     static_assert(WM == 2, "magnitude pairs two 32-row tiles per wave");
     // q = pair index: packed tile 2q holds the real parts of output rows 32q.., tile 2q+1 the imaginary parts
     if ((uint32_t)q * 32u >= Cout) return;
@@ -140,21 +174,7 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
         if constexpr (is_convt(EPI)) {
           const uint32_t s = (uint32_t)p.phase_s;
           const uint32_t Lout = LD;   // row stride of the upsampled output (>= L * s)
-          if constexpr (EPI == EPI_CONVT_S8) {   // row = co*8 + phase: r&3 walks 4 consecutive output samples
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              f32x4 o = {v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
-              *reinterpret_cast<f32x4*>(outb + (size_t)(mt * 4u + c) * Lout + (8u * col + 4u * half)) = o;
-            }
-          } else if constexpr (EPI == EPI_CONVT_S2) {   // row = co*2 + phase
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-              const int r = 2 * jj;
-              const uint32_t co = (rbase + (r & 3) + 8 * (r >> 2)) >> 1;
-              f32x2 o = {v[r], v[r + 1]};
-              *reinterpret_cast<f32x2*>(outb + (co * Lout + 2u * col)) = o;
-            }
-          } else {
+          {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const uint32_t row = rbase + (r & 3) + 8 * (r >> 2);
@@ -508,9 +528,12 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
         }
         // Pin the prefetches here: without this hipcc sinks the loads next to their first use.
         __builtin_amdgcn_sched_barrier(0);
+        // tap of THIS k-step; grouped ConvTranspose: tile parity = phase group, whose third tap is all zeros
+        const int tap_now = (sa % (4 * K)) % K;
 #pragma unroll
         for (int m = 0; m < WM * WN; ++m) {
           const int i = m / WN, j = m % WN;
+          if ((EPI == EPI_CONVT_S8 || EPI == EPI_CONVT_S2) && tap_now == ((i & 1) ? 0 : K - 1)) continue;
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][u], bcur[j], acc[i][j], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);

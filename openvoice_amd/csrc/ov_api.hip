@@ -218,8 +218,8 @@ int ov_conv1d_f32(const ov_conv1d_params* pin, ov_stream_t stream) {
   if (p->x_ld < lin || p->out_ld < lout || (p->mask && p->mask_bstride < p->L)) return OV_E_BADARG;
   // per-utterance offsets are 32-bit inside the kernels
   if ((int64_t)p->Cin * p->x_ld > UINT32_MAX || (int64_t)(p->M + 32) * p->out_ld > UINT32_MAX) return OV_E_BADARG;
-  if (epi == OV_EPI_CONVT) {
-    const int need = p->phase_s == 8 ? 4 : (p->phase_s == 2 ? 2 : 1);   // 16- / 8-byte interleaving stores
+  if (epi == OV_EPI_CONVT && (p->flags & OV_F_CONVT_GROUPED)) {
+    const int need = p->phase_s == 8 ? 4 : 2;   // 16- / 8-byte interleaving stores
     if ((reinterpret_cast<uintptr_t>(p->out) & (4 * need - 1)) || (p->out_bstride % need) || (p->out_ld % need))
       return OV_E_ALIGN;
   }
@@ -236,7 +236,10 @@ int ov_conv1d_f32(const ov_conv1d_params* pin, ov_stream_t stream) {
   int pref[3];
   conv_launch_fn fn = nullptr;
   // ConvTranspose: phase counts 8 and 2 have their own instances (compile-time store pattern)
-  const int kernel_epi = epi != OV_EPI_CONVT ? epi : (p->phase_s == 8 ? EPI_CONVT_S8 : (p->phase_s == 2 ? EPI_CONVT_S2 : epi));
+  // (grouped row order only: those instances skip the all-zero tap of each phase group and store 16 / 8 bytes)
+  const bool grouped = epi == OV_EPI_CONVT && (p->flags & OV_F_CONVT_GROUPED);
+  if (grouped && ((p->phase_s != 8 && p->phase_s != 2) || p->M % 64 != 0 || p->K != 3)) return OV_E_BADARG;
+  const int kernel_epi = !grouped ? epi : (p->phase_s == 8 ? EPI_CONVT_S8 : EPI_CONVT_S2);
   // forced tile / loader count / chunk: exact match or OV_E_UNSUPPORTED (measurement knobs must not silently
   // fall back); otherwise the preferred tile, then 128x128, 16-byte staging before 4-byte.
   const int tiles_try[2] = {tile, p->tile > 0 ? tile : (int)TILE_128x128};

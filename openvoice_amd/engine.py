@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from ._lib import (ConvParams, EPI_CONVT, EPI_COUPLE, EPI_GATE, EPI_LINEAR, EPI_POSTERIOR, EPI_RESSKIP,
-                   F_MASK_V, F_OUT2_INIT)
+                   F_CONVT_GROUPED, F_MASK_V, F_OUT2_INIT)
 from .params import ENC_Q_LAYERS, FLOW_LAYERS, N_FLOWS, REF_ENC_FILTERS, REF_ENC_GRU, effective_weight
 
 LRELU_SLOPE = 0.1       # reference: openvoice/modules.py:14
@@ -84,6 +84,28 @@ def conv_transpose_as_conv(w, stride):
         else:
             wc[rows, :, 2] = w[:, :, p + pad - s].t()         # x[q+1]
     return wc
+
+
+def convt_row_order(cout, stride):
+    """Packed row order of the grouped ConvTranspose kernels (``F_CONVT_GROUPED``, include/openvoice_amd.h
+    OV_EPI_CONVT): natural row ``cout*stride + phase`` of ``conv_transpose_as_conv`` -> 32-row tiles that hold ONE
+    phase group each -- tile 2q the phases < stride/2 (their tap x[t+1] is all zeros), tile 2q+1 the phases >=
+    stride/2 (tap x[t-1] all zeros) of the same output channels -- so the kernel skips a third of the matrix
+    work.  Returns None when the shape cannot be grouped (the natural order + generic kernel are used then)."""
+    s = stride
+    if s == 8 and cout % 8 == 0:
+        per_tile = 8          # channels per tile pair; row-in-tile = 4 * (cout % 8) + phase % 4
+    elif s == 2 and cout % 32 == 0:
+        per_tile = 32         # row-in-tile = cout % 32
+    else:
+        return None
+    idx = []
+    for q in range(cout // per_tile):
+        for grp in range(2):
+            for c in range(per_tile):
+                for ph in range(s // 2):
+                    idx.append((q * per_tile + c) * s + grp * (s // 2) + ph)
+    return torch.tensor(idx, dtype=torch.long)
 
 
 def launch_conv(layer, x, x_off, x_bs, out, out_off, out_bs, B, L, epi=EPI_LINEAR, flags=0, in_slope=1.0,
@@ -185,7 +207,11 @@ class ConverterEngine:
             w = effective_weight(sd, f"dec.ups.{i}")
             wc = conv_transpose_as_conv(w, u)
             bias = sd[f"dec.ups.{i}.bias"].repeat_interleave(u)
-            self.ups.append(dict(conv=PackedConv(wc, bias, dev, K=3, cout=ch // 2), stride=u))
+            order = convt_row_order(ch // 2, u)
+            if order is not None:
+                wc, bias = wc[order], bias[order]
+            self.ups.append(dict(conv=PackedConv(wc, bias, dev, K=3, cout=ch // 2), stride=u,
+                                 flags=F_CONVT_GROUPED if order is not None else 0))
             ch //= 2
             stage = []
             for j, (rk, rd) in enumerate(zip(kernels, dils)):
@@ -404,7 +430,7 @@ class ConverterEngine:
             u = free.pop()
             # leaky_relu(0.1) + ConvTranspose1d (models.py:278-279)
             self._conv(up["conv"], x, 0, cin * x_ld, u, 0, ch * L * s, B, L, epi=EPI_CONVT, in_slope=LRELU_SLOPE,
-                       phase_s=s, x_ld=x_ld, tag="ups", alg_flops=2.0 * cin * ch * 2 * s * L * B)
+                       flags=up["flags"], phase_s=s, x_ld=x_ld, tag="ups", alg_flops=2.0 * cin * ch * 2 * s * L * B)
             if i > 0:
                 free.append(x)
             L *= s

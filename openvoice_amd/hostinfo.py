@@ -27,3 +27,32 @@ def usable_cpus(cap=None):
     if cap:
         n = min(n, cap)
     return max(1, n)
+
+
+def cpu_model():
+    """Model name of the host CPU (``/proc/cpuinfo``), for the CPU-baseline line of bench.py."""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def kernel_source_digest():
+    """sha256 (16 hex digits) over the kernel sources, the C ABI header and the launch sequence -- what decides the
+    HBM traffic of a conversion.  Measurement records (profiles/pmc_traffic_latest.json) carry it, and bench.py only
+    reports a PMC traffic figure whose digest equals the running tree's."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h")) +
+                   glob.glob(os.path.join(here, "..", "include", "*.h")) + [os.path.join(here, "engine.py")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

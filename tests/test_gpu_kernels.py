@@ -13,10 +13,10 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from openvoice_amd import _lib  # noqa: E402
-from openvoice_amd.engine import (PackedConv, conv_transpose_as_conv, gate_row_order, launch_conv,  # noqa: E402
+from openvoice_amd.engine import (PackedConv, conv_transpose_as_conv, convt_row_order, gate_row_order, launch_conv,  # noqa: E402
                                   _ptr)
 from openvoice_amd._lib import (EPI_CONVT, EPI_COUPLE, EPI_GATE, EPI_POSTERIOR, EPI_RESSKIP,  # noqa: E402
-                                F_MASK_V, F_OUT2_INIT)
+                                F_CONVT_GROUPED, F_MASK_V, F_OUT2_INIT)
 
 DEV = "cuda:0"
 
@@ -199,10 +199,21 @@ def test_conv_transpose_as_phase_conv(cin, cout, s, L):
     w, b = _rand(cin, cout, k, seed=2, scale=(2 * cin) ** -0.5), _rand(cout, seed=3, scale=0.1)
     ref = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, stride=s, padding=(k - s) // 2)
     assert ref.shape[2] == s * L
-    layer = PackedConv(conv_transpose_as_conv(w, s), b.repeat_interleave(s), DEV, K=3, cout=cout)
+    wc, bc = conv_transpose_as_conv(w, s), b.repeat_interleave(s)
+    # natural row order (cout*s + phase): the generic kernel, all three taps
+    layer = PackedConv(wc, bc, DEV, K=3, cout=cout)
     out = torch.full((B, cout, s * L), float("nan"), device=DEV)
     launch_conv(layer, x.to(DEV), 0, cin * L, out, 0, cout * s * L, B, L, epi=EPI_CONVT, in_slope=0.1, phase_s=s)
     _close(out, ref, what=f"convT {cin}->{cout} s={s}")
+    # grouped row order (what the engine uses): the all-zero tap of each phase group is skipped
+    order = convt_row_order(cout, s)
+    assert order is not None
+    layer = PackedConv(wc[order], bc[order], DEV, K=3, cout=cout)
+    out2 = torch.full((B, cout, s * L), float("nan"), device=DEV)
+    launch_conv(layer, x.to(DEV), 0, cin * L, out2, 0, cout * s * L, B, L, epi=EPI_CONVT, in_slope=0.1, phase_s=s,
+                flags=F_CONVT_GROUPED)
+    _close(out2, ref, what=f"grouped convT {cin}->{cout} s={s}")
+    assert torch.equal(out, out2)    # skipping a zero tap changes no fmaf
 
 
 @pytest.mark.parametrize("L", [4352, 1001])
@@ -292,10 +303,11 @@ def test_conv_transpose_from_padded_rows(s, cin, cout, L):
     x = _rand(B, cin, L, seed=1)
     w, b = _rand(cin, cout, k, seed=2, scale=(2 * cin) ** -0.5), _rand(cout, seed=3, scale=0.1)
     ref = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, stride=s, padding=(k - s) // 2)
-    layer = PackedConv(conv_transpose_as_conv(w, s), b.repeat_interleave(s), DEV, K=3, cout=cout)
+    order = convt_row_order(cout, s)
+    layer = PackedConv(conv_transpose_as_conv(w, s)[order], b.repeat_interleave(s)[order], DEV, K=3, cout=cout)
     out = torch.full((B, cout, s * L), float("nan"), device=DEV)
     launch_conv(layer, _pad_rows(x, ld).to(DEV), 0, cin * ld, out, 0, cout * s * L, B, L, epi=EPI_CONVT,
-                in_slope=0.1, phase_s=s, x_ld=ld)
+                in_slope=0.1, phase_s=s, x_ld=ld, flags=F_CONVT_GROUPED)
     _close(out, ref, what=f"convT from padded rows s={s}")
 
 

@@ -3,7 +3,7 @@ HIP path relies on must be exact re-expressions of the reference ops."""
 import torch
 import torch.nn.functional as F
 
-from openvoice_amd.engine import conv_transpose_as_conv, gate_row_order, padded_frames
+from openvoice_amd.engine import conv_transpose_as_conv, convt_row_order, gate_row_order, padded_frames
 from openvoice_amd.params import effective_weight
 
 
@@ -24,6 +24,26 @@ def test_conv_transpose_equals_three_tap_phase_conv():
         wc = conv_transpose_as_conv(w, s).reshape(cout, s, cin, 3).transpose(0, 1).reshape(s * cout, cin, 3)
         y2 = F.conv1d(x, wc, b.repeat(s), padding=1).reshape(2, s, cout, 23).permute(0, 2, 3, 1).reshape(2, cout, 23 * s)
         assert torch.allclose(y2, ref, atol=1e-5)
+
+
+def test_convt_row_order_groups_phases_by_their_zero_tap():
+    """Grouped ConvTranspose rows (include/openvoice_amd.h OV_F_CONVT_GROUPED): a permutation of the natural
+    cout*s + phase rows in which every even 32-row tile has an all-zero tap 2 (x[t+1]) and every odd tile an
+    all-zero tap 0 (x[t-1]) -- the taps the kernel skips -- with the documented row-in-tile layout."""
+    for s, cin, cout in ((8, 6, 16), (2, 6, 64), (8, 512, 256), (2, 64, 32)):
+        w = _rand(cin, cout, 2 * s, seed=s)
+        wc = conv_transpose_as_conv(w, s)
+        order = convt_row_order(cout, s)
+        assert sorted(order.tolist()) == list(range(cout * s))
+        g = wc[order].reshape(-1, 32, cin, 3)
+        assert (g[0::2, :, :, 2] == 0).all() and (g[1::2, :, :, 0] == 0).all()
+        assert (g[0::2, :, :, 0] != 0).any() and (g[1::2, :, :, 2] != 0).any()
+        for t in range(g.shape[0]):
+            q, grp = divmod(t, 2)
+            for r in (0, 5, 31):
+                co, ph = ((8 * q + r // 4), 4 * grp + r % 4) if s == 8 else ((32 * q + r), grp)
+                assert order[32 * t + r] == co * s + ph
+    assert convt_row_order(12, 8) is None and convt_row_order(16, 2) is None and convt_row_order(32, 4) is None
 
 
 def test_gate_row_order_pairs_tanh_and_sigmoid_rows():

@@ -45,7 +45,10 @@ def main():
     fetch_dir, write_dir = sys.argv[1], sys.argv[2]
     f_mrf, f_cal = summarise(read(fetch_dir, "FETCH_SIZE"), 80000.0)     # raw FETCH_SIZE is half the bytes
     w_mrf, w_cal = summarise(read(write_dir, "WRITE_SIZE"), 100000.0)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from openvoice_amd.hostinfo import kernel_source_digest
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), counters in KiB",
+           "kernel_source_digest": kernel_source_digest(),
            "mrf_launches_fetch_pass": len(f_mrf), "mrf_launches_write_pass": len(w_mrf)}
     if f_mrf and w_mrf:
         fetch_kib = sum(f_mrf) / len(f_mrf)
