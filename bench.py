@@ -29,18 +29,21 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak 
 PMC_TRAFFIC_FILE = os.path.join(REPO, "profiles", "pmc_traffic_latest.json")
 
 
-def mrf_alg_bytes_per_launch(cfg, B, frames):
-    """Algorithmic HBM bytes of the average MRF launch: conv1 reads x and writes
-    t (2 tensor passes), conv2 reads t and the residual and writes (3), the last conv2 of ResBlocks 2
-    and 3 also reads the running MRF sum (+1 each); tensor = B * C * L * 4 bytes per stage."""
+def mrf_alg_bytes_per_launch(cfg, B, frames, fused=()):
+    """Algorithmic HBM bytes of the average MRF launch: per ResBlock pair as two launches conv1
+    reads x and writes t (2 tensor passes), conv2 reads t and the residual and writes (3); as ONE fused launch
+    (``fused`` = the (channels, kernel) set the engine fuses) x is read and the output written (2); the last pair of
+    ResBlocks 2 and 3 also reads the running MRF sum (+1 each); tensor = B * C * L * 4 bytes per stage."""
     ch, L, total, launches = cfg["upsample_initial_channel"], frames, 0.0, 0
-    nk, nd = len(cfg["resblock_kernel_sizes"]), len(cfg["resblock_dilation_sizes"][0])
+    kernels, nd = cfg["resblock_kernel_sizes"], len(cfg["resblock_dilation_sizes"][0])
     for u in cfg["upsample_rates"]:
         ch //= 2
         L *= u
-        passes = nk * nd * (2 + 3) + (nk - 1)
-        total += passes * 4.0 * B * ch * L
-        launches += nk * nd * 2
+        for j, k in enumerate(kernels):
+            one = (ch, k) in fused
+            passes = nd * (2 if one else 5) + (1 if j > 0 else 0)
+            total += passes * 4.0 * B * ch * L
+            launches += nd * (1 if one else 2)
     return total / launches
 
 
@@ -291,7 +294,9 @@ def main():
         n_mrf, f_mrf, t_mrf = by_tag["mrf"]
     achieved = f_mrf / t_mrf / 1e12
     traffic, traffic_note = pmc_traffic()
-    alg_bytes = mrf_alg_bytes_per_launch(cfg, B, frames)
+    from openvoice_amd.engine import PAIR_POLICY
+    fused_set = PAIR_POLICY if engine.fuse_pairs else ()
+    alg_bytes = mrf_alg_bytes_per_launch(cfg, B, frames, fused_set)
     all_flops = sum(r[1] for r in by_tag.values())
     all_conv_s = sum(r[2] for r in by_tag.values())
 
@@ -325,7 +330,9 @@ def main():
                          "traffic_unit": "HBM bytes per MRF launch (rocprofv3 PMC, profiles/pmc_traffic_latest.json)",
                          "traffic_source": traffic_note,
                          "alg_bytes_per_launch": round(alg_bytes),
-                         "kernel": "ovk::conv1d_mfma_kernel on the MRF ResBlock convs",
+                         "kernel": "ovk::conv1d_mfma_kernel (+ ovk::respair_mfma_kernel where a ResBlock pair is one "
+                                   "launch) on the MRF ResBlock convs",
+                         "fused_pairs": sorted(f"C={c} k={k}" for c, k in fused_set),
                          "launches_per_step": n_mrf, "avg_launch_ms": round(t_mrf / n_mrf * 1e3, 4),
                          "alg_gflop_per_launch": round(f_mrf / n_mrf / 1e9, 2),
                          "all_conv_alg_tflop_per_step": round(all_flops / 1e12, 3),

@@ -136,6 +136,37 @@ int ov_conv1d_pack_f32(const float* w, int Cout, int Cin, int K, float* dst);
  * :273-286 (generator conv_pre, ups, MRF). */
 int ov_conv1d_f32(const ov_conv1d_params* p, ov_stream_t stream);
 
+/* One ResBlock1 iteration in ONE launch, reference openvoice/modules.py:296-306 (the loop body of
+ * ResBlock1.forward with x_mask = None, as the generator calls it at models.py:280-286):
+ *   out = ( c2( lrelu( c1( lrelu(x, slope) ), slope ) ) + x [+ add] ) * scale
+ * c1 = Conv1d(C, C, K, dilation dil), c2 = Conv1d(C, C, K, dilation 1), both 'same'-padded; w1 / w2 packed by
+ * ov_conv1d_pack_f32(C, C, K), b1 / b2 [128] in packed row order.  `add` / `scale` carry the MRF running sum and
+ * the final 1/num_kernels of models.py:282-286.  The intermediate tensor stays in LDS (sliding window along time,
+ * openvoice_amd/csrc/conv1d_pair.h); results are bit-identical to the two ov_conv1d_f32 launches it replaces.
+ * x / out / add are [B][C][L] with rows `ld` floats apart (0 = L), 16-byte aligned rows (ld % 4 == 0);
+ * out must not alias x or add.  Instantiated for the HBM-bound stages only: ov_resblock_pair_supported(). */
+typedef struct ov_respair_params {
+  const float* x;
+  const float* w1;
+  const float* b1;
+  const float* w2;
+  const float* b2;
+  float* out;
+  const float* add;      /* or NULL */
+  int64_t x_bstride, out_bstride, add_bstride;
+  int32_t B, C, L;
+  int32_t ld;            /* row stride of x / out / add in floats; 0 = L */
+  int32_t K, dil;
+  int32_t nwg;           /* 0 = one workgroup per resident slot; n > 0 forces n workgroups (tests) */
+  float slope;           /* leaky-ReLU slope of both activations (modules.py:14: 0.1) */
+  float scale;
+  unsigned long long* dbg; /* measurement only, NULL in production: [workgroups][4 waves][8] shader-clock ticks per
+                          * phase (residual issue, chunk wait, c1, h store, h barrier, c2, epilogue, tail) */
+} ov_respair_params;
+int ov_resblock_pair_f32(const ov_respair_params* p, ov_stream_t stream);
+/* 1 when (C, K, dil) has a fused instance, else 0 (callers then issue the two ov_conv1d_f32 launches). */
+int ov_resblock_pair_supported(int C, int K, int dil);
+
 /* Framing for the linear spectrogram, reference openvoice/mel_processing.py:54-58 (reflect pad) and the framing
  * step of torch.stft at :61-72: hops[b][c][u] = ypad[hop*u + c] for u < U, with ypad the waveform [B][N]
  * reflect-padded by `pad` samples on each side (zero beyond that).  hops is (B, hop, U) with rows ld apart.

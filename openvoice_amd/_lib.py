@@ -50,6 +50,15 @@ class ConvBf16Params(ctypes.Structure):
                 ("in_slope", ctypes.c_float), ("scale", ctypes.c_float)]
 
 
+class RespairParams(ctypes.Structure):
+    """Mirror of ``ov_respair_params`` (include/openvoice_amd.h)."""
+    _fields_ = [("x", _fp), ("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("out", _fp), ("add", _fp),
+                ("x_bstride", ctypes.c_int64), ("out_bstride", ctypes.c_int64), ("add_bstride", ctypes.c_int64),
+                ("B", ctypes.c_int32), ("C", ctypes.c_int32), ("L", ctypes.c_int32), ("ld", ctypes.c_int32),
+                ("K", ctypes.c_int32), ("dil", ctypes.c_int32), ("nwg", ctypes.c_int32),
+                ("slope", ctypes.c_float), ("scale", ctypes.c_float), ("dbg", _fp)]
+
+
 # name -> (restype, argtypes); kept in one table so tests can check every header symbol exists.
 SIGNATURES = {
     "ov_version": (ctypes.c_int, []),
@@ -57,6 +66,8 @@ SIGNATURES = {
     "ov_conv1d_pack_rows": (ctypes.c_int, [ctypes.c_int]),
     "ov_conv1d_pack_f32": (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
     "ov_conv1d_f32": (ctypes.c_int, [ctypes.POINTER(ConvParams), _fp]),
+    "ov_resblock_pair_f32": (ctypes.c_int, [ctypes.POINTER(RespairParams), _fp]),
+    "ov_resblock_pair_supported": (ctypes.c_int, [_i, _i, _i]),
     "ov_conv_post_tanh_f32": (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_float, _fp]),
     "ov_linear_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),

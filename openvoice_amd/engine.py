@@ -136,6 +136,33 @@ def launch_conv(layer, x, x_off, x_bs, out, out_off, out_bs, B, L, epi=EPI_LINEA
     _lib.check(_lib.load().ov_conv1d_f32(ctypes.byref(p), stream), "ov_conv1d_f32")
 
 
+def launch_pair(c1, c2, x, x_bs, out, out_bs, B, L, add=None, add_bs=0, scale=1.0, slope=LRELU_SLOPE, ld=0, nwg=0,
+                dbg=None):
+    """One fused ResBlock1 iteration (``ov_resblock_pair_f32``): out = (c2(lrelu(c1(lrelu(x)))) + x [+ add]) * scale.
+    ``c1`` / ``c2`` are the ``PackedConv`` layers of the two convs; ``out`` must not alias ``x``."""
+    p = _lib.RespairParams()
+    p.x, p.w1, p.b1, p.w2, p.b2 = _ptr(x), _ptr(c1.w), _ptr(c1.bias), _ptr(c2.w), _ptr(c2.bias)
+    p.out = _ptr(out)
+    p.add = _ptr(add) if add is not None else None
+    p.x_bstride, p.out_bstride, p.add_bstride = x_bs, out_bs, add_bs
+    p.B, p.C, p.L, p.ld, p.K, p.dil, p.nwg = B, c1.cin, L, ld, c1.K, c1.dil, nwg
+    p.slope, p.scale = slope, scale
+    p.dbg = ctypes.c_void_p(dbg.data_ptr()) if dbg is not None else None
+    stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(_lib.load().ov_resblock_pair_f32(ctypes.byref(p), stream), "ov_resblock_pair_f32")
+
+
+def pair_supported(C, K, dil):
+    return bool(_lib.load().ov_resblock_pair_supported(C, K, dil))
+
+
+# Where the fused pair beats its two launches on MI355X (profiles/r02_s5_pair_vs_two_launches.txt, B = 32 x 10 s):
+# C = 32, k = 3: 0.91 vs 1.09 ms; C = 32, k = 7: 1.75 vs 1.85; C = 64, k = 3: 1.60 vs 1.64.  The MFMA-bound shapes
+# (C = 32 k = 11, C = 64 k = 7) run 4-9 % SLOWER fused (32 accumulator registers per wave instead of 64: less matrix
+# work per LDS operand) and stay on the two-launch path.
+PAIR_POLICY = {(32, 3), (32, 7), (64, 3)}
+
+
 class _WaveNet:
     """Packed WN stack (reference: openvoice/modules.py:133-210)."""
 
@@ -245,6 +272,7 @@ class ConverterEngine:
                 proj_b=sd["ref_enc.proj.bias"].contiguous().to(dev))
         self._ws = {}
         self.profile = None   # set to [] to collect per-launch HIP-event timings
+        self.fuse_pairs = True   # ResBlock pairs of the HBM-bound stages as one launch each (PAIR_POLICY)
         # opt-in fast generator: bf16 activations, fp32 accumulation (waveform within
         # ~1e-2 of the fp32 path instead of ~1e-5).  Built lazily by use_bf16_generator().
         self._state_dict_for_bf16 = sd
@@ -267,6 +295,18 @@ class ConverterEngine:
         if alg_flops is None:
             alg_flops = 2.0 * layer.rows * (kwargs.get("cin") or layer.cin) * layer.K * L * B
         self.profile.append((tag, alg_flops, e0, e1))
+
+    def _pair(self, c1, c2, x, out, bs, B, L, add, scale):
+        """One fused ResBlock1 iteration; profiled under the same tag as the two launches it replaces, with their
+        algorithmic FLOPs (both convs)."""
+        if self.profile is None:
+            launch_pair(c1, c2, x, bs, out, bs, B, L, add=add, add_bs=bs, scale=scale)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch_pair(c1, c2, x, bs, out, bs, B, L, add=add, add_bs=bs, scale=scale)
+        e1.record()
+        self.profile.append(("mrf", 2 * 2.0 * c1.rows * c1.cin * c1.K * L * B, e0, e1))
 
     def _linear(self, x2d, w, b):
         Bg, Kd = x2d.shape
@@ -440,13 +480,21 @@ class ConverterEngine:
             # MRF: mean of the 3 ResBlock1 outputs (models.py:280-286, modules.py:296-306)
             for j, pairs in enumerate(self.resblocks[i]):
                 cur = u
+                fused = self.fuse_pairs and all((ch, c1.K) in PAIR_POLICY and pair_supported(ch, c1.K, c1.dil)
+                                                for c1, _ in pairs) and L % 4 == 0
                 for n, (c1, c2) in enumerate(pairs):
-                    self._conv(c1, cur, 0, bs, t1, 0, bs, B, L, in_slope=LRELU_SLOPE, tag="mrf")
                     last = n == len(pairs) - 1
-                    dst = acc if last else ra
-                    self._conv(c2, t1, 0, bs, dst, 0, bs, B, L, in_slope=LRELU_SLOPE, res=cur, res_bs=bs,
-                               add=acc if (last and j > 0) else None, add_bs=bs,
-                               scale=1.0 / nk if (last and j == nk - 1) else 1.0, tag="mrf")
+                    add = acc if (last and j > 0) else None
+                    scale = 1.0 / nk if (last and j == nk - 1) else 1.0
+                    if fused:
+                        # one launch per pair, intermediate in LDS; out must not alias x: ra / t1 ping-pong
+                        dst = acc if last else (t1 if cur is ra else ra)
+                        self._pair(c1, c2, cur, dst, bs, B, L, add, scale)
+                    else:
+                        self._conv(c1, cur, 0, bs, t1, 0, bs, B, L, in_slope=LRELU_SLOPE, tag="mrf")
+                        dst = acc if last else ra
+                        self._conv(c2, t1, 0, bs, dst, 0, bs, B, L, in_slope=LRELU_SLOPE, res=cur, res_bs=bs,
+                                   add=add, add_bs=bs, scale=scale, tag="mrf")
                     cur = dst
             free += [u, t1, ra]
             x = acc

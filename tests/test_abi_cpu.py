@@ -127,3 +127,23 @@ def test_bf16_weight_packer_layout_and_rounding(cout, cin, k):
     assert torch.all(got[-1] == 0)                         # the zero record that ends the stream
     assert lib.ov_conv1d_bf16_pack_size(32, 40, 3) == 0     # Cin must be a multiple of 32
     assert lib.ov_conv1d_bf16cl(None, None) == -1
+
+
+def test_respair_params_struct_matches_header_field_order_and_size():
+    header = open(os.path.join(REPO, "include", "openvoice_amd.h")).read()
+    body = header[header.index("typedef struct ov_respair_params {"):header.index("} ov_respair_params;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        first, *rest = decl.split(",")
+        names.append(re.findall(r"(\w+)$", first.strip())[0])
+        names += [r.strip() for r in rest]
+    assert names == [f[0] for f in _lib.RespairParams._fields_]
+    import ctypes
+    assert ctypes.sizeof(_lib.RespairParams) == 128          # 7 pointers, 3 int64, 7 int32, 2 float, pad, 1 pointer
+    lib = _lib.load()
+    assert lib.ov_resblock_pair_f32(None, None) == -1
+    assert lib.ov_resblock_pair_supported(32, 3, 1) == 1 and lib.ov_resblock_pair_supported(128, 3, 1) == 0

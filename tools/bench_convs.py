@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--modes", nargs="+", default=["plain1", "plain5", "res", "res+add"],
                     help="plain1 / plain5 = conv1 with dilation 1 / 5, res = conv2 with the residual (16 of the 18 conv2 "
                          "launches of a stage), res+add = conv2 with residual and MRF running sum (the other 2)")
+    ap.add_argument("--pair", action="store_true", help="time the fused ResBlock pair against its two-launch equivalent")
+    ap.add_argument("--nwg", type=int, nargs="+", default=[0], help="--pair: workgroup counts (0 = one per resident slot)")
+    ap.add_argument("--skip-single", action="store_true", help="skip the single-conv table")
     ap.add_argument("--wn", action="store_true", help="also time the WaveNet k5 gate conv and the 1x1 res/skip conv")
     args = ap.parse_args()
     dev = "cuda:0"
@@ -64,7 +67,7 @@ def main():
     print(f"B={B}")
     print(f"{'C':>4} {'L':>7} {'k':>2} {'d':>1} {'epi':>8} {'tile':>4} {'nld':>3} {'ch':>2} {'tpw':>3} {'ms':>8} {'TF/s':>7} {'%peak':>6}")
     for c, L in stages:
-        if c not in args.channels:
+        if c not in args.channels or args.skip_single:
             continue
         x = torch.randn(B, c, L, device=dev)
         res = torch.randn(B, c, L, device=dev)
@@ -92,6 +95,33 @@ def main():
                     print(f"{c:>4} {L:>7} {k:>2} {d:>1} {mode:>8} {tile:>4} {nld:>3} {chunk:>2} {tpw:>3} {ms:8.3f} {tf:7.1f} "
                           f"{100 * tf / PEAK:6.1f}", flush=True)
         del x, res, add, out
+    if args.pair:
+        import itertools
+        from openvoice_amd.engine import launch_pair, pair_supported
+        print(f"{'C':>4} {'L':>7} {'k':>2} {'d':>1} {'pair ms':>8} {'TF/s':>7} {'%peak':>6} {'c1+c2 ms':>9} {'%peak':>6}")
+        for c, L in stages:
+            if c not in args.channels:
+                continue
+            x = torch.randn(B, c, L, device=dev)
+            t = torch.empty(B, c, L, device=dev)
+            out = torch.empty(B, c, L, device=dev)
+            for k in args.kernels:
+                for d in (1, 5):
+                    if not pair_supported(c, k, d):
+                        continue
+                    c1 = PackedConv(torch.randn(c, c, k) * (c * k) ** -0.5, torch.zeros(c), dev, K=k, dil=d)
+                    c2 = PackedConv(torch.randn(c, c, k) * (c * k) ** -0.5, torch.zeros(c), dev, K=k, dil=1)
+
+                    def two():
+                        launch_conv(c1, x, 0, c * L, t, 0, c * L, B, L, in_slope=0.1)
+                        launch_conv(c2, t, 0, c * L, out, 0, c * L, B, L, in_slope=0.1, res=x, res_bs=c * L)
+                    for nwg in args.nwg:
+                        ms = timed(lambda: launch_pair(c1, c2, x, c * L, out, c * L, B, L, nwg=nwg), args.reps, args.warm_ms)
+                        ms2 = timed(two, args.reps, args.warm_ms)
+                        fl = 2 * 2.0 * c * c * k * L * B
+                        print(f"{c:>4} {L:>7} {k:>2} {d:>1} {ms:8.3f} {fl / ms / 1e9:7.1f} {100 * fl / ms / 1e9 / PEAK:6.1f} "
+                              f"{ms2:9.3f} {100 * fl / ms2 / 1e9 / PEAK:6.1f}  nwg={nwg}", flush=True)
+            del x, t, out
     if args.wn:
         from openvoice_amd._lib import EPI_GATE, EPI_RESSKIP
         from openvoice_amd.engine import gate_row_order, padded_frames
