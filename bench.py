@@ -167,6 +167,88 @@ def cpu_baseline(sd, cfg, seconds, budget_s=20.0, want_reference=True):
     return out
 
 
+def init_ranks(args, backend):
+    """One process per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); returns
+    (world, rank, local_rank, device).  ``backend`` "nccl" = RCCL on the GPUs, "gloo" = the CPU rehearsal."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    gpu = backend == "nccl"
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if gpu:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group("gloo")
+    dev = torch.device(f"cuda:{local_rank}") if gpu else torch.device("cpu")
+    if gpu:
+        torch.cuda.set_device(dev)
+    return world, rank, local_rank, dev
+
+
+def timed_steps(step, args, world, dev):
+    """``args.warmup`` untimed steps, then EXACTLY ``args.steps`` steps bracketed by a barrier + device synchronise on
+    both sides; returns (seconds, max over ranks; last step's result)."""
+    import torch.distributed as dist
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+    sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    return elapsed, result
+
+
+def dry_run(args):
+    """bench.py's multi-rank control flow on CPU + gloo (see --dry-run)."""
+    import torch.distributed as dist
+    from openvoice_amd.parallel import broadcast_speaker_embeddings
+    world, rank, _, dev = init_ranks(args, "gloo")
+    gen = torch.Generator().manual_seed(1)
+    se = (0.1 * torch.randn(1, 256, 1, generator=gen), 0.1 * torch.randn(1, 256, 1, generator=gen))
+    B = args.batch
+    wave = torch.full((B, 64), float(rank))
+
+    def step():
+        src_se, tgt_se = broadcast_speaker_embeddings(se[0] if rank == 0 else None, se[1] if rank == 0 else None,
+                                                      256, dev) if world > 1 else (se[0], se[1])
+        return wave * (src_se.sum() - tgt_se.sum()), 1      # stand-in for the conversion
+
+    elapsed, (o, _) = timed_steps(step, args, world, dev)
+    ok = bool(torch.allclose(o, wave * (se[0].sum() - se[1].sum())))   # every rank saw rank 0's embeddings
+    if world > 1:
+        flag = torch.tensor([1.0 if ok else 0.0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item() == 1.0)
+    if rank == 0:
+        print(json.dumps({"metric": "real_time_factor", "value": None, "unit": "x real-time (audio s / wall s)",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "dry_run": True, "broadcast_consistent": ok,
+                          "config": {"workload": "control-flow rehearsal on CPU + gloo, no conversion",
+                                     "batch_per_gpu": B, "global_batch": B * world}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,7 +264,14 @@ def main():
     ap.add_argument("--pmc-calibration", action="store_true",
                     help="after the timed region, run three 1 GiB device-to-device copies (a known byte count) "
                          "so a rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass can be calibrated")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="control-flow rehearsal without a GPU (tests/test_bench_dry_run.py): gloo instead of RCCL, CPU "
+                         "tensors, the conversion replaced by a stand-in; everything else -- rendezvous, the per-step "
+                         "speaker-embedding broadcast, barriers, max-over-ranks timing, one JSON line on rank 0 -- is "
+                         "the code the N-GPU run executes.  The line is marked dry_run and carries no measurement")
     args = ap.parse_args()
+    if args.dry_run:
+        return dry_run(args)
 
     import torch.distributed as dist
     from openvoice_amd.mel_processing import spectrogram_torch
@@ -191,15 +280,7 @@ def main():
     from openvoice_amd.params import synthetic_state_dict
     from openvoice_amd.utils import default_converter_hparams
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
-        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    dev = torch.device(f"cuda:{local_rank}")
-    torch.cuda.set_device(dev)
+    world, rank, local_rank, dev = init_ranks(args, "nccl")
 
     hps = default_converter_hparams("v2")
     cfg = dict(hps.model.items())
@@ -226,24 +307,7 @@ def main():
         o_hat, _, _ = model.voice_conversion(spec, lengths, src_se, tgt_se, tau=0.3)
         return o_hat, spec.shape[2]
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        o_hat, frames = step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = tmax.item()
+    elapsed, (o_hat, frames) = timed_steps(step, args, world, dev)
     assert o_hat.shape == (B, 1, frames * engine.total_upsample) and bool(torch.isfinite(o_hat).all())
 
     # PCIe-inclusive rate, reported beside `value` (never as it): the same step with the waveforms coming from
@@ -355,4 +419,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

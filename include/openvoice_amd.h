@@ -47,8 +47,9 @@ enum {
    * row < split : out[b][row][t]  = (out[b][row][t] + v) * mask[b][t]      (residual, in place)
    * row >= split: out2[b][row-split][t] (+)= v     ('=' when OV_F_OUT2_INIT, else '+=')      */
   OV_EPI_RESSKIP = 2,
-  /* mean-only coupling combine, reference openvoice/modules.py:441-455 (out is x1, in place):
-   * forward (scale > 0): out = v*mask + out*mask ;  reverse (scale < 0): out = (out - v*mask)*mask */
+  /* mean-only coupling combine, reference openvoice/modules.py:441-455; x1 = res when res != NULL (indexed like
+   * out), else out itself (in place):
+   * forward (scale > 0): out = v*mask + x1*mask ;  reverse (scale < 0): out = (x1 - v*mask)*mask */
   OV_EPI_COUPLE = 3,
   /* posterior sample, reference openvoice/models.py:218-220 (rows paired like OV_EPI_GATE:
    * m = tile 2q, logs = tile 2q+1): out = (m*mask + res*scale*exp(logs*mask))*mask,
@@ -87,7 +88,7 @@ typedef struct ov_conv1d_params {
   const float* bias;     /* [M rounded up to 128] in packed row order; required (zeros if none) */
   const float* bias_b;   /* per-batch bias [B or 1][M] in packed row order, or NULL             */
   float* out;            /* primary output, indexed [b][row][t] with out_bstride                */
-  const float* res;      /* LINEAR: residual; POSTERIOR: noise; indexed like out; or NULL       */
+  const float* res;      /* LINEAR: residual; POSTERIOR: noise; COUPLE: x1 source; indexed like out; or NULL */
   const float* add;      /* LINEAR: second addend (MRF running sum), indexed like out; or NULL  */
   float* out2;           /* RESSKIP: skip accumulator [b][row-split][t]                         */
   const float* mask;     /* [B][>=L] sequence mask (1/0), rows mask_bstride apart, or NULL      */

@@ -228,7 +228,7 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
 //   every kind      bias[row] (+ bias_b[b][row])
 //   LINEAR          + res (+ add)                 the ResBlock residual and the MRF running sum
 //   RESSKIP         + h (residual rows) / + skip (skip rows, unless OV_F_OUT2_INIT)
-//   COUPLE          + x1 (forward) / - x1 (reverse; the epilogue negates)
+//   COUPLE          + x1 (forward) / - x1 (reverse; the epilogue negates); x1 = res when given, else out (in place)
 // so that the epilogue only scales / masks and stores.  All of these loads -- 16 x WM x WN per lane -- are issued
 // back to back as ONE batch at the top of the tile, straight into the accumulator registers (no temporaries, no
 // branches: out-of-range columns and padding rows are clamped to a valid address and simply never stored), where
@@ -250,6 +250,8 @@ __device__ __forceinline__ bool conv_preload(const ov_conv1d_params& p, f32x16 (
     int64_t src_bs = 0;
     if constexpr (EPI == OV_EPI_LINEAR) {
       if (p.res && !(p.flags & OV_F_MASK_V)) { src = p.res; src_bs = p.res_bstride; }   // v*mask + res keeps the epilogue order
+    } else if (EPI == OV_EPI_COUPLE && p.res) {
+      src = p.res; src_bs = p.res_bstride;      // x1 read from another tensor, written to out (no latent copy)
     } else {
       src = p.out; src_bs = p.out_bstride;
     }

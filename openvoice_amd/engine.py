@@ -353,18 +353,23 @@ class ConverterEngine:
                        flags=F_OUT2_INIT if i == 0 else 0, out2=ws["skip"], out2_bs=H * Tp, mask=mask, mask_bs=Tp,
                        split=0 if last else H, x_ld=Tp, out_ld=Tp, tag="wn_rs")
 
-    def _flow(self, buf, ws, B, T, conds, mask, reverse):
+    def _flow(self, src, buf, ws, B, T, conds, mask, reverse):
+        """ResidualCouplingBlock (models.py:390-397) from ``src`` into ``buf`` without a copy: a coupling rewrites one
+        half of the channels (x1) and leaves the other (x0) alone, and consecutive couplings alternate halves (the
+        folded Flips), so the first two couplings read their x1 operand from ``src`` and write it to ``buf`` -- after
+        them every channel of ``buf`` has been written -- and the rest run in place."""
         C, half, H, Tp = self.inter, self.half, self.hidden, ws["Tp"]
         order = range(N_FLOWS - 1, -1, -1) if reverse else range(N_FLOWS)
-        for f in order:
+        for n, f in enumerate(order):
             cp = self.couplings[f]
             x0_off = half * Tp if cp["flipped"] else 0
             x1_off = 0 if cp["flipped"] else half * Tp
-            self._conv(cp["pre"], buf, x0_off, C * Tp, ws["h"], 0, H * Tp, B, T, flags=F_MASK_V, mask=mask,
-                       mask_bs=Tp, x_ld=Tp, out_ld=Tp, tag="cpl_pre")
+            self._conv(cp["pre"], src if n == 0 else buf, x0_off, C * Tp, ws["h"], 0, H * Tp, B, T, flags=F_MASK_V,
+                       mask=mask, mask_bs=Tp, x_ld=Tp, out_ld=Tp, tag="cpl_pre")
             self._wavenet(cp["wn"], ws, B, T, conds[f], mask)
             self._conv(cp["post"], ws["skip"], 0, H * Tp, buf, x1_off, C * Tp, B, T, epi=EPI_COUPLE, mask=mask,
-                       mask_bs=Tp, x_ld=Tp, out_ld=Tp, scale=-1.0 if reverse else 1.0, tag="cpl_post")
+                       mask_bs=Tp, x_ld=Tp, out_ld=Tp, scale=-1.0 if reverse else 1.0, tag="cpl_post",
+                       res=src if n < 2 else None, res_off=x1_off, res_bs=C * Tp)
 
     # ---- the path ----------------------------------------------------------------------------------
     @torch.no_grad()
@@ -380,8 +385,7 @@ class ConverterEngine:
         # rows may be padded (the native spectrogram returns a [B, F, T] view of 16-byte aligned rows)
         if not (spec.stride(2) == 1 and spec.stride(1) >= T and spec.stride(0) >= F * spec.stride(1)):
             spec = spec.contiguous()
-        spec_ld, spec_bs = spec.stride(1), spec.stride(0)
-        C, H = self.inter, self.hidden
+        C = self.inter
         lengths = spec_lengths.to(dev, torch.int64).contiguous()
         g_src = sid_src.to(dev, torch.float32).reshape(sid_src.shape[0], -1).contiguous()
         g_tgt = sid_tgt.to(dev, torch.float32).reshape(sid_tgt.shape[0], -1).contiguous()
@@ -396,22 +400,16 @@ class ConverterEngine:
         # conditioning GEMVs (T = 1): modules.py:189-190 for every WN, models.py:275 for the decoder
         g_q = torch.zeros_like(g_src) if self.zero_g else g_src
         g_d = torch.zeros_like(g_tgt) if self.zero_g else g_tgt
-        cond_q = self._linear(g_q, self.q_wn.cond_w, self.q_wn.cond_b)
-        cond_src = [self._linear(g_src, cp["wn"].cond_w, cp["wn"].cond_b) for cp in self.couplings]
-        cond_tgt = [self._linear(g_tgt, cp["wn"].cond_w, cp["wn"].cond_b) for cp in self.couplings]
+        conds = dict(q=self._linear(g_q, self.q_wn.cond_w, self.q_wn.cond_b),
+                     src=[self._linear(g_src, cp["wn"].cond_w, cp["wn"].cond_b) for cp in self.couplings],
+                     tgt=[self._linear(g_tgt, cp["wn"].cond_w, cp["wn"].cond_b) for cp in self.couplings])
         cond_d = self._linear(g_d, self.dec_cond_w, self.dec_cond_b)
-        # ---- posterior encoder (models.py:212-221) -------------------------------------------------
-        self._conv(self.q_pre, spec, 0, spec_bs, ws["h"], 0, H * Tp, B, T, flags=F_MASK_V, mask=mask, mask_bs=Tp,
-                   x_ld=spec_ld, out_ld=Tp, tag="q_pre")
-        self._wavenet(self.q_wn, ws, B, T, cond_q, mask)
+        # ---- posterior encoder + flows at frame rate ---------------------------------------------------
+        # (measured and dropped: issuing this part -- ~100 launches of <= 1.3 tiles per workgroup slot -- as 2 / 4
+        # independent sub-batch chains on separate HIP streams, so that one chain's tiles would fill the other's
+        # launch tails, takes 16.1 / 14.0 ms instead of 12.1 ms: profiles/r02_s7_frame_streams_ab.txt)
+        self._frames(ws, 0, B, spec, conds, tau)
         z, z_p, z_hat = ws["z"], ws["z_p"], ws["z_hat"]
-        self._conv(self.q_proj, ws["skip"], 0, H * Tp, z, 0, C * Tp, B, T, epi=EPI_POSTERIOR, res=ws["noise"],
-                   res_bs=C * Tp, scale=float(tau), mask=mask, mask_bs=Tp, rows=2 * C, x_ld=Tp, out_ld=Tp, tag="q_proj")
-        # ---- flow forward with g_src, reverse with g_tgt (models.py:496-497) -----------------------
-        z_p.copy_(z)
-        self._flow(z_p, ws, B, T, cond_src, mask, reverse=False)
-        z_hat.copy_(z_p)
-        self._flow(z_hat, ws, B, T, cond_tgt, mask, reverse=True)
         # ---- generator (models.py:272-291); z_hat * y_mask is the identity (z_hat already masked) --
         if getattr(self, "_bf16_on", False):
             if self.profile is not None:
@@ -426,6 +424,25 @@ class ConverterEngine:
         # fresh dense tensors for the caller (the workspace is reused by the next call)
         outs = tuple(t[:, :, :T].contiguous() for t in (z, z_p, z_hat))
         return o_hat, mask[:, :T].unsqueeze(1).contiguous(), outs
+
+    def _frames(self, ws, b0, b1, spec, conds, tau):
+        """Posterior encoder and the two flow passes for the utterances [b0, b1) (views of the whole-batch workspace)."""
+        nb, T, Tp = b1 - b0, spec.shape[2], ws["Tp"]
+        C, H = self.inter, self.hidden
+        sub = {k: (v[b0:b1] if torch.is_tensor(v) else v) for k, v in ws.items() if k != "dec"}
+        rows = lambda t: t if t.shape[0] == 1 else t[b0:b1]
+        mask = sub["mask"]
+        x = spec[b0:b1]
+        # ---- posterior encoder (models.py:212-221) -------------------------------------------------
+        self._conv(self.q_pre, x, 0, spec.stride(0), sub["h"], 0, H * Tp, nb, T, flags=F_MASK_V, mask=mask, mask_bs=Tp,
+                   x_ld=spec.stride(1), out_ld=Tp, tag="q_pre")
+        self._wavenet(self.q_wn, sub, nb, T, rows(conds["q"]), mask)
+        z, z_p, z_hat = sub["z"], sub["z_p"], sub["z_hat"]
+        self._conv(self.q_proj, sub["skip"], 0, H * Tp, z, 0, C * Tp, nb, T, epi=EPI_POSTERIOR, res=sub["noise"],
+                   res_bs=C * Tp, scale=float(tau), mask=mask, mask_bs=Tp, rows=2 * C, x_ld=Tp, out_ld=Tp, tag="q_proj")
+        # ---- flow forward with g_src, reverse with g_tgt (models.py:496-497) -----------------------
+        self._flow(z, z_p, sub, nb, T, [rows(c) for c in conds["src"]], mask, reverse=False)
+        self._flow(z_p, z_hat, sub, nb, T, [rows(c) for c in conds["tgt"]], mask, reverse=True)
 
     def graphed(self, B, T, tau, src_rows=1, tgt_rows=1, max_cached=4):
         """``voice_conversion`` for one fixed (B, T, tau) as a captured HIP graph (see ``GraphedConversion``);

@@ -1,0 +1,57 @@
+"""bench.py's N > 1 control flow, rehearsed on CPU with gloo: the exact launch line
+the driver uses (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...), the
+rendezvous, the per-step broadcast of rank 0's speaker embeddings, the barrier / synchronise bracketing, the
+max-over-ranks all-reduce of the elapsed time and the single JSON line on rank 0 -- so that the first RCCL run is not
+also the first execution of that code.  Only the conversion itself is replaced by a stand-in (--dry-run)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _lines(stdout):
+    return [json.loads(line) for line in stdout.splitlines() if line.startswith("{")]
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_multi_rank_control_flow_on_gloo(n):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(REPO, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1", "--dry-run"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=REPO)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = _lines(res.stdout)
+    assert len(lines) == 1, f"exactly one JSON line, from rank 0: {res.stdout!r}"
+    rec = lines[0]
+    assert rec["n_gpus"] == n and rec["steps"] == 3 and rec["warmup"] == 1 and rec["dry_run"] is True
+    assert rec["broadcast_consistent"] is True
+    assert rec["config"]["global_batch"] == 32 * n and rec["scaling"] == "weak"
+    assert rec["ms_per_step"] >= 0
+
+
+def test_bench_single_rank_dry_run_needs_no_process_group():
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--dry-run", "--steps", "2", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=120, cwd=REPO)
+    assert res.returncode == 0, res.stderr[-2000:]
+    (rec,) = _lines(res.stdout)
+    assert rec["n_gpus"] == 1 and rec["dry_run"] is True
+
+
+def test_world_size_mismatch_is_refused():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--dry-run", "--gpus", "4"],
+                         capture_output=True, text=True, timeout=120, env=env, cwd=REPO)
+    assert res.returncode != 0 and "nproc-per-node" in res.stderr

@@ -44,9 +44,11 @@ def test_voice_conversion_matches_reference_golden(golden_dir, synth_sd, name):
 
 
 @pytest.mark.parametrize("B,T,zero_g,per_item", [(1, 1, True, False), (2, 64, False, True), (3, 127, True, False),
-                                                 (1, 861, True, False)])
+                                                 (1, 861, True, False), (1, 1000, False, False),
+                                                 (9, 65, False, True)])
 def test_voice_conversion_matches_oracle(synth_sd, B, T, zero_g, per_item):
-    """Tile/halo edge shapes and the benchmark frame count (T = 861), vs the CPU oracle."""
+    """Tile/halo edge shapes, the benchmark frame count (T = 861), T = 1000 (SURVEY.md section 8c's shape list) and a
+    ragged batch of 9 with per-item embeddings, vs the CPU oracle."""
     from oracle import vc_oracle
     gen = torch.Generator().manual_seed(B * 1000 + T)
     spec = torch.rand(B, 513, T, generator=gen).abs() * torch.linspace(3, 0.05, 513)[None, :, None]
@@ -202,6 +204,35 @@ def test_voice_conversion_matches_reference_at_benchmark_length(golden_dir, synt
     print("T=861 vs reference: o_hat err", err)
     assert (z_hat.cpu().sum(2) - rec["z_hat_sum"]).abs().max().item() <= 5e-3
     assert err <= O_HAT_TOL
+
+
+def test_benchmark_batch_items_match_the_oracle_directly(synth_sd):
+    """BASELINE.json configs[1] itself -- B = 32 x T = 861 in ONE call --
+    compared with the oracle, not only through properties: the oracle converts items 3 and 20 of the same inputs one
+    at a time (utterances are independent at full length: no padding)."""
+    from oracle import vc_oracle
+    B, T = 32, 861
+    gen = torch.Generator().manual_seed(4242)
+    spec = torch.rand(B, 513, T, generator=gen) * torch.linspace(3, 0.05, 513)[None, :, None]
+    lengths = torch.full((B,), T, dtype=torch.long)
+    g_src, g_tgt = 0.3 * torch.randn(1, 256, 1, generator=gen), 0.3 * torch.randn(1, 256, 1, generator=gen)
+    noise = torch.randn(B, 192, T, generator=gen)
+    model = _model(synth_sd, True)
+    o_hat, _, (z, z_p, z_hat) = model.voice_conversion(spec.to(DEV), lengths.to(DEV), g_src.to(DEV), g_tgt.to(DEV),
+                                                       tau=0.3, noise=noise.to(DEV))
+    torch.cuda.synchronize()
+    torch.set_num_threads(usable_cpus(32))
+    for b in (3, 20):
+        with torch.no_grad():
+            o_r, _, (z_r, zp_r, zh_r) = vc_oracle.voice_conversion(
+                synth_sd, CONVERTER_MODEL_CONFIG, spec[b:b + 1], lengths[b:b + 1], g_src, g_tgt, 0.3, noise[b:b + 1],
+                zero_g=True)
+        errs = dict(z=(z[b:b + 1].cpu() - z_r).abs().max().item(), z_p=(z_p[b:b + 1].cpu() - zp_r).abs().max().item(),
+                    z_hat=(z_hat[b:b + 1].cpu() - zh_r).abs().max().item(),
+                    o_hat=(o_hat[b:b + 1].cpu() - o_r).abs().max().item())
+        print("B=32 x T=861, item", b, errs)
+        assert max(errs["z"], errs["z_p"], errs["z_hat"]) <= LATENT_TOL, errs
+        assert errs["o_hat"] <= O_HAT_TOL, errs
 
 
 @pytest.mark.gpu
