@@ -314,6 +314,9 @@ int ov_conv_post_tanh_bf16(const uint16_t* x, const float* w, float* out, int B,
 
 /* Library/ABI version (major*100 + minor). */
 int ov_version(void);
+/* 0 for a production build; non-zero = a measurement build with parts of the kernels compiled out (results are
+ * meaningless; openvoice_amd/_lib.py refuses to load it unless OPENVOICE_AMD_ALLOW_EXPERIMENT=1). */
+int ov_build_experiment(void);
 
 #ifdef __cplusplus
 }

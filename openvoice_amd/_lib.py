@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libopenvoice_amd.so")
+# OPENVOICE_AMD_LIB: measurement builds (scripts/exp_sync.sh) live outside the tree and are selected explicitly
+LIB_PATH = os.environ.get("OPENVOICE_AMD_LIB") or os.path.join(_HERE, "libopenvoice_amd.so")
 
 OV_OK = 0
 OV_ERRORS = {-1: "OV_E_BADARG", -2: "OV_E_UNSUPPORTED", -3: "OV_E_ALIGN", -4: "OV_E_LAUNCH"}
@@ -62,6 +63,7 @@ class RespairParams(ctypes.Structure):
 # name -> (restype, argtypes); kept in one table so tests can check every header symbol exists.
 SIGNATURES = {
     "ov_version": (ctypes.c_int, []),
+    "ov_build_experiment": (ctypes.c_int, []),
     "ov_conv1d_pack_size": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "ov_conv1d_pack_rows": (ctypes.c_int, [ctypes.c_int]),
     "ov_conv1d_pack_f32": (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
@@ -116,6 +118,10 @@ def load():
             fn = getattr(lib, name)
             fn.restype = restype
             fn.argtypes = argtypes
+        exp = lib.ov_build_experiment()
+        if exp != 0 and os.environ.get("OPENVOICE_AMD_ALLOW_EXPERIMENT") != "1":
+            raise OvError(f"{LIB_PATH} is a measurement build (OV_EXP={exp}: kernels with loads / barriers compiled "
+                          f"out, results meaningless); rebuild with `make -C openvoice_amd/csrc clean all`")
         _lib = lib
     return _lib
 

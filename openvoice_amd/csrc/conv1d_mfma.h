@@ -31,6 +31,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "openvoice_amd.h"
 
 namespace ovk {
@@ -569,14 +571,24 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
   }
 }
 
-// Workgroups of one kernel instance that fit on the chip at once (occupancy x CUs).
-inline int query_resident_workgroups(const void* kernel, int block_threads) {
-  int per_cu = 0, dev = 0;
+// Workgroups of one kernel instance that fit on the chip at once (occupancy x CUs) on the CURRENT device.  Cached per
+// (kernel instance, device ordinal): `cache` is that instance's zero-initialised array, so a process driving several
+// GPUs sizes each launch for the device it is launched on, and concurrent first calls are benign (same value).
+constexpr int OV_MAX_DEVICES = 16;
+inline int resident_workgroups(const void* kernel, int block_threads, std::atomic<int>* cache) {
+  int dev = 0;
+  const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < OV_MAX_DEVICES;
+  if (known) {
+    const int v = cache[dev].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+  }
+  int per_cu = 0, slots = 512;   // 2 per CU on an MI355X
   hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, 0) != hipSuccess || per_cu <= 0)
-    return 512;   // 2 per CU on an MI355X
-  return per_cu * prop.multiProcessorCount;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, 0) == hipSuccess && per_cu > 0)
+    slots = per_cu * prop.multiProcessorCount;
+  if (known) cache[dev].store(slots, std::memory_order_relaxed);
+  return slots;
 }
 
 typedef int (*conv_launch_fn)(const ov_conv1d_params*, hipStream_t);
@@ -597,8 +609,8 @@ int conv1d_launch(const ov_conv1d_params* p, hipStream_t stream) {
   // launch (tests, A/B measurements).
   const long total = (long)ntiles * mblocks * p->B;
   auto kernel = conv1d_mfma_kernel<K, DIL, WM, WN, WVM, WVN, CHUNK, VEC, EPI, NLD>;
-  static int slots = 0;   // per kernel instance (this function is instantiated once per variant)
-  if (slots == 0) slots = query_resident_workgroups(reinterpret_cast<const void*>(kernel), 64 * (4 + NLD));
+  static std::atomic<int> slot_cache[OV_MAX_DEVICES];   // per kernel instance (one instantiation per variant)
+  const int slots = resident_workgroups(reinterpret_cast<const void*>(kernel), 64 * (4 + NLD), slot_cache);
   const int tpw = p->tiles_per_wg > 0 ? p->tiles_per_wg : 1;
   const bool persistent = p->tiles_per_wg < 0 || (p->tiles_per_wg == 0 && p->res == nullptr && total >= 16L * slots);
   long nwg = persistent ? (long)slots : (total + tpw - 1) / tpw;

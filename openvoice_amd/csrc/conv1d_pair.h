@@ -375,8 +375,8 @@ typedef int (*pair_launch_fn)(const ov_respair_params*, hipStream_t);
 template <int K, int DIL, int C, int NT, int CHUNK, int NLD>
 int respair_launch(const ov_respair_params* p, hipStream_t stream) {
   auto kernel = respair_mfma_kernel<K, DIL, C, NT, CHUNK, NLD>;
-  static int slots = 0;
-  if (slots == 0) slots = query_resident_workgroups(reinterpret_cast<const void*>(kernel), 64 * (4 + NLD));
+  static std::atomic<int> slot_cache[OV_MAX_DEVICES];
+  const int slots = resident_workgroups(reinterpret_cast<const void*>(kernel), 64 * (4 + NLD), slot_cache);
   constexpr int P2 = (K - 1) / 2;
   const long S = (long)p->B * ((p->L + P2 + NT - 1) / NT);
   long nwg = p->nwg > 0 ? p->nwg : slots;

@@ -160,7 +160,11 @@ using namespace ovk;
 
 extern "C" {
 
-int ov_version(void) { return 103; }
+int ov_version(void) { return 200; }
+
+// 0 in every shippable build; the measurement builds of scripts/exp_sync.sh (OV_EXP = 1 / 2: staging loads and / or
+// barriers compiled out, numerically meaningless) report their number so that the Python binding can refuse them.
+int ov_build_experiment(void) { return OV_EXP; }
 
 int ov_conv1d_pack_rows(int Cout) { return (Cout + 127) / 128 * 128; }
 

@@ -23,6 +23,23 @@ LRELU_SLOPE = 0.1       # reference: openvoice/modules.py:14
 FINAL_LRELU_SLOPE = 0.01  # F.leaky_relu default at openvoice/models.py:287
 
 
+def on_own_device(method):
+    """Run an engine method with the engine's device current: kernels go to ``current_stream(self.device)`` already,
+    but event records (profile mode), HIP-graph capture and the per-device launch sizing inside the library follow
+    the CURRENT device, which need not be the engine's (``ToneColorConverter(cfg, device='cuda:1')`` while cuda:0 is
+    current)."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        dev = getattr(self, "device", None)
+        if dev is None:      # GraphedConversion: the engine is an attribute, or the first constructor argument
+            dev = (getattr(self, "engine", None) or args[0]).device
+        with torch.cuda.device(dev):
+            return method(self, *args, **kwargs)
+    return wrapper
+
+
 def _ptr(t, offset_elems=0):
     return ctypes.c_void_p(t.data_ptr() + 4 * offset_elems)
 
@@ -373,6 +390,7 @@ class ConverterEngine:
 
     # ---- the path ----------------------------------------------------------------------------------
     @torch.no_grad()
+    @on_own_device
     def voice_conversion(self, spec, spec_lengths, sid_src, sid_tgt, tau=1.0, noise=None):
         """Same contract as the reference seam (openvoice/models.py:492-499):
         ``(o_hat [B,1,256T], y_mask [B,1,T], (z, z_p, z_hat) [B,192,T])``.  ``noise`` [B,192,T]
@@ -523,6 +541,7 @@ class ConverterEngine:
 
     # ---- extract_se path -----------------------------------------------------------------------------
     @torch.no_grad()
+    @on_own_device
     def reference_encoder(self, spec_t):
         """``spec_t`` [N, Ty, n_freq] (the transposed spectrogram the reference API passes,
         openvoice/api.py:131) -> [N, gin]; reference: openvoice/models.py:339-359.  Internally every
@@ -565,6 +584,7 @@ class GraphedConversion:
     replay** -- clone what must outlive it (``ToneColorConverter.convert_batch`` does).  The engine's workspace of
     this shape is pinned for the life of the graph.  Reference contract unchanged: openvoice/models.py:492-499."""
 
+    @on_own_device
     def __init__(self, engine, B, T, tau, src_rows=1, tgt_rows=1):
         dev = engine.device
         self.engine, self.B, self.T, self.tau = engine, int(B), int(T), float(tau)
@@ -590,6 +610,7 @@ class GraphedConversion:
             engine.profile = saved
 
     @torch.no_grad()
+    @on_own_device
     def __call__(self, spec, spec_lengths, sid_src, sid_tgt, noise=None):
         if tuple(spec.shape) != (self.B, self.engine.spec_channels, self.T):
             raise _lib.OvError(f"graph captured for spec {(self.B, self.engine.spec_channels, self.T)}, got {tuple(spec.shape)}")

@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from ._lib import F_MASK_V, LN_POST_GELU, LN_PRE_RELU
-from .engine import ConverterEngine, PackedConv, _ptr, padded_frames
+from .engine import ConverterEngine, PackedConv, _ptr, on_own_device, padded_frames
 from .params import ATTN_WINDOW, SDP_DDS_LAYERS, SDP_FLOWS, SDP_KERNEL, SDP_NUM_BINS, SDP_TAIL_BOUND
 
 LN_EPS = 1e-5   # modules.LayerNorm / attentions.LayerNorm default
@@ -139,6 +139,7 @@ class TtsEngine:
 
     # ---- the path ----------------------------------------------------------------------------------------
     @torch.no_grad()
+    @on_own_device
     def infer(self, tokens, lengths, sid, noise_scale=1.0, length_scale=1.0, noise_scale_w=1.0, sdp_ratio=0.2,
               max_len=None, noise_w=None, noise_z=None, return_attn=True):
         """Same contract as the reference (models.py:467-490): returns

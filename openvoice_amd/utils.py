@@ -49,25 +49,45 @@ def get_hparams_from_file(config_path):
 
 
 def split_sentence(text, min_len=10, language_str="[EN]"):
-    """Sentence pieces for ``BaseSpeakerTTS.tts`` (reference: openvoice/utils.py:78-194).  Same policy as the
-    reference -- split at sentence punctuation, then merge pieces shorter than ``min_len`` words (EN) or
-    ``min_len`` characters (ZH) into their neighbour -- written compactly; it is CPU string handling in
-    front of the measured path and exact piece-for-piece parity with the reference splitter is not claimed."""
+    """Sentence pieces for ``BaseSpeakerTTS.tts`` -- the reference's policy (openvoice/utils.py:78-194), checked piece
+    for piece against the reference splitter in tests/test_api_cpu.py (golden: tests/golden/split_sentence.json):
+
+    1. full-width punctuation -> ASCII; Latin text ('EN') also loses quotes and ``<>()[]"`` brackets, so user text
+       can never inject the ``[EN]`` language marks ``BaseSpeakerTTS.tts`` wraps around each piece;
+    2. cut after every ``, . ! ? ;``;
+    3. glue consecutive cuts together until a piece exceeds ``min_len`` words (Latin) / characters (anything else);
+    4. a piece of <= 2 words / characters is merged into its successor, a trailing one into its predecessor.
+
+    Only ``language_str == 'EN'`` takes the Latin rules, like the reference (utils.py:79)."""
     import re
-    zh = language_str in ("ZH", "[ZH]", "zh")
-    text = re.sub(r"[\n\t ]+", " ", text)
-    text = text.translate(str.maketrans({"\u201c": '"', "\u201d": '"', "\u2018": "'", "\u2019": "'"}))
-    pieces = [p.strip() for p in re.split(r"(?<=[.!?;\u3002\uff01\uff1f\uff1b])\s*", text) if p.strip()]
-    size = (lambda p: len(p)) if zh else (lambda p: len(p.split(" ")))
+    latin = language_str == "EN"
+    size = (lambda piece: len(piece.split(" "))) if latin else len
+    for pattern, repl in (("[\u3002\uff01\uff1f\uff1b]", "."), ("[\uff0c]", ",")):
+        text = re.sub(pattern, repl, text)
+    if latin:
+        text = re.sub("[\u201c\u201d]", '"', text)
+        text = re.sub("[\u2018\u2019]", "'", text)
+        text = re.sub(r'[<>()\[\]"\u00ab\u00bb]+', "", text)
+    text = re.sub("[\n\t ]+", " ", text)
+    cuts = [c.strip() for c in re.sub("([,.!?;])", "\\1 \x00", text).split("\x00")]
+    if cuts and not cuts[-1]:
+        cuts.pop()
+    pieces, run, count = [], [], 0
+    for n, cut in enumerate(cuts):
+        run.append(cut)
+        count += size(cut)
+        if count > min_len or n == len(cuts) - 1:
+            pieces.append(" ".join(run))
+            run, count = [], 0
     merged = []
-    for p in pieces:
-        if merged and size(merged[-1]) < min_len:
-            merged[-1] = merged[-1] + ("" if zh else " ") + p
+    for piece in pieces:
+        if merged and size(merged[-1]) <= 2:
+            merged[-1] += " " + piece
         else:
-            merged.append(p)
+            merged.append(piece)
     if len(merged) > 1 and size(merged[-1]) <= 2:
         last = merged.pop()
-        merged[-1] = merged[-1] + ("" if zh else " ") + last
+        merged[-1] += " " + last
     return merged
 
 

@@ -146,6 +146,22 @@ def test_sentence_splitter_and_intersperse():
     assert api.intersperse([5, 6, 7], 0) == [0, 5, 0, 6, 0, 7, 0]          # reference: openvoice/commons.py:22-25
 
 
+def test_sentence_splitter_matches_the_reference_piece_for_piece(golden_dir):
+    """tests/golden/split_sentence.json = the UNMODIFIED reference splitter (openvoice/utils.py:78-194) on 54
+    (text, language, min_len) cases, generated by oracle/make_split_golden.py: brackets / quotes / language marks in
+    user text, comma splitting, count-then-merge, short-piece merging, Chinese punctuation, empty tails."""
+    import json
+    import os
+    with open(os.path.join(golden_dir, "split_sentence.json"), encoding="utf-8") as fh:
+        cases = json.load(fh)
+    assert len(cases) >= 50
+    for c in cases:
+        got = utils.split_sentence(c["text"], min_len=c["min_len"], language_str=c["language"])
+        assert got == c["pieces"], (c["language"], c["min_len"], c["text"])
+    # user text cannot smuggle the language marks BaseSpeakerTTS.tts wraps around every piece
+    assert all("[" not in p and "]" not in p for p in utils.split_sentence("say [EN] this [ZH] now.", language_str="EN"))
+
+
 def test_tts_text_front_end_is_a_hook():
     hps = utils.HParams(symbols=list("_abc"), data=dict(text_cleaners=["x"], add_blank=True))
     with pytest.raises(RuntimeError, match="no text front end"):
