@@ -85,7 +85,14 @@ def spectrogram_torch(y, n_fft, sampling_rate, hop_size, win_size, center=False)
             print("min value is ", lo)
         if hi > 1.1:
             print("max value is ", hi)
-    if y.is_cuda and y.dtype == torch.float32 and not center and win_size == n_fft and n_fft == 4 * hop_size:
+    if y.is_cuda:
+        # Device tensors take the native kernels or fail loudly -- never a silent torch.stft / rocFFT fallback.
+        if not (y.dtype == torch.float32 and not center and win_size == n_fft and n_fft == 4 * hop_size):
+            from ._lib import OvError
+            raise OvError(f"native spectrogram: float32, center=False and win_size == n_fft == 4 * hop_size only "
+                          f"(every released OpenVoice config: 1024 / 256); got dtype={y.dtype}, center={center}, "
+                          f"n_fft={n_fft}, win_size={win_size}, hop_size={hop_size}.  CPU tensors are evaluated with "
+                          f"torch.stft (host tooling); there is no rocFFT path on the device")
         key = (str(y.device), n_fft, hop_size)
         eng = _native.get(key)
         if eng is None:

@@ -369,3 +369,17 @@ def test_native_spectrogram_matches_torch_stft(B, N):
     _close(got, ref, what=f"spectrogram B={B} N={N}")
     # the view's storage rows are 16-byte aligned and padded columns hold no garbage
     assert got.stride(2) == 1 and got.stride(1) % 4 == 0
+
+
+def test_spectrogram_on_device_never_falls_back_to_rocfft():
+    """A device tensor with a configuration the native kernels do not cover must raise, not take torch.stft."""
+    from openvoice_amd.mel_processing import spectrogram_torch
+    y = torch.zeros(1, 4096, device=DEV)
+    for kw in (dict(n_fft=1024, hop_size=200, win_size=1024), dict(n_fft=1024, hop_size=256, win_size=800),
+               dict(n_fft=2048, hop_size=256, win_size=2048)):
+        with pytest.raises(_lib.OvError):
+            spectrogram_torch(y, kw["n_fft"], 22050, kw["hop_size"], kw["win_size"], center=False)
+    with pytest.raises(_lib.OvError):
+        spectrogram_torch(y, 1024, 22050, 256, 1024, center=True)
+    with pytest.raises(_lib.OvError):
+        spectrogram_torch(y.double(), 1024, 22050, 256, 1024, center=False)
