@@ -312,6 +312,27 @@ int ov_conv1d_bf16cl(const ov_conv1d_bf16_params* p, ov_stream_t stream);
 int ov_conv_post_tanh_bf16(const uint16_t* x, const float* w, float* out, int B, int C, int L, int K, float in_slope,
                            ov_stream_t stream);
 
+/* One ResBlock1 iteration in ONE launch on the bf16 channels-last tensors (the fp32 twin: ov_resblock_pair_f32):
+ *   out = bf16( (c2(lrelu(bf16(c1(lrelu(x)) + b1))) + b2 + x [+ add]) * scale ),  reference openvoice/modules.py:296-306.
+ * The intermediate is rounded to bf16 exactly where the two ov_conv1d_bf16cl launches round it and stays in LDS;
+ * results are bit-identical to that path.  w1 / w2 from ov_conv1d_bf16_pack(C, C, K), b1 / b2 fp32 [C].
+ * C in {32, 64}; out must not alias x (add may alias out). */
+typedef struct ov_respair_bf16_params {
+  const uint16_t* x;    /* [B][L][C] bf16 */
+  const uint16_t* w1;
+  const float* b1;
+  const uint16_t* w2;
+  const float* b2;
+  uint16_t* out;        /* [B][L][C] bf16 */
+  const uint16_t* add;  /* MRF running sum, like out, or NULL */
+  int32_t B, L, C, K, dil;
+  int32_t nwg;          /* 0 = one workgroup per resident slot; n > 0 forces n workgroups (tests) */
+  float slope, scale;
+  unsigned long long* dbg; /* measurement only, NULL in production: [workgroups][4 waves][9] ticks per phase */
+} ov_respair_bf16_params;
+int ov_resblock_pair_bf16cl(const ov_respair_bf16_params* p, ov_stream_t stream);
+int ov_resblock_pair_bf16_supported(int C, int K, int dil);
+
 /* Library/ABI version (major*100 + minor). */
 int ov_version(void);
 /* 0 for a production build; non-zero = a measurement build with parts of the kernels compiled out (results are

@@ -60,6 +60,14 @@ class RespairParams(ctypes.Structure):
                 ("slope", ctypes.c_float), ("scale", ctypes.c_float), ("dbg", _fp)]
 
 
+class RespairBf16Params(ctypes.Structure):
+    """Mirror of ``ov_respair_bf16_params`` (include/openvoice_amd.h)."""
+    _fields_ = [("x", _fp), ("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("out", _fp), ("add", _fp),
+                ("B", ctypes.c_int32), ("L", ctypes.c_int32), ("C", ctypes.c_int32), ("K", ctypes.c_int32),
+                ("dil", ctypes.c_int32), ("nwg", ctypes.c_int32), ("slope", ctypes.c_float), ("scale", ctypes.c_float),
+                ("dbg", _fp)]
+
+
 # name -> (restype, argtypes); kept in one table so tests can check every header symbol exists.
 SIGNATURES = {
     "ov_version": (ctypes.c_int, []),
@@ -82,6 +90,8 @@ SIGNATURES = {
     "ov_conv1d_bf16_pack_size": (ctypes.c_size_t, [_i, _i, _i]),
     "ov_conv1d_bf16_pack": (ctypes.c_int, [_fp, _i, _i, _i, _fp]),
     "ov_conv1d_bf16cl": (ctypes.c_int, [ctypes.POINTER(ConvBf16Params), _fp]),
+    "ov_resblock_pair_bf16cl": (ctypes.c_int, [ctypes.POINTER(RespairBf16Params), _fp]),
+    "ov_resblock_pair_bf16_supported": (ctypes.c_int, [_i, _i, _i]),
     "ov_conv_post_tanh_bf16": (ctypes.c_int, [_fp, _fp, _fp, _i, _i, _i, _i, ctypes.c_float, _fp]),
     "ov_frame_hops_f32": (ctypes.c_int, [_fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
     "ov_embed_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, ctypes.c_float, _fp]),

@@ -42,6 +42,28 @@ def launch_conv_bf16(layer, x, out, in_slope=1.0, scale=1.0, res=None, add=None,
     _lib.check(_lib.load().ov_conv1d_bf16cl(ctypes.byref(p), stream), "ov_conv1d_bf16cl")
 
 
+def launch_pair_bf16(c1, c2, x, out, add=None, scale=1.0, slope=0.1, nwg=0, dbg=None):
+    """One fused ResBlock1 iteration on bf16 channels-last tensors (``ov_resblock_pair_bf16cl``):
+    out = bf16((c2(lrelu(bf16(c1(lrelu(x))))) + x [+ add]) * scale).  x / out / add (B, L, C) contiguous bfloat16;
+    ``out`` must not alias ``x``."""
+    B, L, C = x.shape
+    assert c1.cin == c1.cout == c2.cin == c2.cout == C and c1.K == c2.K and c2.dil == 1 and out.shape == x.shape
+    for t in (x, out, add):
+        assert t is None or (t.dtype == torch.bfloat16 and t.is_contiguous())
+    p = _lib.RespairBf16Params()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    p.x, p.w1, p.b1, p.w2, p.b2, p.out, p.add = vp(x), vp(c1.w), vp(c1.bias), vp(c2.w), vp(c2.bias), vp(out), vp(add)
+    p.B, p.L, p.C, p.K, p.dil, p.nwg = B, L, C, c1.K, c1.dil, nwg
+    p.slope, p.scale = slope, scale
+    p.dbg = vp(dbg)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(_lib.load().ov_resblock_pair_bf16cl(ctypes.byref(p), stream), "ov_resblock_pair_bf16cl")
+
+
+def pair_bf16_supported(C, K, dil):
+    return bool(_lib.load().ov_resblock_pair_bf16_supported(C, K, dil))
+
+
 def _launch(layer, x, out, L, in_slope=1.0, scale=1.0, res=None, add=None, phase_s=0, bias=None, bias_bstride=0):
     B = x.shape[0]
     p = ConvBf16Params()
@@ -54,18 +76,23 @@ def _launch(layer, x, out, L, in_slope=1.0, scale=1.0, res=None, add=None, phase
     _lib.check(_lib.load().ov_conv1d_bf16cl(ctypes.byref(p), stream), "ov_conv1d_bf16cl")
 
 
-def generator_alg_bytes(cfg, B, T, esize=2, z_channels=192):
+def generator_alg_bytes(cfg, B, T, esize=2, z_channels=192, fused=True):
     """Algorithmic HBM bytes of one generator pass: every tensor pass of the launch sequence (conv_pre; per stage
-    the ups read + write and the MRF's 9 x (conv1 r+w, conv2 r+res+w) + 2 running-sum reads; conv_post)."""
+    the ups read + write and the MRF -- per ResBlock pair 2 passes when it is one fused launch (read x, write out),
+    5 as two launches (conv1 r + w, conv2 r + res + w) -- plus the 2 running-sum reads; conv_post)."""
     ch, L = cfg["upsample_initial_channel"], T
     total = B * T * (z_channels + ch) * esize
-    nk, nd = len(cfg["resblock_kernel_sizes"]), len(cfg["resblock_dilation_sizes"][0])
+    kernels, dils = cfg["resblock_kernel_sizes"], cfg["resblock_dilation_sizes"]
     for u in cfg["upsample_rates"]:
         total += B * L * ch * esize
         ch //= 2
         L *= u
         tensor = B * L * ch * esize
-        total += tensor + tensor * (nk * nd * (2 + 3) + (nk - 1))
+        passes = 1                                                  # the ups write
+        for j, (k, rd) in enumerate(zip(kernels, dils)):
+            one = fused and all(pair_bf16_supported(ch, k, d) for d in rd)
+            passes += len(rd) * (2 if one else 5) + (1 if j > 0 else 0)
+        total += tensor * passes
     return total + B * L * ch * esize + B * L * 4
 
 
@@ -104,6 +131,9 @@ class GeneratorBf16:
         self.final_channels = ch
         self.post_w = sd["dec.conv_post.weight"][0].contiguous().to(dev)              # [C, 7] fp32
         self._ws = {}
+        # ResBlock pairs of the HBM-bound stages as ONE launch each (csrc/conv1d_bf16_pair.hip; bit-identical to the two
+        # launches): C = 32 every kernel size, C = 64 K = 3 -- 1.7-2.0x faster than the two launches on MI355X
+        self.fuse_pairs = True
 
     def _workspace(self, B, T):
         key = (B, T)
@@ -144,12 +174,18 @@ class GeneratorBf16:
             t1, ra, acc = (free.pop()[: B * L * ch].view(B, L, ch) for _ in range(3))
             for j, pairs in enumerate(self.resblocks[i]):
                 cur = u
+                fused = self.fuse_pairs and all(pair_bf16_supported(ch, c1.K, c1.dil) for c1, _ in pairs)
                 for n, (c1, c2) in enumerate(pairs):
-                    _launch(c1, cur, t1, L, in_slope=LRELU_SLOPE)
                     last = n == len(pairs) - 1
-                    dst = acc if last else ra
-                    _launch(c2, t1, dst, L, in_slope=LRELU_SLOPE, res=cur, add=acc if (last and j > 0) else None,
-                            scale=1.0 / nk if (last and j == nk - 1) else 1.0)
+                    add = acc if (last and j > 0) else None
+                    scale = 1.0 / nk if (last and j == nk - 1) else 1.0
+                    if fused:      # one launch per pair, intermediate in LDS; out must not alias x: ra / t1 ping-pong
+                        dst = acc if last else (t1 if cur is ra else ra)
+                        launch_pair_bf16(c1, c2, cur, dst, add=add, scale=scale, slope=LRELU_SLOPE)
+                    else:
+                        _launch(c1, cur, t1, L, in_slope=LRELU_SLOPE)
+                        dst = acc if last else ra
+                        _launch(c2, t1, dst, L, in_slope=LRELU_SLOPE, res=cur, add=add, scale=scale)
                     cur = dst
             # every scratch buffer except the one holding this stage's output is free again
             free = [buf for buf in ws["dec"] if buf.data_ptr() != acc.data_ptr()]

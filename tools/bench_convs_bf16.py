@@ -13,12 +13,40 @@ from openvoice_amd.bf16 import PackedConvBf16, launch_conv_bf16  # noqa: E402
 from bench_convs import timed  # noqa: E402
 
 
+def pair_table(args):
+    from openvoice_amd.bf16 import launch_pair_bf16, pair_bf16_supported
+    dev, B = "cuda:0", args.batch
+    print(f"B={B}: fused bf16 pair vs c1 + c2 launches; GB/s = algorithmic bytes of the FUSED form (x + out) / time")
+    print(f"{'C':>4} {'L':>7} {'k':>2} {'d':>1} {'pair ms':>8} {'GB/s':>7} {'c1+c2 ms':>9}")
+    for c, L in [(64, 110208), (32, 220416)]:
+        x = torch.randn(B, L, c, device=dev).to(torch.bfloat16)
+        t, out = torch.empty_like(x), torch.empty_like(x)
+        for k in (3, 7, 11):
+            for d in (1, 5):
+                if not pair_bf16_supported(c, k, d):
+                    continue
+                c1 = PackedConvBf16(torch.randn(c, c, k) * (c * k) ** -0.5, torch.zeros(c), dev, dil=d)
+                c2 = PackedConvBf16(torch.randn(c, c, k) * (c * k) ** -0.5, torch.zeros(c), dev, dil=1)
+
+                def two():
+                    launch_conv_bf16(c1, x, t, in_slope=0.1)
+                    launch_conv_bf16(c2, t, out, in_slope=0.1, res=x)
+                ms = timed(lambda: launch_pair_bf16(c1, c2, x, out), args.reps, 100.0)
+                ms2 = timed(two, args.reps, 100.0)
+                print(f"{c:>4} {L:>7} {k:>2} {d:>1} {ms:8.3f} {2 * 2.0 * B * c * L / ms / 1e6:7.0f} {ms2:9.3f}", flush=True)
+        del x, t, out
+    print("done")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--layouts", type=int, nargs="+", default=[0])
+    ap.add_argument("--pair", action="store_true", help="time the fused ResBlock pair against its two launches only")
     args = ap.parse_args()
+    if args.pair:
+        return pair_table(args)
     dev, B = "cuda:0", args.batch
     print(f"B={B}  (HBM peak 8000 GB/s spec, ~6300 achievable; bf16 MFMA peak 2500 TF/s)")
     print(f"{'C':>4} {'L':>7} {'k':>2} {'d':>1} {'epi':>8} {'ms':>8} {'GB/s':>8} {'TF/s':>7}")
