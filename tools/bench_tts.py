@@ -53,10 +53,23 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
     frames = int(y_mask.sum())
     audio_s = frames * 256 / 22050.0
+    # Algorithmic FLOPs (2 x MACs of the convs; SURVEY.md section 8d's per-frame hand count): the generator and the
+    # reverse flow run at FRAME rate on the padded batch (B x max frames), the text encoder / duration predictors at
+    # token rate (enc_p 4.4, sdp 0.33, dp 0.21 GFLOP per ~100-symbol utterance).
+    Ty = int(y_mask.shape[2])
+    per_frame = 614.8e6 + 4 * 3.54e6            # generator + 4 coupling layers (one flow direction)
+    flops = per_frame * B * Ty + (4.4e9 + 0.33e9 + 0.21e9) * B * Tx / 100.0
     out = {"workload": f"SynthesizerTrn.infer, batch {B} x {Tx} symbols, fp32, synthetic weights",
            "ms_per_batch": round(dt * 1e3, 3), "utterances_per_s": round(B / dt, 2),
            "audio_s_per_batch": round(audio_s, 2), "real_time_factor": round(audio_s / dt, 1),
-           "frames_per_utterance": round(frames / B, 1)}
+           "frames_per_utterance": round(frames / B, 1), "padded_frames": Ty,
+           "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
+                        "frac": round(flops / dt / 157.3e12, 4), "alg_tflop_per_batch": round(flops / 1e12, 3),
+                        "note": "whole infer() incl. its host sync (Ty = y_lengths.max(), as in the reference, "
+                                "models.py:478-480) and the token-rate kernels; the frame-rate convs of this batch "
+                                "run at ~55 % of peak vs 82-88 % in the converter bench: 3 760 frames per batch "
+                                "(1-4 tiles per workgroup slot per launch) and a GPU that never reaches its sustained "
+                                "clock inside a 33 ms call -- profiles/r02_tts_kernel_trace_analysis.txt"}}
     if args.cpu:
         from oracle import tts_oracle
         from openvoice_amd.hostinfo import usable_cpus
