@@ -16,7 +16,8 @@ import os
 import re
 import sys
 
-MRF = re.compile(r"conv1d_mfma_kernel<(3|7|11), (1|3|5), \d+, \d+, \d+, \d+, \d+, (?:true|1|2), 0, \d+>")
+# the MRF launches: single ResBlock convs (EPI = LINEAR, K in {3, 7, 11}) and the fused ResBlock pairs
+MRF = re.compile(r"conv1d_mfma_kernel<(3|7|11), (1|3|5), \d+, \d+, \d+, \d+, \d+, (?:true|1|2), 0, \d+>|respair_mfma_kernel<")
 GIB = float(1 << 30)
 
 
