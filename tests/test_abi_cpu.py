@@ -147,3 +147,37 @@ def test_respair_params_struct_matches_header_field_order_and_size():
     lib = _lib.load()
     assert lib.ov_resblock_pair_f32(None, None) == -1
     assert lib.ov_resblock_pair_supported(32, 3, 1) == 1 and lib.ov_resblock_pair_supported(128, 3, 1) == 0
+
+
+def test_respair_bf16_params_struct_matches_header_field_order():
+    header = open(os.path.join(REPO, "include", "openvoice_amd.h")).read()
+    body = header[header.index("typedef struct ov_respair_bf16_params {"):header.index("} ov_respair_bf16_params;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        first, *rest = decl.split(",")
+        names.append(re.findall(r"(\w+)$", first.strip())[0])
+        names += [r.strip() for r in rest]
+    assert names == [f[0] for f in _lib.RespairBf16Params._fields_]
+    lib = _lib.load()
+    assert lib.ov_resblock_pair_bf16cl(None, None) == -1
+    assert lib.ov_resblock_pair_bf16_supported(32, 11, 5) == 1 and lib.ov_resblock_pair_bf16_supported(64, 7, 1) == 0
+
+
+def test_every_header_function_is_bound_and_exported():
+    """Every `int|size_t ov_*(...)` declared in include/openvoice_amd.h is in _lib.SIGNATURES and exported by the .so."""
+    header = open(os.path.join(REPO, "include", "openvoice_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"^(?:int|size_t)\s+(ov_\w+)\s*\(", header, flags=re.M))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+
+
+def test_production_library_is_not_a_measurement_build():
+    assert _lib.load().ov_build_experiment() == 0
