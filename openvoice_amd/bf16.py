@@ -26,7 +26,7 @@ class PackedConvBf16:
         self.bias = None if bias is None else bias.detach().float().contiguous().to(device)
 
 
-def launch_conv_bf16(layer, x, out, in_slope=1.0, scale=1.0, res=None, add=None, layout=0):
+def launch_conv_bf16(layer, x, out, in_slope=1.0, scale=1.0, res=None, add=None, layout=0, out_slope=1.0):
     """out = (conv1d(lrelu(x, in_slope)) + bias [+ res] [+ add]) * scale on torch's current stream.
     x (B, L, Cin), out / res / add (B, L, Cout), all contiguous bfloat16."""
     B, L, cin = x.shape
@@ -37,7 +37,7 @@ def launch_conv_bf16(layer, x, out, in_slope=1.0, scale=1.0, res=None, add=None,
     vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     p.x, p.w, p.bias, p.out, p.res, p.add = vp(x), vp(layer.w), vp(layer.bias), vp(out), vp(res), vp(add)
     p.B, p.L, p.Cin, p.Cout, p.K, p.dil = B, L, cin, layer.cout, layer.K, layer.dil
-    p.in_slope, p.scale, p.layout = in_slope, scale, layout
+    p.in_slope, p.scale, p.layout, p.out_slope = in_slope, scale, layout, out_slope
     stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(_lib.load().ov_conv1d_bf16cl(ctypes.byref(p), stream), "ov_conv1d_bf16cl")
 
@@ -64,14 +64,15 @@ def pair_bf16_supported(C, K, dil):
     return bool(_lib.load().ov_resblock_pair_bf16_supported(C, K, dil))
 
 
-def _launch(layer, x, out, L, in_slope=1.0, scale=1.0, res=None, add=None, phase_s=0, bias=None, bias_bstride=0):
+def _launch(layer, x, out, L, in_slope=1.0, scale=1.0, res=None, add=None, phase_s=0, bias=None, bias_bstride=0,
+            out_slope=1.0):
     B = x.shape[0]
     p = ConvBf16Params()
     vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     bias = layer.bias if bias is None else bias
     p.x, p.w, p.bias, p.out, p.res, p.add = vp(x), vp(layer.w), vp(bias), vp(out), vp(res), vp(add)
     p.B, p.L, p.Cin, p.Cout, p.K, p.dil = B, L, layer.cin, layer.cout, layer.K, layer.dil
-    p.phase_s, p.bias_bstride, p.in_slope, p.scale = phase_s, bias_bstride, in_slope, scale
+    p.phase_s, p.bias_bstride, p.in_slope, p.scale, p.out_slope = phase_s, bias_bstride, in_slope, scale, out_slope
     stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(_lib.load().ov_conv1d_bf16cl(ctypes.byref(p), stream), "ov_conv1d_bf16cl")
 
@@ -183,9 +184,11 @@ class GeneratorBf16:
                         dst = acc if last else (t1 if cur is ra else ra)
                         launch_pair_bf16(c1, c2, cur, dst, add=add, scale=scale, slope=LRELU_SLOPE)
                     else:
-                        _launch(c1, cur, t1, L, in_slope=LRELU_SLOPE)
+                        # t1 is consumed by c2 only, which activates it: store it activated (one rounding instead of
+                        # two) and let c2's loaders copy it as is
+                        _launch(c1, cur, t1, L, in_slope=LRELU_SLOPE, out_slope=LRELU_SLOPE)
                         dst = acc if last else ra
-                        _launch(c2, t1, dst, L, in_slope=LRELU_SLOPE, res=cur, add=add, scale=scale)
+                        _launch(c2, t1, dst, L, in_slope=1.0, res=cur, add=add, scale=scale)
                     cur = dst
             # every scratch buffer except the one holding this stage's output is free again
             free = [buf for buf in ws["dec"] if buf.data_ptr() != acc.data_ptr()]

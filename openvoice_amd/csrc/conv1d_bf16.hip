@@ -30,7 +30,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CH = 32;          // input channels per LDS chunk = 2 MFMA k-blocks
 constexpr int PITCH = 80;       // bytes per LDS row: 64 data + 16 pad
-constexpr int NLD = 2;          // loader waves
 
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
 __device__ __forceinline__ uint16_t f2bf(float f) {
@@ -41,7 +40,10 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 }
 
 // WM x WN fragments of 32x32 per matrix wave; WVT x WVC matrix waves (time x channel) per workgroup.
-template <int K, int DIL, int WM, int WN, int WVT, int WVC>
+// DEEP: weight fragments are requested WDEPTH - 1 k-steps ahead instead of one (see the main loop); needs an even
+// number of 32-channel chunks (Cin % 64 == 0).
+// NLD: loader waves (2 or 4).
+template <int K, int DIL, int WM, int WN, int WVT, int WVC, bool DEEP, int NLD>
 __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_conv1d_bf16_params p) {
   static_assert(WVT * WVC == 4, "4 matrix waves");
   constexpr int TT = 32 * WM * WVT;             // time rows per workgroup
@@ -147,13 +149,70 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
 #pragma unroll
   for (int n = 0; n < WN; ++n) widx[n] = (uint32_t)(ntile0 + n) * (uint32_t)(nchunks * K * 2) * 64u + (uint32_t)lane;
 
-  // Weight fragments are requested one k-block ahead.  (Measured: a 4-deep request queue costs 24-40 VGPRs,
-  // drops a workgroup per CU and is slower overall -- 69 ms vs 61 ms per batch-64 generator.)
+  // per-lane LDS byte offset of the A operand: row (trow0 + lane & 31), k-slot half
+  const int xl_off = (trow0 + l31) * PITCH + half * 16;
+
+  if constexpr (DEEP) {
+    // Weight fragments are a continuous stream of 1 KiB records (chunk, tap, k-block), requested WDEPTH - 1 k-steps
+    // ahead into a ring of WDEPTH register sets.  One k-step is only WM MFMAs (128-256 cycles of a SIMD's matrix
+    // pipe) against a ~700-cycle L2 round trip: with the round-1 one-step-ahead request every k-step waited ~500
+    // cycles for its fragment (C >= 128 ran at 32-37 % of the bf16 MFMA peak).  The loop is unrolled over chunk
+    // PAIRS so that the ring slot of every step is a compile-time constant (2 * STEPS % WDEPTH == 0) and hipcc's
+    // s_waitcnt insertion waits for the oldest request only (vmcnt(WDEPTH - 2)); a 4-deep queue with a run-time slot
+    // (round 1) cost 24-40 VGPRs and a workgroup per CU.
+    constexpr int STEPS = 2 * K, WDEPTH = 4;
+    static_assert((2 * STEPS) % WDEPTH == 0, "ring slot must be static across a chunk pair");
+    const int total = nchunks * STEPS;                          // records of one output tile; record `total` exists
+    u32x4 bq[WDEPTH][WN];                                       // (next tile's first record, or the packer's zero record)
+    auto wload = [&](int g, u32x4 (&dst)[WN]) {
+      const int r = min(g, total);
+#pragma unroll
+      for (int n = 0; n < WN; ++n)
+        dst[n] = (ntile0 + n) < ntiles_co ? (wbase + (size_t)r * 64)[widx[n]] : u32x4{0u, 0u, 0u, 0u};
+    };
+#pragma unroll
+    for (int q = 0; q < WDEPTH - 1; ++q) wload(q, bq[q]);
+    for (int c = 0; c < nchunks; c += 2) {
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        __syncthreads();
+        const unsigned char* xl = xs + ((c + cc) & 1) * BUF + xl_off;
+        u32x4 acur[WM], anxt[WM];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) acur[i] = *reinterpret_cast<const u32x4*>(xl + (32 * i) * PITCH);   // tap 0, kb 0
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+          const int gs = cc * STEPS + s;                          // step inside the chunk pair: static
+          wload((c + cc) * STEPS + s + WDEPTH - 1, bq[(gs + WDEPTH - 1) % WDEPTH]);
+          if (s + 1 < STEPS) {
+            const int tap = (s + 1) >> 1, kb = (s + 1) & 1;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+              anxt[i] = *reinterpret_cast<const u32x4*>(xl + (32 * i + tap * DIL) * PITCH + kb * 32);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int n = 0; n < WN; ++n) {
+              bf16x8 av, bv;
+              __builtin_memcpy(&av, &acur[i], 16);
+              __builtin_memcpy(&bv, &bq[gs % WDEPTH][n], 16);
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][n], 0, 0, 0);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+          if (s + 1 < STEPS) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i) acur[i] = anxt[i];
+          }
+        }
+      }
+    }
+  } else {
+  // Weight fragments are requested one k-block ahead.
   u32x4 bcur[WN], bnxt[WN];
 #pragma unroll
   for (int n = 0; n < WN; ++n) bcur[n] = (ntile0 + n) < ntiles_co ? wbase[widx[n]] : u32x4{0u, 0u, 0u, 0u};
-  // per-lane LDS byte offset of the A operand: row (trow0 + lane & 31), k-slot half
-  const int xl_off = (trow0 + l31) * PITCH + half * 16;
 
   int rec = 0;
   for (int c = 0; c < nchunks; ++c) {
@@ -194,6 +253,7 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
       }
     }
   }
+  }
 
   // ---- identity rounds: acc += res, acc += add ----------------------------------------------------------
   for (int rd = rounds_x; rd < rounds; ++rd) {
@@ -231,6 +291,7 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
   const int Creal = Cout / s_ph;
   uint16_t* outb = p.out + (int64_t)b * L * Cout;           // L * s_ph rows of Creal channels
   const float scale = p.scale;
+  const float oslope = p.out_slope > 0.f ? p.out_slope : 1.f;   // 0 (old callers) = none
 #pragma unroll
   for (int n = 0; n < WN; ++n) {
     const int col = 32 * (ntile0 + n) + l31;
@@ -241,7 +302,11 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int t = t0 + trow0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (t < L) outb[((int64_t)t * s_ph + ph) * Creal + co] = f2bf(acc[i][n][r] * scale);
+        if (t < L) {
+          float v = acc[i][n][r] * scale;
+          v = v > 0.f ? v : v * oslope;      // optional activation on the way out (its only consumer applies it anyway)
+          outb[((int64_t)t * s_ph + ph) * Creal + co] = f2bf(v);
+        }
       }
     }
   }
@@ -251,7 +316,20 @@ template <int K, int DIL, int WM, int WN, int WVT, int WVC>
 int launch(const ov_conv1d_bf16_params* p, hipStream_t stream) {
   constexpr int TT = 32 * WM * WVT, NB = 32 * WN * WVC;
   dim3 grid((p->L + TT - 1) / TT, p->B, (p->Cout + NB - 1) / NB);
-  hipLaunchKernelGGL((conv1d_bf16cl_kernel<K, DIL, WM, WN, WVT, WVC>), grid, dim3(64 * (4 + NLD)), 0, stream, *p);
+  // Deep weight prefetch for Cout > 64 (C = 64 measured 5-20 % slower with it); layout 2 = the one-step-ahead request
+  // of round 1 (measurement knob).  Loader waves: the staging pass costs ~350 instructions per lane and item (unpack,
+  // leaky-ReLU, repack) -- with 2 loader waves that is longer than a K = 3 chunk's MFMAs and than an identity round, so
+  // K = 3 and every launch with a residual get 4 (measured: -8...-18 % there, +3...+9 % on plain K >= 7 launches).
+  const bool deep = p->Cin % (2 * CH) == 0 && p->Cout > 64 && p->layout != 2;
+  const bool four = (K == 3 || p->res != nullptr) && p->layout != 2;
+  const dim3 grid2 = grid;
+#define OV16_GO(DEEP_, NLD_) \
+  hipLaunchKernelGGL((conv1d_bf16cl_kernel<K, DIL, WM, WN, WVT, WVC, DEEP_, NLD_>), grid2, dim3(64 * (4 + NLD_)), 0, stream, *p)
+  if (deep && four) OV16_GO(true, 4);
+  else if (deep) OV16_GO(true, 2);
+  else if (four) OV16_GO(false, 4);
+  else OV16_GO(false, 2);
+#undef OV16_GO
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
 }
 
@@ -262,6 +340,8 @@ int launch(const ov_conv1d_bf16_params* p, hipStream_t stream) {
 // (wider outputs in N-blocks); 64 -> 256 t x 64 co; 32 -> 256 t x 32 co (4 waves along time in both).
 template <int K, int DIL>
 int launch_by_width(const ov_conv1d_bf16_params* p, hipStream_t stream) {
+  if (p->Cout > 64 && p->layout == 3)       // measurement: 128 t x 64 co per wave (half the LDS operand reads per MFMA)
+    return p->Cout % 256 == 0 ? launch<K, DIL, 4, 2, 1, 4>(p, stream) : launch<K, DIL, 4, 2, 2, 2>(p, stream);
   if (p->Cout > 64) return p->layout == 1 ? launch<K, DIL, 2, 2, 2, 2>(p, stream) : launch<K, DIL, 4, 1, 1, 4>(p, stream);
   if (p->Cout > 32) return launch<K, DIL, 2, 2, 4, 1>(p, stream);
   return launch<K, DIL, 2, 1, 4, 1>(p, stream);

@@ -50,6 +50,27 @@ def test_plain_conv_bf16_no_bias_no_residual():
     assert (out.float().cpu() - ref).abs().max().item() <= 1e-2 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("c,k,d", [(128, 7, 3), (64, 3, 1), (256, 11, 5)])
+def test_conv_bf16_output_activation(c, k, d):
+    """``out_slope``: the leaky ReLU of a tensor's only consumer applied before the output rounding (conv1 of a ResBlock
+    pair on the two-launch path), and that consumer staging it with ``in_slope = 1`` (a plain copy)."""
+    B, L = 2, 700
+    x = _r(_rand(B, L, c, seed=1))
+    w1, b1 = _r(_rand(c, c, k, seed=2, scale=(c * k) ** -0.5)), _rand(c, seed=3, scale=0.1)
+    w2, b2 = _r(_rand(c, c, k, seed=4, scale=(c * k) ** -0.5)), _rand(c, seed=5, scale=0.1)
+    t_ref = _r(F.leaky_relu(F.conv1d(_r(F.leaky_relu(x, 0.1)).transpose(1, 2), w1, b1, dilation=d,
+                                     padding=(k - 1) * d // 2), 0.1))
+    ref = (F.conv1d(t_ref, w2, b2, padding=(k - 1) // 2) + x.transpose(1, 2)).transpose(1, 2)
+    c1, c2 = PackedConvBf16(w1, b1, DEV, dil=d), PackedConvBf16(w2, b2, DEV, dil=1)
+    xd = x.to(DEV, torch.bfloat16)
+    t = torch.full_like(xd, float("nan"))
+    out = torch.full_like(xd, float("nan"))
+    launch_conv_bf16(c1, xd, t, in_slope=0.1, out_slope=0.1)
+    launch_conv_bf16(c2, t, out, in_slope=1.0, res=xd)
+    assert (t.float().cpu() - t_ref.transpose(1, 2)).abs().max().item() <= 1e-2 * max(1.0, t_ref.abs().max().item())
+    assert (out.float().cpu() - ref).abs().max().item() <= 1e-2 * max(1.0, ref.abs().max().item())
+
+
 def test_conv_transpose_and_batch_bias_bf16():
     """ups as a phase conv with (phase, channel) column order, and conv_pre's per-utterance bias over 512 columns
     (two N-blocks)."""
