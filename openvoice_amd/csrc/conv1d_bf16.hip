@@ -285,6 +285,10 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
   }
 
   // ---- epilogue: scale, round to bf16, store channels-last (32 lanes = 64 contiguous bytes) -------------
+  // (Measured and dropped in round 2: issuing the MFMAs transposed, as the fused-pair kernel does, so that a lane
+  // holds 4 x 4 consecutive channels of ONE time row and stores 8 bytes at a time -- a quarter of the store
+  // instructions, but each touching 32 rows x 16 B instead of 2 rows x 64 B: no faster on any shape here, within the
+  // +-3 % box-to-box spread, profiles/r02_s10_bf16_convs.txt.)
   // ConvTranspose (phase_s > 1): column n = phase * C + c of the phase conv is channel c of output row
   // t * phase_s + phase (a 32-column tile never straddles a phase because C % 32 == 0).
   const int s_ph = p.phase_s > 1 ? p.phase_s : 1;
