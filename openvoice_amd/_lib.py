@@ -139,3 +139,28 @@ def load():
 def check(code, what):
     if code != OV_OK:
         raise OvError(f"{what} failed: {OV_ERRORS.get(code, code)}")
+
+
+# ---- the torch binding (csrc/torch_shim.cpp): `torch.ops.openvoice_amd.*` -------------------------------------------
+SHIM_PATH = os.path.join(_HERE, "libopenvoice_amd_torch.so")
+_ops = None
+
+
+def use_torch_binding():
+    """True when launches go through ``torch.ops.openvoice_amd`` (TORCH_LIBRARY shim: current-stream pickup,
+    TORCH_CHECK errors) instead of ctypes.  Selected with OPENVOICE_AMD_BINDING=torch; both bindings drive the same
+    C ABI with the same arguments."""
+    return os.environ.get("OPENVOICE_AMD_BINDING", "ctypes") == "torch"
+
+
+def torch_ops():
+    """Load (once) the shim and return ``torch.ops.openvoice_amd``; raises if it was not built."""
+    global _ops
+    if _ops is None:
+        import torch
+        load()                       # libopenvoice_amd.so first: the shim links against it by soname
+        if not os.path.exists(SHIM_PATH):
+            raise OvError(f"{SHIM_PATH} not found: make -C openvoice_amd/csrc torch_shim")
+        torch.ops.load_library(SHIM_PATH)
+        _ops = torch.ops.openvoice_amd
+    return _ops

@@ -131,6 +131,12 @@ def launch_conv(layer, x, x_off, x_bs, out, out_off, out_bs, B, L, epi=EPI_LINEA
                 x_ld=0, out_ld=0, mask_bs=0, tile=0, loaders=0, chunk=0):
     """Fill ``ov_conv1d_params`` and launch on torch's current stream of ``x``'s device.
     Offsets, row strides (``*_ld``, 0 = dense) and batch strides are in elements."""
+    if _lib.use_torch_binding():
+        ip = [B, layer.cin if cin is None else cin, L, x_ld, out_ld, layer.rows if rows is None else rows, layer.cout,
+              layer.K, layer.dil, epi, flags, split, phase_s, tiles_per_wg, tile, loaders, chunk,
+              x_bs, out_bs, res_bs, add_bs, out2_bs, bias_b_bs, mask_bs, x_off, out_off, res_off, bias_b_off]
+        _lib.torch_ops().conv1d(x, layer.w, layer.bias, out, res, add, out2, mask, bias_b, ip, [in_slope, scale])
+        return
     p = ConvParams()
     p.x, p.w = _ptr(x, x_off), _ptr(layer.w)
     p.bias = _ptr(layer.bias)        # zeros when the layer has no bias (the kernel always adds it)
@@ -157,6 +163,10 @@ def launch_pair(c1, c2, x, x_bs, out, out_bs, B, L, add=None, add_bs=0, scale=1.
                 dbg=None):
     """One fused ResBlock1 iteration (``ov_resblock_pair_f32``): out = (c2(lrelu(c1(lrelu(x)))) + x [+ add]) * scale.
     ``c1`` / ``c2`` are the ``PackedConv`` layers of the two convs; ``out`` must not alias ``x``."""
+    if _lib.use_torch_binding() and dbg is None and nwg == 0:
+        _lib.torch_ops().resblock_pair(x, c1.w, c1.bias, c2.w, c2.bias, out, add, B, c1.cin, L, ld, c1.K, c1.dil,
+                                       x_bs, out_bs, add_bs, slope, scale)
+        return
     p = _lib.RespairParams()
     p.x, p.w1, p.b1, p.w2, p.b2 = _ptr(x), _ptr(c1.w), _ptr(c1.bias), _ptr(c2.w), _ptr(c2.bias)
     p.out = _ptr(out)
@@ -326,6 +336,8 @@ class ConverterEngine:
         self.profile.append(("mrf", 2 * 2.0 * c1.rows * c1.cin * c1.K * L * B, e0, e1))
 
     def _linear(self, x2d, w, b):
+        if _lib.use_torch_binding():
+            return _lib.torch_ops().linear(x2d, w, b)
         Bg, Kd = x2d.shape
         M = w.shape[0]
         y = torch.empty(Bg, M, dtype=torch.float32, device=self.device)
@@ -412,9 +424,11 @@ class ConverterEngine:
         ws = self._workspace(B, T)
         Tp, mask = ws["Tp"], ws["mask"]
         ws["noise"][:, :, :T].copy_(noise.to(dev, torch.float32))     # into the padded-row layout
-        st = self._stream()
-        _lib.check(self.lib.ov_sequence_mask_f32(ctypes.c_void_p(lengths.data_ptr()), _ptr(mask), B, T, Tp, st),
-                   "ov_sequence_mask_f32")
+        if _lib.use_torch_binding():
+            _lib.torch_ops().sequence_mask(lengths, mask, B, T, Tp)
+        else:
+            _lib.check(self.lib.ov_sequence_mask_f32(ctypes.c_void_p(lengths.data_ptr()), _ptr(mask), B, T, Tp,
+                                                     self._stream()), "ov_sequence_mask_f32")
         # conditioning GEMVs (T = 1): modules.py:189-190 for every WN, models.py:275 for the decoder
         g_q = torch.zeros_like(g_src) if self.zero_g else g_src
         g_d = torch.zeros_like(g_tgt) if self.zero_g else g_tgt
@@ -534,9 +548,13 @@ class ConverterEngine:
             free += [u, t1, ra]
             x = acc
         o_hat = torch.empty(B, 1, L, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.ov_conv_post_tanh_f32(_ptr(x), _ptr(self.post_w), _ptr(o_hat), B, ch, L,
-                                                  self.post_w.shape[1], FINAL_LRELU_SLOPE, self._stream()),
-                   "ov_conv_post_tanh_f32")
+        if _lib.use_torch_binding():
+            _lib.torch_ops().conv_post_tanh(x[: B * ch * L], self.post_w, o_hat, B, ch, L, self.post_w.shape[1],
+                                            FINAL_LRELU_SLOPE)
+        else:
+            _lib.check(self.lib.ov_conv_post_tanh_f32(_ptr(x), _ptr(self.post_w), _ptr(o_hat), B, ch, L,
+                                                      self.post_w.shape[1], FINAL_LRELU_SLOPE, self._stream()),
+                       "ov_conv_post_tanh_f32")
         return o_hat
 
     # ---- extract_se path -----------------------------------------------------------------------------

@@ -181,3 +181,14 @@ def test_every_header_function_is_bound_and_exported():
 
 def test_production_library_is_not_a_measurement_build():
     assert _lib.load().ov_build_experiment() == 0
+
+
+def test_torch_binding_loads_without_a_gpu_and_rejects_cpu_tensors():
+    """openvoice_amd/libopenvoice_amd_torch.so (csrc/torch_shim.cpp): TORCH_LIBRARY ops over the same C ABI."""
+    import torch
+    ops = _lib.torch_ops()
+    assert ops.version() == _lib.load().ov_version()
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        ops.linear(torch.zeros(2, 4), torch.zeros(3, 4), torch.zeros(3))
+    with pytest.raises(RuntimeError, match="on device"):
+        ops.sequence_mask(torch.zeros(2, dtype=torch.long), torch.zeros(2, 8), 2, 8, 8)
