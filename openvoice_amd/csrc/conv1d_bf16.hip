@@ -177,9 +177,9 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
       for (int cc = 0; cc < 2; ++cc) {
         __syncthreads();
         const unsigned char* xl = xs + ((c + cc) & 1) * BUF + xl_off;
-        u32x4 acur[WM], anxt[WM];
+        u32x4 aq[2][WM];          // A operands of the current / next k-step, alternating by step parity (no copies)
 #pragma unroll
-        for (int i = 0; i < WM; ++i) acur[i] = *reinterpret_cast<const u32x4*>(xl + (32 * i) * PITCH);   // tap 0, kb 0
+        for (int i = 0; i < WM; ++i) aq[0][i] = *reinterpret_cast<const u32x4*>(xl + (32 * i) * PITCH);   // tap 0, kb 0
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
           const int gs = cc * STEPS + s;                          // step inside the chunk pair: static
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
             const int tap = (s + 1) >> 1, kb = (s + 1) & 1;
 #pragma unroll
             for (int i = 0; i < WM; ++i)
-              anxt[i] = *reinterpret_cast<const u32x4*>(xl + (32 * i + tap * DIL) * PITCH + kb * 32);
+              aq[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(xl + (32 * i + tap * DIL) * PITCH + kb * 32);
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -196,15 +196,11 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
 #pragma unroll
             for (int n = 0; n < WN; ++n) {
               bf16x8 av, bv;
-              __builtin_memcpy(&av, &acur[i], 16);
+              __builtin_memcpy(&av, &aq[s & 1][i], 16);
               __builtin_memcpy(&bv, &bq[gs % WDEPTH][n], 16);
               acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][n], 0, 0, 0);
             }
           __builtin_amdgcn_sched_barrier(0);
-          if (s + 1 < STEPS) {
-#pragma unroll
-            for (int i = 0; i < WM; ++i) acur[i] = anxt[i];
-          }
         }
       }
     }
@@ -219,9 +215,9 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
     __syncthreads();
     const unsigned char* xl = xs + (c & 1) * BUF + xl_off;
     constexpr int STEPS = 2 * K;                            // (tap, k-block) pairs of one chunk
-    u32x4 acur[WM], anxt[WM];
+    u32x4 aq[2][WM];          // A operands of the current / next k-step, alternating by step parity (no copies)
 #pragma unroll
-    for (int i = 0; i < WM; ++i) acur[i] = *reinterpret_cast<const u32x4*>(xl + (32 * i) * PITCH);   // tap 0, kb 0
+    for (int i = 0; i < WM; ++i) aq[0][i] = *reinterpret_cast<const u32x4*>(xl + (32 * i) * PITCH);   // tap 0, kb 0
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       ++rec;   // one zero record per output tile is appended by the packer for the final prefetch
@@ -232,7 +228,7 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
         const int tap = (s + 1) >> 1, kb = (s + 1) & 1;
 #pragma unroll
         for (int i = 0; i < WM; ++i)
-          anxt[i] = *reinterpret_cast<const u32x4*>(xl + (32 * i + tap * DIL) * PITCH + kb * 32);
+          aq[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(xl + (32 * i + tap * DIL) * PITCH + kb * 32);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -240,17 +236,13 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
 #pragma unroll
         for (int n = 0; n < WN; ++n) {
           bf16x8 av, bv;
-          __builtin_memcpy(&av, &acur[i], 16);
+          __builtin_memcpy(&av, &aq[s & 1][i], 16);
           __builtin_memcpy(&bv, &bcur[n], 16);
           acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][n], 0, 0, 0);
         }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int n = 0; n < WN; ++n) bcur[n] = bnxt[n];
-      if (s + 1 < STEPS) {
-#pragma unroll
-        for (int i = 0; i < WM; ++i) acur[i] = anxt[i];
-      }
     }
   }
   }
