@@ -137,3 +137,48 @@ def test_pair_refuses_what_it_cannot_do():
     assert not pair_supported(128, 3, 1)
     with pytest.raises(_lib.OvError):       # no instance: the caller must issue the two launches itself
         launch_pair(c1b, c2b, xb, 128 * 64, torch.zeros_like(xb), 128 * 64, 1, 64)
+
+
+@pytest.mark.parametrize("name", ["resblock1_c32_k3", "resblock1_c32_k11", "resblock1_c64_k7"])
+def test_three_fused_pairs_match_the_reference_resblock1_module(golden_dir, name):
+    """tests/golden/resblock1_*.pt = the UNMODIFIED reference ``ResBlock1.forward`` (openvoice/modules.py:221-309) on a
+    seeded input with random weight-norm parameters (oracle/make_resblock_golden.py).  Three fused launches -- weight-norm
+    folded by ``params.effective_weight`` -- must reproduce the module; so must the two-launch path; the bf16 kernels
+    within the bf16 path's tolerance."""
+    import os
+    from openvoice_amd.params import effective_weight
+    rec = torch.load(os.path.join(golden_dir, name + ".pt"), weights_only=False)
+    case, sd, x = rec["case"], rec["state_dict"], rec["x"]
+    c, k, B, L = case["C"], case["K"], case["B"], case["L"]
+    layers = [(PackedConv(effective_weight(sd, f"convs1.{i}"), sd[f"convs1.{i}.bias"], DEV, K=k, dil=d),
+               PackedConv(effective_weight(sd, f"convs2.{i}"), sd[f"convs2.{i}.bias"], DEV, K=k, dil=1))
+              for i, d in enumerate((1, 3, 5))]
+    fused = all(pair_supported(c, k, d) for d in (1, 3, 5))
+    cur = x.to(DEV)
+    for n, (c1, c2) in enumerate(layers):
+        nxt = torch.full_like(cur, float("nan"))
+        if fused:
+            launch_pair(c1, c2, cur, c * L, nxt, c * L, B, L)
+        else:
+            nxt = _two_launches(c1, c2, cur, B, c, L)
+        if n == 0:
+            _close(nxt, rec["after_pair0"])
+        cur = nxt
+    _close(cur, rec["out"], tol=3e-5)
+    # bf16 twin (channels-last): within the bf16 path's stated tolerance of the fp32 module
+    from openvoice_amd.bf16 import PackedConvBf16, launch_conv_bf16, launch_pair_bf16, pair_bf16_supported
+    l16 = [(PackedConvBf16(effective_weight(sd, f"convs1.{i}"), sd[f"convs1.{i}.bias"], DEV, dil=d),
+            PackedConvBf16(effective_weight(sd, f"convs2.{i}"), sd[f"convs2.{i}.bias"], DEV, dil=1))
+           for i, d in enumerate((1, 3, 5))]
+    cur = x.transpose(1, 2).contiguous().to(DEV, torch.bfloat16)
+    for d, (c1, c2) in zip((1, 3, 5), l16):
+        nxt = torch.full_like(cur, float("nan"))
+        if pair_bf16_supported(c, k, d):
+            launch_pair_bf16(c1, c2, cur, nxt)
+        else:
+            t = torch.empty_like(cur)
+            launch_conv_bf16(c1, cur, t, in_slope=0.1)
+            launch_conv_bf16(c2, t, nxt, in_slope=0.1, res=cur)
+        cur = nxt
+    err = (cur.float().cpu().transpose(1, 2) - rec["out"]).abs().max().item()
+    assert err <= 3e-2 * rec["out"].abs().max().item(), err
