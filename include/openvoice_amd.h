@@ -168,6 +168,56 @@ int ov_resblock_pair_f32(const ov_respair_params* p, ov_stream_t stream);
 /* 1 when (C, K, dil) has a fused instance, else 0 (callers then issue the two ov_conv1d_f32 launches). */
 int ov_resblock_pair_supported(int C, int K, int dil);
 
+/* One WaveNet layer in ONE launch, reference openvoice/modules.py:192-209 (the loop body of WN.forward) with
+ * commons.py:100-107 (fused_add_tanh_sigmoid_multiply):
+ *   x_in = in_layer(x) + cond;  acts = tanh(x_in[:H]) * sigmoid(x_in[H:]);  rs = res_skip_layer(acts)
+ *   out  = (x + rs[:H]) * mask;  skip = (first ? 0 : skip) + rs[H:]       (last layer: rs has H rows, all skip)
+ * x / out / skip are [B][H][T] with rows ld floats apart and batch items bstride apart; out must not alias x (tiles
+ * read a (K-1)/2-column halo of x from their neighbours: the caller ping-pongs two buffers).  `acts` never leaves
+ * the CU (openvoice_amd/csrc/wn_layer.hip).
+ * Weights: w_in = ov_wn_pack_f32 of the dense [2H][H][K] in_layer weight with its ROWS in gate order -- 16-row
+ * block q holds, at row 4j + {0, 1, 2, 3}, the tanh rows of channels 8q + j and 8q + j + 4 followed by their
+ * sigmoid rows (j = 0..3); b_in [2H] and cond [B or 1][2H] (cond_bstride 0 broadcasts) in the same row order.
+ * w_rs = ov_wn_pack_f32 of the dense [2H][H][1] res_skip weight in natural row order (last layer: rows 0..H-1 zero,
+ * the H skip rows at H..2H-1), b_rs [2H] likewise.
+ * Replaces two ov_conv1d_f32 launches (OV_EPI_GATE, OV_EPI_RESSKIP); results agree with them to fp32 rounding
+ * (different summation order; the gate uses v_exp_f32 / v_rcp_f32 instead of libm tanhf / expf: <= 4e-7 absolute). */
+typedef struct ov_wn_layer_params {
+  const float* x;
+  float* out;
+  float* skip;
+  const float* w_in;
+  const float* b_in;
+  const float* cond;     /* or NULL */
+  const float* w_rs;
+  const float* b_rs;
+  const float* mask;     /* [B][T] 0/1, rows mask_bstride apart (0 = ld) */
+  int64_t bstride;       /* batch stride of x / out / skip */
+  int64_t cond_bstride;
+  int64_t mask_bstride;
+  int32_t B, H, T;
+  int32_t ld;            /* row stride in floats, multiple of 4; 0 = T */
+  int32_t K;
+  int32_t first;         /* 1: skip is initialised, not accumulated (layer 0) */
+  int32_t last;          /* 1: the layer has no residual rows; out is not written */
+  int32_t width;         /* tile width in columns: 0 = chosen by the launcher (ov_wn_layer_tile), else 16 .. 128 step 16 */
+  int32_t ntile;         /* filled in by the launcher */
+  int32_t reserved;
+  unsigned long long* dbg; /* measurement only, NULL in production: [workgroups][8 matrix waves][8] shader-clock ticks
+                          * per phase (first chunk wait, gate-conv k-steps, chunk waits, gate, operand issue + acts
+                          * barrier, res/skip k-steps, epilogue) and the wave's start tick */
+} ov_wn_layer_params;
+int ov_wn_layer_f32(const ov_wn_layer_params* p, ov_stream_t stream);
+/* 1 when (hidden channels, taps) has a fused instance (192, 5: every WN of the converter and of the V1 speaker). */
+int ov_wn_layer_supported(int H, int K);
+/* Floats written by ov_wn_pack_f32 (0 when rows % 128 or cin % 32). */
+size_t ov_wn_pack_size(int rows, int cin, int K);
+/* Dense HOST w[rows][cin][K] -> 16x16x4 A-fragment order, [wave][record][row block][lane][4 k-steps] (HOST dst). */
+int ov_wn_pack_f32(const float* w, int rows, int cin, int K, float* dst);
+/* Tile width the launcher uses for (B, T) on the current device: equal tiles per utterance, a multiple of 16
+ * columns, that fill the compute units in whole rounds (width > 0: validated and returned; 0 = invalid). */
+int ov_wn_layer_tile(int B, int T, int width);
+
 /* Framing for the linear spectrogram, reference openvoice/mel_processing.py:54-58 (reflect pad) and the framing
  * step of torch.stft at :61-72: hops[b][c][u] = ypad[hop*u + c] for u < U, with ypad the waveform [B][N]
  * reflect-padded by `pad` samples on each side (zero beyond that).  hops is (B, hop, U) with rows ld apart.

@@ -68,6 +68,16 @@ class RespairBf16Params(ctypes.Structure):
                 ("dbg", _fp)]
 
 
+class WnLayerParams(ctypes.Structure):
+    """Mirror of ``ov_wn_layer_params`` (include/openvoice_amd.h)."""
+    _fields_ = [("x", _fp), ("out", _fp), ("skip", _fp), ("w_in", _fp), ("b_in", _fp), ("cond", _fp), ("w_rs", _fp),
+                ("b_rs", _fp), ("mask", _fp),
+                ("bstride", ctypes.c_int64), ("cond_bstride", ctypes.c_int64), ("mask_bstride", ctypes.c_int64),
+                ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("T", ctypes.c_int32), ("ld", ctypes.c_int32),
+                ("K", ctypes.c_int32), ("first", ctypes.c_int32), ("last", ctypes.c_int32), ("width", ctypes.c_int32),
+                ("ntile", ctypes.c_int32), ("reserved", ctypes.c_int32), ("dbg", _fp)]
+
+
 # name -> (restype, argtypes); kept in one table so tests can check every header symbol exists.
 SIGNATURES = {
     "ov_version": (ctypes.c_int, []),
@@ -78,6 +88,11 @@ SIGNATURES = {
     "ov_conv1d_f32": (ctypes.c_int, [ctypes.POINTER(ConvParams), _fp]),
     "ov_resblock_pair_f32": (ctypes.c_int, [ctypes.POINTER(RespairParams), _fp]),
     "ov_resblock_pair_supported": (ctypes.c_int, [_i, _i, _i]),
+    "ov_wn_layer_f32": (ctypes.c_int, [ctypes.POINTER(WnLayerParams), _fp]),
+    "ov_wn_layer_supported": (ctypes.c_int, [_i, _i]),
+    "ov_wn_pack_size": (ctypes.c_size_t, [_i, _i, _i]),
+    "ov_wn_pack_f32": (ctypes.c_int, [_fp, _i, _i, _i, _fp]),
+    "ov_wn_layer_tile": (ctypes.c_int, [_i, _i, _i]),
     "ov_conv_post_tanh_f32": (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_float, _fp]),
     "ov_linear_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),

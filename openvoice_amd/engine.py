@@ -190,25 +190,85 @@ def pair_supported(C, K, dil):
 PAIR_POLICY = {(32, 3), (32, 7), (64, 3)}
 
 
+def wn_fused_row_order(hidden):
+    """Gate row order of the fused WaveNet-layer kernel (``ov_wn_layer_f32``, include/openvoice_amd.h): 16-row block
+    q holds, at rows 4j + {0, 1, 2, 3}, the tanh rows of channels 8q + j and 8q + j + 4, then their sigmoid rows, so
+    that the four accumulator rows of a lane of the 16x16x4 MFMA are both halves of two gates."""
+    assert hidden % 8 == 0
+    idx = []
+    for q in range(hidden // 8):
+        for j in range(4):
+            a, b = 8 * q + j, 8 * q + j + 4
+            idx += [a, b, hidden + a, hidden + b]
+    return torch.tensor(idx, dtype=torch.long)
+
+
+def wn_pack(w_dense, device):
+    """Dense [rows][cin][K] -> the 16x16x4 fragment order of ``ov_wn_pack_f32`` (device tensor)."""
+    lib = _lib.load()
+    w_dense = w_dense.detach().to(torch.float32).cpu().contiguous()
+    rows, cin, k = w_dense.shape
+    n = lib.ov_wn_pack_size(rows, cin, k)
+    assert n > 0, (rows, cin, k)
+    packed = torch.empty(n, dtype=torch.float32)
+    _lib.check(lib.ov_wn_pack_f32(_ptr(w_dense), rows, cin, k, _ptr(packed)), "ov_wn_pack_f32")
+    return packed.to(device)
+
+
+def launch_wn_layer(layer, x, out, skip, mask, B, T, ld, cond=None, cond_off=0, cond_bs=0, first=False, last=False,
+                    width=0, mask_bs=0, dbg=None):
+    """One fused WaveNet layer (``ov_wn_layer_f32``): out = (x + res) * mask, skip (+)= rs; ``layer`` is a dict of
+    the packed tensors built by ``_WaveNet``; x / out / skip are [B][H][ld]."""
+    p = _lib.WnLayerParams()
+    p.x, p.out, p.skip = _ptr(x), _ptr(out), _ptr(skip)
+    p.w_in, p.b_in, p.w_rs, p.b_rs = _ptr(layer["w_in"]), _ptr(layer["b_in"]), _ptr(layer["w_rs"]), _ptr(layer["b_rs"])
+    p.cond = _ptr(cond, cond_off) if cond is not None else None
+    p.mask = _ptr(mask)
+    H = layer["hidden"]
+    p.bstride, p.cond_bstride, p.mask_bstride = H * ld, cond_bs, mask_bs
+    p.B, p.H, p.T, p.ld, p.K = B, H, T, ld, layer["K"]
+    p.first, p.last, p.width = int(first), int(last), width
+    p.dbg = ctypes.c_void_p(dbg.data_ptr()) if dbg is not None else None
+    stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(_lib.load().ov_wn_layer_f32(ctypes.byref(p), stream), "ov_wn_layer_f32")
+
+
 class _WaveNet:
-    """Packed WN stack (reference: openvoice/modules.py:133-210)."""
+    """Packed WN stack (reference: openvoice/modules.py:133-210).  Two forms of every layer: the fused one-launch
+    layer (``ov_wn_layer_f32``) where the shape has an instance, and the gate + res/skip launch pair."""
 
     def __init__(self, sd, prefix, n_layers, hidden, device):
         order = gate_row_order(hidden)
         self.hidden, self.n_layers = hidden, n_layers
-        self.in_layers, self.rs_layers = [], []
+        self.in_layers, self.rs_layers, self.fused_layers = [], [], []
+        K = sd[f"{prefix}.in_layers.0.weight_v"].shape[2] if f"{prefix}.in_layers.0.weight_v" in sd else \
+            sd[f"{prefix}.in_layers.0.weight"].shape[2]
+        self.fused = bool(_lib.load().ov_wn_layer_supported(hidden, K))
+        forder = wn_fused_row_order(hidden) if self.fused else None
         for i in range(n_layers):
-            w = effective_weight(sd, f"{prefix}.in_layers.{i}")
-            self.in_layers.append(PackedConv(w[order], sd[f"{prefix}.in_layers.{i}.bias"][order], device,
-                                             K=w.shape[2], cout=hidden))
-            w = effective_weight(sd, f"{prefix}.res_skip_layers.{i}")
-            self.rs_layers.append(PackedConv(w, sd[f"{prefix}.res_skip_layers.{i}.bias"], device, K=1))
+            w_in = effective_weight(sd, f"{prefix}.in_layers.{i}")
+            b_in = sd[f"{prefix}.in_layers.{i}.bias"].float()
+            self.in_layers.append(PackedConv(w_in[order], b_in[order], device, K=w_in.shape[2], cout=hidden))
+            w_rs = effective_weight(sd, f"{prefix}.res_skip_layers.{i}")
+            b_rs = sd[f"{prefix}.res_skip_layers.{i}.bias"].float()
+            self.rs_layers.append(PackedConv(w_rs, b_rs, device, K=1))
+            if self.fused:
+                if w_rs.shape[0] == hidden:      # last layer: skip rows only (modules.py:170-173, :203-207)
+                    w_rs = torch.cat([torch.zeros_like(w_rs), w_rs])
+                    b_rs = torch.cat([torch.zeros_like(b_rs), b_rs])
+                self.fused_layers.append(dict(hidden=hidden, K=w_in.shape[2], w_in=wn_pack(w_in[forder], device),
+                                              b_in=b_in[forder].contiguous().to(device), w_rs=wn_pack(w_rs, device),
+                                              b_rs=b_rs.contiguous().to(device)))
         # cond_layer rows re-ordered per layer so its output is directly the gate's per-batch bias
         wc = effective_weight(sd, prefix + ".cond_layer")[:, :, 0]
         bc = sd[prefix + ".cond_layer.bias"].float()
         full = torch.cat([order + 2 * hidden * i for i in range(n_layers)])
         self.cond_w = wc[full].contiguous().to(device)
         self.cond_b = bc[full].contiguous().to(device)
+        if self.fused:
+            full = torch.cat([forder + 2 * hidden * i for i in range(n_layers)])
+            self.cond_w_fused = wc[full].contiguous().to(device)
+            self.cond_b_fused = bc[full].contiguous().to(device)
 
 
 class ConverterEngine:
@@ -299,6 +359,7 @@ class ConverterEngine:
                 proj_b=sd["ref_enc.proj.bias"].contiguous().to(dev))
         self._ws = {}
         self.profile = None   # set to [] to collect per-launch HIP-event timings
+        self.fuse_wn = True      # WaveNet layers as one launch each (ov_wn_layer_f32) where the shape has an instance
         self.fuse_pairs = True   # ResBlock pairs of the HBM-bound stages as one launch each (PAIR_POLICY)
         # opt-in fast generator: bf16 activations, fp32 accumulation (waveform within
         # ~1e-2 of the fp32 path instead of ~1e-5).  Built lazily by use_bf16_generator().
@@ -345,6 +406,13 @@ class ConverterEngine:
                    "ov_linear_f32")
         return y
 
+    def _wn_cond(self, wn, g):
+        """cond_layer (modules.py:189-190) for every layer of ``wn`` at once, rows in the order the gate kernel in
+        use expects them as its per-utterance bias."""
+        if self.fuse_wn and wn.fused:
+            return self._linear(g, wn.cond_w_fused, wn.cond_b_fused)
+        return self._linear(g, wn.cond_w, wn.cond_b)
+
     def _workspace(self, B, T):
         key = (B, T)
         ws = self._ws.get(key)
@@ -354,7 +422,7 @@ class ConverterEngine:
             Tp = padded_frames(T)
             # zero-filled once: the pad columns [T, Tp) are never written by a kernel and never read as data
             f = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
-            ws = dict(Tp=Tp, mask=f(B, Tp), h=f(B, H, Tp), acts=f(B, H, Tp), skip=f(B, H, Tp), noise=f(B, C, Tp),
+            ws = dict(Tp=Tp, mask=f(B, Tp), h=f(B, H, Tp), h2=f(B, H, Tp), acts=f(B, H, Tp), skip=f(B, H, Tp), noise=f(B, C, Tp),
                       z=f(B, C, Tp), z_p=f(B, C, Tp), z_hat=f(B, C, Tp))
             ch = self.cfg["upsample_initial_channel"]
             ws["pre"] = f(B, ch, Tp)
@@ -374,6 +442,24 @@ class ConverterEngine:
         whose own epilogue multiplies by the same 0/1 mask, which makes it a no-op."""
         H, Tp = wn.hidden, ws["Tp"]
         cbs = 0 if cond.shape[0] == 1 else cond.shape[1]
+        if self.fuse_wn and wn.fused:
+            # one launch per layer; h ping-pongs between two buffers (a tile reads its neighbours' halo columns)
+            src, dst = ws["h"], ws["h2"]
+            for i in range(wn.n_layers):
+                layer = wn.fused_layers[i]
+                args = dict(cond=cond, cond_off=2 * H * i, cond_bs=cbs, first=i == 0, last=i == wn.n_layers - 1,
+                            mask_bs=Tp)
+                if self.profile is None:
+                    launch_wn_layer(layer, src, dst, ws["skip"], mask, B, T, Tp, **args)
+                else:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    launch_wn_layer(layer, src, dst, ws["skip"], mask, B, T, Tp, **args)
+                    e1.record()
+                    rs_rows = H if args["last"] else 2 * H
+                    self.profile.append(("wn_layer", 2.0 * (2 * H * H * layer["K"] + rs_rows * H) * T * B, e0, e1))
+                src, dst = dst, src
+            return
         for i in range(wn.n_layers):
             self._conv(wn.in_layers[i], ws["h"], 0, H * Tp, ws["acts"], 0, H * Tp, B, T, epi=EPI_GATE,
                        bias_b=cond, bias_b_off=2 * H * i, bias_b_bs=cbs, rows=2 * H, x_ld=Tp, out_ld=Tp, tag="wn_in")
@@ -432,9 +518,9 @@ class ConverterEngine:
         # conditioning GEMVs (T = 1): modules.py:189-190 for every WN, models.py:275 for the decoder
         g_q = torch.zeros_like(g_src) if self.zero_g else g_src
         g_d = torch.zeros_like(g_tgt) if self.zero_g else g_tgt
-        conds = dict(q=self._linear(g_q, self.q_wn.cond_w, self.q_wn.cond_b),
-                     src=[self._linear(g_src, cp["wn"].cond_w, cp["wn"].cond_b) for cp in self.couplings],
-                     tgt=[self._linear(g_tgt, cp["wn"].cond_w, cp["wn"].cond_b) for cp in self.couplings])
+        conds = dict(q=self._wn_cond(self.q_wn, g_q),
+                     src=[self._wn_cond(cp["wn"], g_src) for cp in self.couplings],
+                     tgt=[self._wn_cond(cp["wn"], g_tgt) for cp in self.couplings])
         cond_d = self._linear(g_d, self.dec_cond_w, self.dec_cond_b)
         # ---- posterior encoder + flows at frame rate ---------------------------------------------------
         # (measured and dropped: issuing this part -- ~100 launches of <= 1.3 tiles per workgroup slot -- as 2 / 4

@@ -237,7 +237,7 @@ class TtsEngine:
                                            ctypes.c_void_p(y_len.data_ptr()), _ptr(ws["noise"]), C * Ly, Ly, _ptr(z_p),
                                            _ptr(m_p), _ptr(logs_p), _ptr(attn) if attn is not None else None, B, C, Tx,
                                            Ty, Ly, float(noise_scale), st), "ov_expand_prior_f32")
-        cond_flow = [core._linear(g, cp["wn"].cond_w, cp["wn"].cond_b) for cp in core.couplings]
+        cond_flow = [core._wn_cond(cp["wn"], g) for cp in core.couplings]
         core._flow(z_p, z, ws, B, Ty, cond_flow, mask_y, reverse=True)      # z_p -> z, no copy
         cond_d = core._linear(g, core.dec_cond_w, core.dec_cond_b)
         Td = Ty if max_len is None else min(Ty, int(max_len))

@@ -1,0 +1,120 @@
+"""The fused WaveNet layer (``ov_wn_layer_f32``, openvoice_amd/csrc/wn_layer.hip) against plain fp32 PyTorch on CPU
+(reference: openvoice/modules.py:192-209, commons.py:100-107), through the C ABI.
+
+Tolerance: 2e-5 of the output scale -- fp32 MFMA is an exact fmaf chain (summation order differs from the CPU's);
+the gate uses v_exp_f32 / v_rcp_f32 (1 ulp) instead of libm tanhf / expf.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from openvoice_amd import _lib  # noqa: E402
+from openvoice_amd.engine import launch_wn_layer, wn_fused_row_order, wn_pack  # noqa: E402
+
+DEV = "cuda:0"
+H, K = 192, 5
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    gen = torch.Generator().manual_seed(seed)
+    return scale * torch.randn(*shape, generator=gen)
+
+
+def _close(got, ref, rel=2e-5, what=""):
+    err = (got.cpu() - ref).abs().max().item()
+    bound = rel * max(1.0, ref.abs().max().item())
+    assert err <= bound, f"{what}: max-abs err {err:.3e} > {bound:.3e}"
+
+
+def _layer(seed, last=False):
+    w_in, b_in = _rand(2 * H, H, K, seed=seed, scale=(K * H) ** -0.5), _rand(2 * H, seed=seed + 1, scale=0.1)
+    rows = H if last else 2 * H
+    w_rs, b_rs = _rand(rows, H, 1, seed=seed + 2, scale=H ** -0.5), _rand(rows, seed=seed + 3, scale=0.1)
+    return w_in, b_in, w_rs, b_rs
+
+
+def _packed(w_in, b_in, w_rs, b_rs):
+    order = wn_fused_row_order(H)
+    if w_rs.shape[0] == H:
+        w_rs = torch.cat([torch.zeros_like(w_rs), w_rs])
+        b_rs = torch.cat([torch.zeros_like(b_rs), b_rs])
+    return dict(hidden=H, K=K, w_in=wn_pack(w_in[order], DEV), b_in=b_in[order].contiguous().to(DEV),
+                w_rs=wn_pack(w_rs, DEV), b_rs=b_rs.contiguous().to(DEV))
+
+
+def _reference(x, g, mask, skip0, w_in, b_in, w_rs, b_rs, first, last):
+    x_in = F.conv1d(x, w_in, b_in, padding=(K - 1) // 2) + g[:, :, None]
+    acts = torch.tanh(x_in[:, :H]) * torch.sigmoid(x_in[:, H:])
+    rs = F.conv1d(acts, w_rs, b_rs)
+    if last:
+        return None, (0 if first else skip0) + rs
+    return (x + rs[:, :H]) * mask[:, None], (0 if first else skip0) + rs[:, H:]
+
+
+def _run(B, T, lengths, width, first=False, last=False, per_item_cond=True, seed=10):
+    ld = (T + 3) // 4 * 4
+    x, skip0 = _rand(B, H, T, seed=seed), _rand(B, H, T, seed=seed + 1)
+    g = _rand(B if per_item_cond else 1, 2 * H, seed=seed + 2, scale=0.3)
+    mask = (torch.arange(T)[None, :] < torch.tensor(lengths)[:, None]).float()
+    x = x * mask[:, None]                 # the WN input is always masked (modules.py:207, models.py:216)
+    lw = _layer(seed + 3, last)
+    x_ref, skip_ref = _reference(x, g.expand(B, -1), mask, skip0, *lw, first, last)
+    pad = lambda t: F.pad(t, (0, ld - T)).contiguous().to(DEV)
+    xd, skipd, maskd = pad(x), pad(skip0 if not first else torch.full_like(skip0, float("nan"))), pad(mask)
+    outd = torch.full((B, H, ld), float("nan"), device=DEV)
+    gd = g[:, wn_fused_row_order(H)].contiguous().to(DEV)
+    launch_wn_layer(_packed(*lw), xd, outd, skipd, maskd, B, T, ld, cond=gd, cond_bs=2 * H if per_item_cond else 0,
+                    first=first, last=last, width=width, mask_bs=ld)
+    torch.cuda.synchronize()
+    if not last:
+        _close(outd[:, :, :T], x_ref, what=f"h' (T={T}, width={width})")
+        assert torch.isnan(outd[:, :, T:]).all(), "columns >= T must not be written"
+    _close(skipd[:, :, :T], skip_ref, what=f"skip (T={T}, width={width})")
+    assert (skipd[:, :, T:].cpu() == 0).all()
+
+
+@pytest.mark.parametrize("width", [16, 32, 48, 64, 80, 96, 112, 128])
+def test_every_tile_width(width):
+    """Each instantiated tile width (16 .. 128 columns), three tiles and a ragged last one, ragged utterance lengths."""
+    T = 2 * width + max(1, width // 2 - 3)
+    _run(2, T, [T, max(1, T - 5)], width)
+
+
+@pytest.mark.parametrize("T", [1, 3, 17, 200, 861, 1000])
+def test_launcher_chosen_width(T):
+    """width = 0: the launcher's rule; T = 1 (one column), T not a multiple of 4, the benchmark length and beyond."""
+    _run(3, T, [T, max(1, T - 5), max(1, T // 2)], 0)
+
+
+def test_first_and_last_layer_forms():
+    """Layer 0 initialises the skip accumulator (NaN-poisoned here); the last layer has H skip rows only and does not
+    write h' (modules.py:170-173, :203-207)."""
+    _run(2, 150, [150, 99], 0, first=True)
+    _run(2, 150, [150, 99], 0, last=True)
+    _run(2, 150, [150, 99], 64, first=True, last=True)
+
+
+def test_broadcast_conditioning_row():
+    _run(3, 77, [77, 50, 1], 0, per_item_cond=False)
+
+
+def test_tile_rule():
+    lib = _lib.load()
+    assert lib.ov_wn_layer_tile(32, 861, 0) == 112      # 8 tiles per utterance = 256 tiles on 256 CUs
+    assert lib.ov_wn_layer_tile(1, 861, 0) == 16        # 54 tiles: as many CUs as possible
+    assert lib.ov_wn_layer_tile(4, 100, 24) == 0 and lib.ov_wn_layer_tile(4, 100, 144) == 0
+    assert lib.ov_wn_layer_tile(4, 100, 96) == 96
+
+
+def test_argument_checks():
+    B, T = 1, 16
+    layer = _packed(*_layer(1))
+    x = torch.zeros(B, H, T, device=DEV)
+    mask = torch.ones(B, T, device=DEV)
+    with pytest.raises(_lib.OvError, match="BADARG|bad"):
+        launch_wn_layer(layer, x, x, torch.zeros_like(x), mask, B, T, T)          # out aliases x
+    bad = dict(layer, hidden=128)
+    with pytest.raises(_lib.OvError):
+        launch_wn_layer(bad, x, torch.zeros_like(x), torch.zeros_like(x), mask, B, T, T)

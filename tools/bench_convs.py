@@ -150,6 +150,21 @@ def main():
                         continue
                     print(f"{name:>14} ld={ld} nld={nld} {ms:8.4f} ms {fl / ms / 1e9:7.1f} TF/s "
                           f"{100 * fl / ms / 1e9 / PEAK:6.1f} %", flush=True)
+        # the same layer as ONE launch (ov_wn_layer_f32), per tile width
+        from openvoice_amd.engine import launch_wn_layer, wn_fused_row_order, wn_pack
+        ld = padded_frames(T)
+        x, out = torch.randn(B, H, ld, device=dev), torch.empty(B, H, ld, device=dev)
+        skip, mask, cond = torch.zeros(B, H, ld, device=dev), torch.ones(B, ld, device=dev), torch.randn(B, 2 * H, device=dev)
+        fo = wn_fused_row_order(H)
+        layer = dict(hidden=H, K=5, w_in=wn_pack((torch.randn(2 * H, H, 5) * (5 * H) ** -0.5)[fo], dev),
+                     b_in=torch.zeros(2 * H, device=dev), w_rs=wn_pack(torch.randn(2 * H, H, 1) * H ** -0.5, dev),
+                     b_rs=torch.zeros(2 * H, device=dev))
+        fl = 2.0 * 2 * H * H * 6 * T * B
+        for width in (0, 64, 96, 112, 128):
+            ms = timed(lambda: launch_wn_layer(layer, x, out, skip, mask, B, T, ld, cond=cond, cond_bs=2 * H,
+                                               width=width, mask_bs=ld), 10, args.warm_ms)
+            print(f"fused wn layer ld={ld} width={width or 'auto'} {ms:8.4f} ms {fl / ms / 1e9:7.1f} TF/s "
+                  f"{100 * fl / ms / 1e9 / PEAK:6.1f} %", flush=True)
     print("done")
 
 
