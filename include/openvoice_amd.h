@@ -73,7 +73,9 @@ enum {
 enum {
   OV_F_MASK_V = 1,    /* LINEAR: multiply v by mask[b][t] before the residual add */
   OV_F_OUT2_INIT = 2, /* RESSKIP: out2 = v instead of out2 += v (first WaveNet layer) */
-  OV_F_CONVT_GROUPED = 4 /* CONVT, phase_s 8 / 2: rows packed by phase group (see OV_EPI_CONVT); M % 64 == 0 */
+  OV_F_CONVT_GROUPED = 4, /* CONVT, phase_s 8 / 2: rows packed by phase group (see OV_EPI_CONVT); M % 64 == 0 */
+  OV_F_NO_XCD_MAP = 8 /* measurement knob: walk the tile list round-robin over the workgroups instead of giving each
+                       * XCD (workgroup id % 8) a contiguous eighth of it; results are identical either way */
 };
 
 /* One Conv1d launch.  Input length == output length L ('same' padding, stride 1), as every conv

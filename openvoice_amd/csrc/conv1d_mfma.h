@@ -161,6 +161,28 @@ __device__ __forceinline__ void conv_epilogue(const ov_conv1d_params& p, f32x16 
     }
     return;
   } else {
+    if constexpr (EPI == OV_EPI_LINEAR) {
+      // Nothing to read back (every conv1 of the MRF, and every conv2: its residual is already in the accumulators):
+      // stores only, back to back.  Kept apart from the general path on purpose -- there the optional operand loads
+      // sit between the fragments' stores and the wait for a load (vmcnt counts in order) is a wait for every store
+      // issued before it: one exposed write round trip per fragment (1 500 cycles per tile, phase timers r02 s13).
+      if (!mrow && !(p.res && !preloaded) && !(p.add && !preloaded)) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+          const uint32_t mt = (uint32_t)(mtile0 + i);
+          if (mt * 32u >= Cout) continue;
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            const uint32_t col = col0 + 32u * j;
+            if (col >= L) continue;
+            const uint32_t voff = (mt * 32u + 4u * half) * LD + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) (outb + (size_t)((r & 3) + 8 * (r >> 2)) * LD)[voff] = acc[i][j][r] * scale;
+          }
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       const uint32_t mt = (uint32_t)(mtile0 + i);
@@ -393,12 +415,25 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
   const int L = p.L, Cin = p.Cin;
   const int nunits = packed_units(Cin);
   const int nchunks = nunits / UPC;
-  // work list: wid = (b * mblocks + mblock) * ntiles + tile, walked with the grid as stride
+  // work list: wid = (b * ntiles + tile) * mblocks + mblock -- the M-blocks of one time tile (same x) and the
+  // neighbouring time tiles (shared halo lines) are neighbours in the list.
   const int ntiles = (L + N_BLK - 1) / N_BLK;
   const int mblocks = (p.M + 32 * WM * WVM - 1) / (32 * WM * WVM);
   const int total = ntiles * mblocks * p.B;
-  const int wstride = gridDim.x;
-  if ((int)blockIdx.x >= total) return;
+  // XCD-contiguous order: block j runs on XCD j % 8 (observed placement, a speed assumption only), and every XCD has
+  // its own L2.  XCD x therefore owns the contiguous eighth [x * total / 8, (x + 1) * total / 8) of the list and its
+  // workgroups stride through it together, so that list neighbours -- which share the 128-byte lines at their tile
+  // edges and, for several M-blocks, the whole x tile -- are in flight on the SAME L2 at the same time.  With the
+  // round-robin order every tile edge line was fetched from the fabric twice (PMC: 1.5x the tensor bytes read).
+  int wid0 = blockIdx.x, wend = total, wstride = gridDim.x;
+  if (!(p.flags & OV_F_NO_XCD_MAP) && (gridDim.x & 7u) == 0) {
+    const int xcd = blockIdx.x & 7;
+    const int lo = (int)(((long long)xcd * total) >> 3);
+    wend = (int)(((long long)(xcd + 1) * total) >> 3);
+    wid0 = lo + (int)(blockIdx.x >> 3);
+    wstride = gridDim.x >> 3;
+  }
+  if (wid0 >= wend) return;
 
   // Written as a chain of equalities on purpose: with `wave >= 4` hipcc (ROCm 7.2) allocates 12 more
   // VGPRs for the matrix path (132 instead of 120), which costs a wave per SIMD and 5-25 % on MI355X.
@@ -406,8 +441,8 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
 #pragma unroll
   for (int i = 0; i < NLD; ++i) is_loader |= (wave == 4 + i);
 #ifndef OV_EXP
-#define OV_EXP 0   // measurement builds only (scripts/exp_sync.sh): 1 = no loads, no barriers; 2 = no loads
-#endif
+#define OV_EXP 0   // measurement builds only (scripts/exp_sync.sh): 1 = no loads, no barriers; 2 = no loads;
+#endif             // 3 = phase timers of the matrix waves written through p.out2 (scripts/conv_phases.sh)
   if (is_loader) {
     if (OV_EXP == 1) return;
     // ================================ loader waves ===============================================
@@ -417,8 +452,8 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
     // valid INPUT columns: L for 'same' convs; the forward-aligned even-K conv consumes (K-1)*DIL more
     const int Lin = L + ((K % 2 == 1) ? 0 : (K - 1) * DIL);
     int it = 0;
-    for (int wid = blockIdx.x; wid < total; wid += wstride) {
-      const int t0 = (wid % ntiles) * N_BLK;
+    for (int wid = wid0; wid < wend; wid += wstride) {
+      const int t0 = ((wid / mblocks) % ntiles) * N_BLK;
       const float* __restrict__ xb = p.x + (int64_t)(wid / (ntiles * mblocks)) * p.x_bstride;
       for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
         float* dst = xs + (it & 1) * BUF;
@@ -482,8 +517,8 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
   // ================================== matrix waves ================================================
   const int wm = wave / WVN, wn = wave % WVN;
   const int recs_per_mtile = nunits * K + 1;
-  int wid = blockIdx.x;
-  int tile = wid % ntiles, mblk = (wid / ntiles) % mblocks, b = wid / (ntiles * mblocks);
+  int wid = wid0;
+  int mblk = wid % mblocks, tile = (wid / mblocks) % ntiles, b = wid / (ntiles * mblocks);
   int mtile0 = (mblk * WVM + wm) * WM;
 
   // weight fragments: scalar base + per-lane 32-bit index (in 16-byte units), record stride 64
@@ -499,14 +534,25 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
 #pragma unroll
   for (int i = 0; i < WM; ++i) a_cur[i] = wbase[widx[i]];
 
+#if OV_EXP == 3
+  // phase timers (measurement build): ticks per matrix wave in 0 = tile set-up + accumulator preload, 1 = chunk
+  // barriers, 2 = k-step loops, 3 = next-tile bookkeeping + epilogue; 4 = tiles
+  unsigned long long tph[5] = {0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+#define OV_MARK(q) { const unsigned long long now_ = __builtin_readcyclecounter(); tph[q] += now_ - tlast; tlast = now_; }
+#else
+#define OV_MARK(q)
+#endif
   int it = 0;
   while (true) {
     f32x16 acc[WM][WN];
     const bool preloaded = conv_preload<EPI, WM, WN>(p, acc, b, tile * N_BLK + wn * (32 * WN), mtile0, lane);
+    OV_MARK(0)
 
     int rec = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
       if (OV_EXP != 1) __syncthreads();  // loader finished buffer (it & 1); we finished reading the other one
+      OV_MARK(1)
       const float* xl = xs + (it & 1) * BUF + xl_off;
       // One k-step = one ci pair x one tap = WM*WN MFMAs (256 cycles of matrix pipe).  The B operands
       // of k-step s+1 are read from LDS while the MFMAs of k-step s run (explicit double buffer,
@@ -550,11 +596,12 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
           for (int i = 0; i < WM; ++i) a_cur[i] = a_nxt[i];
         }
       }
+      OV_MARK(2)
     }
     // next work item; its first weight record is in flight while the epilogue of this one runs
     const int nwid = wid + wstride;
-    const bool more = nwid < total;
-    const int ntile = nwid % ntiles, nmblk = (nwid / ntiles) % mblocks, nb = nwid / (ntiles * mblocks);
+    const bool more = nwid < wend;
+    const int nmblk = nwid % mblocks, ntile = (nwid / mblocks) % ntiles, nb = nwid / (ntiles * mblocks);
     const int nmtile0 = (nmblk * WVM + wm) * WM;
     uint32_t nwidx[WM];
 #pragma unroll
@@ -564,6 +611,15 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
       for (int i = 0; i < WM; ++i) a_cur[i] = wbase[nwidx[i]];
     }
     conv_epilogue<EPI, WM, WN>(p, acc, b, tile * N_BLK + wn * (32 * WN), mtile0, mblk * WVM + wm, lane, preloaded);
+    OV_MARK(3)
+#if OV_EXP == 3
+    ++tph[4];
+    if (!more && EPI == OV_EPI_LINEAR && p.out2 && lane == 0) {
+      unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.out2) + ((size_t)blockIdx.x * 4 + wave) * 8;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) dbg[q] = tph[q];
+    }
+#endif
     if (!more) break;
     wid = nwid; tile = ntile; mblk = nmblk; b = nb; mtile0 = nmtile0;
 #pragma unroll
@@ -615,6 +671,9 @@ int conv1d_launch(const ov_conv1d_params* p, hipStream_t stream) {
   const bool persistent = p->tiles_per_wg < 0 || (p->tiles_per_wg == 0 && p->res == nullptr && total >= 16L * slots);
   long nwg = persistent ? (long)slots : (total + tpw - 1) / tpw;
   if (nwg > total) nwg = total;
+  // whole multiples of 8 workgroups: the kernel's XCD-contiguous work order needs the same count on every XCD
+  // (workgroups whose share of the list is empty exit at once)
+  if (!(p->flags & OV_F_NO_XCD_MAP) && nwg >= 8) nwg = (nwg + 7) / 8 * 8;
   hipLaunchKernelGGL(kernel, dim3((unsigned)nwg), dim3(64 * (4 + NLD)), 0, stream, *p);
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
 }

@@ -11,6 +11,7 @@ PosteriorEncoder (models.py:212-221) -> ResidualCouplingBlock forward with g_src
 g_tgt (models.py:390-397) -> Generator (models.py:272-291).
 """
 import ctypes
+import os
 
 import torch
 
@@ -125,12 +126,18 @@ def convt_row_order(cout, stride):
     return torch.tensor(idx, dtype=torch.long)
 
 
+# measurement knob (A/B runs of the same process image): flag bits OR-ed into every conv launch, e.g.
+# OPENVOICE_AMD_CONV_FLAGS=8 (OV_F_NO_XCD_MAP) restores the round-robin tile order
+_EXTRA_CONV_FLAGS = int(os.environ.get("OPENVOICE_AMD_CONV_FLAGS", "0"))
+
+
 def launch_conv(layer, x, x_off, x_bs, out, out_off, out_bs, B, L, epi=EPI_LINEAR, flags=0, in_slope=1.0,
                 scale=1.0, res=None, res_off=0, res_bs=0, add=None, add_bs=0, out2=None, out2_bs=0, mask=None,
                 bias_b=None, bias_b_off=0, bias_b_bs=0, split=0, phase_s=1, cin=None, rows=None, tiles_per_wg=0,
                 x_ld=0, out_ld=0, mask_bs=0, tile=0, loaders=0, chunk=0):
     """Fill ``ov_conv1d_params`` and launch on torch's current stream of ``x``'s device.
     Offsets, row strides (``*_ld``, 0 = dense) and batch strides are in elements."""
+    flags |= _EXTRA_CONV_FLAGS
     if _lib.use_torch_binding():
         ip = [B, layer.cin if cin is None else cin, L, x_ld, out_ld, layer.rows if rows is None else rows, layer.cout,
               layer.K, layer.dil, epi, flags, split, phase_s, tiles_per_wg, tile, loaders, chunk,
