@@ -346,13 +346,14 @@ typedef struct ov_conv1d_bf16_params {
   int32_t phase_s;      /* > 1: ConvTranspose as a phase conv -- Cout = phase_s * C columns ordered
                          * (phase, c); column (ph, c) of row t is written to out[b][t * phase_s + ph][c]    */
   int32_t bias_bstride; /* elements between the bias vectors of consecutive batch items (0 = shared)     */
-  int32_t layout;       /* 0 = dispatcher's choice; measurement knobs: 1 = 64x64 wave tiles for Cout > 64,
-                         * 2 = weight fragments requested one k-step ahead (round-1 scheme) instead of three   */
+  int32_t layout;       /* 0 = dispatcher's choice; measurement knobs: 2 = weight fragments requested one k-step
+                         * ahead (round-1 scheme) instead of three; otherwise 0                     */
   float in_slope;       /* leaky-ReLU slope applied to x while staging (1.0f = identity)                  */
   float scale;          /* out = (conv + bias + res + add) * scale                                        */
   float out_slope;      /* leaky-ReLU applied to the result before rounding (0 or 1.0f = none): a tensor whose only
                          * consumer activates it (conv1 of a ResBlock pair) is stored activated, and that consumer
                          * stages it with in_slope = 1 -- no unpack / activate / repack pass in its loaders */
+  unsigned long long* dbg; /* measurement only, NULL in production: [workgroups][4 matrix waves][8] ticks per phase */
 } ov_conv1d_bf16_params;
 
 /* Number of bf16 elements ov_conv1d_bf16_pack writes for a dense fp32 [Cout][Cin][K] weight (0 if unsupported). */

@@ -48,7 +48,7 @@ class ConvBf16Params(ctypes.Structure):
     _fields_ = [("x", _fp), ("w", _fp), ("bias", _fp), ("out", _fp), ("res", _fp), ("add", _fp),
                 ("B", ctypes.c_int32), ("L", ctypes.c_int32), ("Cin", ctypes.c_int32), ("Cout", ctypes.c_int32),
                 ("K", ctypes.c_int32), ("dil", ctypes.c_int32), ("phase_s", ctypes.c_int32), ("bias_bstride", ctypes.c_int32), ("layout", ctypes.c_int32),
-                ("in_slope", ctypes.c_float), ("scale", ctypes.c_float), ("out_slope", ctypes.c_float)]
+                ("in_slope", ctypes.c_float), ("scale", ctypes.c_float), ("out_slope", ctypes.c_float), ("dbg", _fp)]
 
 
 class RespairParams(ctypes.Structure):

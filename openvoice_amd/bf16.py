@@ -26,7 +26,7 @@ class PackedConvBf16:
         self.bias = None if bias is None else bias.detach().float().contiguous().to(device)
 
 
-def launch_conv_bf16(layer, x, out, in_slope=1.0, scale=1.0, res=None, add=None, layout=0, out_slope=1.0):
+def launch_conv_bf16(layer, x, out, in_slope=1.0, scale=1.0, res=None, add=None, layout=0, out_slope=1.0, dbg=None):
     """out = (conv1d(lrelu(x, in_slope)) + bias [+ res] [+ add]) * scale on torch's current stream.
     x (B, L, Cin), out / res / add (B, L, Cout), all contiguous bfloat16."""
     B, L, cin = x.shape
@@ -38,6 +38,7 @@ def launch_conv_bf16(layer, x, out, in_slope=1.0, scale=1.0, res=None, add=None,
     p.x, p.w, p.bias, p.out, p.res, p.add = vp(x), vp(layer.w), vp(layer.bias), vp(out), vp(res), vp(add)
     p.B, p.L, p.Cin, p.Cout, p.K, p.dil = B, L, cin, layer.cout, layer.K, layer.dil
     p.in_slope, p.scale, p.layout, p.out_slope = in_slope, scale, layout, out_slope
+    p.dbg = vp(dbg)
     stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(_lib.load().ov_conv1d_bf16cl(ctypes.byref(p), stream), "ov_conv1d_bf16cl")
 

@@ -39,6 +39,28 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
   return u;
 }
 
+// leaky-ReLU of two packed bf16 values, evaluated in fp32 and rounded to nearest even -- the loaders' inner loop, 6
+// instructions per pair: unpack (shift, and), v_pk_mul_f32 by the slope, max(v, slope * v) for 0 < slope < 1 (positive
+// values keep their bits, negative ones take the product -- identical to `v > 0 ? v : v * slope`), v_cvt_pk_bf16_f32.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+template <bool LT1>
+__device__ __forceinline__ uint32_t lrelu_bf16x2(uint32_t w, float slope) {
+  f32x2 v = {__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+  const f32x2 sv = v * slope;
+  if constexpr (LT1) {   // (asm: fmaxf() canonicalises both operands first -- three v_max_f32 per value)
+    asm("v_max_f32 %0, %1, %2" : "=v"(v[0]) : "v"(v[0]), "v"(sv[0]));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v[1]) : "v"(v[1]), "v"(sv[1]));
+  } else {
+    v[0] = v[0] > 0.f ? v[0] : sv[0];
+    v[1] = v[1] > 0.f ? v[1] : sv[1];
+  }
+  const bf16x2 r = __builtin_convertvector(v, bf16x2);
+  uint32_t u;
+  __builtin_memcpy(&u, &r, 4);
+  return u;
+}
+
 // WM x WN fragments of 32x32 per matrix wave; WVT x WVC matrix waves (time x channel) per workgroup.
 // DEEP: weight fragments are requested WDEPTH - 1 k-steps ahead instead of one (see the main loop); needs an even
 // number of 32-channel chunks (Cin % 64 == 0).
@@ -52,7 +74,11 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
   constexpr int BUF = R * PITCH;                // bytes per LDS buffer
   constexpr int NITEM = R * 4;                  // 16-byte vectors per chunk
   constexpr int PER_LANE = (NITEM + 64 * NLD - 1) / (64 * NLD);
-  __shared__ __attribute__((aligned(16))) unsigned char xs[2 * BUF];
+  // one LDS block: the two chunk buffers during the main loop, the output staging tile in the epilogue
+  constexpr int NBW = 32 * WN * WVC;                          // output columns per workgroup
+  constexpr int SP = NBW * 2 + 16;                            // staging row pitch in bytes (see the epilogue)
+  constexpr int SMEM = 2 * BUF > TT * SP ? 2 * BUF : TT * SP;
+  __shared__ __attribute__((aligned(16))) unsigned char xs[SMEM];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,6 +103,7 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
   if (is_loader) {
     const int llane = (wave - 4) * 64 + lane;
     const float slope = p.in_slope;
+    const bool slope_lt1 = slope > 0.f && slope < 1.f;
     u32x4 stg[PER_LANE];
     int ok[PER_LANE];
     // issue the 16-byte loads of round `rd` into registers (they stay in flight across the barrier)
@@ -107,12 +134,12 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
           u32x4 v = stg[i];
           if (!ok[i]) v = u32x4{0u, 0u, 0u, 0u};
           else if (act) {
+            if (slope_lt1) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
-              lo = lo > 0.f ? lo : lo * slope;
-              hi = hi > 0.f ? hi : hi * slope;
-              v[e] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+              for (int e = 0; e < 4; ++e) v[e] = lrelu_bf16x2<true>(v[e], slope);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = lrelu_bf16x2<false>(v[e], slope);
             }
           }
           *reinterpret_cast<u32x4*>(dst + (idx >> 2) * PITCH + (idx & 3) * 16) = v;
@@ -125,6 +152,26 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
   }
 
   // ---------------------------------- matrix waves ---------------------------------------------------
+  // phase timers (measurement only: p.dbg != NULL): 0 set-up, 1 chunk barriers, 2 k-step loops, 3 identity rounds,
+  // 4 staging the tile in LDS, 5 its barrier, 6 global stores; 7 = tiles (1)
+  const bool dbg = p.dbg != nullptr;
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 1};
+  unsigned long long tlast = dbg ? __builtin_readcyclecounter() : 0ull;
+  auto mark = [&](int q) {
+    if (dbg) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      tph[q] += now - tlast;
+      tlast = now;
+    }
+  };
+  auto dump = [&]() {
+    if (dbg && lane == 0) {
+      unsigned long long* d =
+          p.dbg + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 + wave * 8;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) d[q] = tph[q];
+    }
+  };
   const int wt = wave / WVC, wc = wave % WVC;
   const int half = lane >> 5, l31 = lane & 31;
   const int ntile0 = (blockIdx.z * WVC + wc) * WN;          // first 32-column output tile of this wave
@@ -145,13 +192,22 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
 
   // packed weights: record index ((nt * nchunks + c) * K + tap) * 2 + kb, 64 lanes x 16 bytes each
   const u32x4* __restrict__ wbase = reinterpret_cast<const u32x4*>(p.w);
-  uint32_t widx[WN];
+  // Column tiles past Cout (a partial last N-block) read the packer's trailing zero record at every step: the weight
+  // loads are UNCONDITIONAL.  (As `tile valid ? load : 0` each load sat in its own branch diamond, hipcc's s_waitcnt
+  // insertion lost count at every join and waited vmcnt(0) -- for the request just issued, a full L2 round trip --
+  // once per ring revolution: +5...11 % on the C >= 128, K >= 7 convs, profiles/r02_s14.)
+  uint32_t widx[WN], wstep[WN];
 #pragma unroll
-  for (int n = 0; n < WN; ++n) widx[n] = (uint32_t)(ntile0 + n) * (uint32_t)(nchunks * K * 2) * 64u + (uint32_t)lane;
+  for (int n = 0; n < WN; ++n) {
+    const bool valid = (ntile0 + n) < ntiles_co;
+    widx[n] = (valid ? (uint32_t)(ntile0 + n) : (uint32_t)ntiles_co) * (uint32_t)(nchunks * K * 2) * 64u + (uint32_t)lane;
+    wstep[n] = valid ? 64u : 0u;
+  }
 
   // per-lane LDS byte offset of the A operand: row (trow0 + lane & 31), k-slot half
   const int xl_off = (trow0 + l31) * PITCH + half * 16;
 
+  mark(0);
   if constexpr (DEEP) {
     // Weight fragments are a continuous stream of 1 KiB records (chunk, tap, k-block), requested WDEPTH - 1 k-steps
     // ahead into a ring of WDEPTH register sets.  One k-step is only WM MFMAs (128-256 cycles of a SIMD's matrix
@@ -167,8 +223,7 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
     auto wload = [&](int g, u32x4 (&dst)[WN]) {
       const int r = min(g, total);
 #pragma unroll
-      for (int n = 0; n < WN; ++n)
-        dst[n] = (ntile0 + n) < ntiles_co ? (wbase + (size_t)r * 64)[widx[n]] : u32x4{0u, 0u, 0u, 0u};
+      for (int n = 0; n < WN; ++n) dst[n] = wbase[(uint32_t)r * wstep[n] + widx[n]];
     };
 #pragma unroll
     for (int q = 0; q < WDEPTH - 1; ++q) wload(q, bq[q]);
@@ -176,6 +231,7 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
         __syncthreads();
+        mark(1);
         const unsigned char* xl = xs + ((c + cc) & 1) * BUF + xl_off;
         u32x4 aq[2][WM];          // A operands of the current / next k-step, alternating by step parity (no copies)
 #pragma unroll
@@ -202,17 +258,19 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
             }
           __builtin_amdgcn_sched_barrier(0);
         }
+        mark(2);
       }
     }
   } else {
   // Weight fragments are requested one k-block ahead.
   u32x4 bcur[WN], bnxt[WN];
 #pragma unroll
-  for (int n = 0; n < WN; ++n) bcur[n] = (ntile0 + n) < ntiles_co ? wbase[widx[n]] : u32x4{0u, 0u, 0u, 0u};
+  for (int n = 0; n < WN; ++n) bcur[n] = wbase[widx[n]];
 
   int rec = 0;
   for (int c = 0; c < nchunks; ++c) {
     __syncthreads();
+    mark(1);
     const unsigned char* xl = xs + (c & 1) * BUF + xl_off;
     constexpr int STEPS = 2 * K;                            // (tap, k-block) pairs of one chunk
     u32x4 aq[2][WM];          // A operands of the current / next k-step, alternating by step parity (no copies)
@@ -222,8 +280,7 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
     for (int s = 0; s < STEPS; ++s) {
       ++rec;   // one zero record per output tile is appended by the packer for the final prefetch
 #pragma unroll
-      for (int n = 0; n < WN; ++n)
-        bnxt[n] = (ntile0 + n) < ntiles_co ? (wbase + (size_t)rec * 64)[widx[n]] : u32x4{0u, 0u, 0u, 0u};
+      for (int n = 0; n < WN; ++n) bnxt[n] = wbase[(uint32_t)rec * wstep[n] + widx[n]];
       if (s + 1 < STEPS) {
         const int tap = (s + 1) >> 1, kb = (s + 1) & 1;
 #pragma unroll
@@ -244,6 +301,7 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
 #pragma unroll
       for (int n = 0; n < WN; ++n) bcur[n] = bnxt[n];
     }
+    mark(2);
   }
   }
 
@@ -276,13 +334,56 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
     }
   }
 
-  // ---- epilogue: scale, round to bf16, store channels-last (32 lanes = 64 contiguous bytes) -------------
-  // (Measured and dropped in round 2: issuing the MFMAs transposed, as the fused-pair kernel does, so that a lane
-  // holds 4 x 4 consecutive channels of ONE time row and stores 8 bytes at a time -- a quarter of the store
-  // instructions, but each touching 32 rows x 16 B instead of 2 rows x 64 B: no faster on any shape here, within the
-  // +-3 % box-to-box spread, profiles/r02_s10_bf16_convs.txt.)
-  // ConvTranspose (phase_s > 1): column n = phase * C + c of the phase conv is channel c of output row
-  // t * phase_s + phase (a 32-column tile never straddles a phase because C % 32 == 0).
+  // ---- epilogue: scale, round to bf16, store channels-last ------------------------------------------------
+  // Plain convs (phase_s <= 1): the workgroup's TT x NB output tile goes through LDS and leaves as 16-byte stores of
+  // whole rows -- NB * 2 bytes contiguous per time row, 4 KiB per instruction round of the four matrix waves.  Storing
+  // from the accumulator layout is 64 two-byte store instructions per lane and tile, each 2 x 64 bytes, and the CU's
+  // store path is issue-bound (the regime profiles/r02_s13 measured on the fp32 kernel): staging took the k = 3 convs
+  // 10-20 % down (profiles/r02_s14).  (MFMAs issued transposed + 8-byte stores from registers, tried earlier in round
+  // 2, touch 32 rows x 16 B per instruction and were no faster.)
+  mark(3);
+  if (p.phase_s <= 1) {
+    const float scale = p.scale;
+    const float oslope = p.out_slope > 0.f ? p.out_slope : 1.f;   // 0 (old callers) = none
+    unsigned char* stg_out = xs;
+    __syncthreads();   // every matrix wave is done reading the chunk buffers (the loader waves have exited; a barrier
+                       // counts the live waves only)
+    // lanes 0-31: 32 consecutive channels of row t, lanes 32-63: of row t + 4 -> 4 * SP = 64 (mod 256) bytes apart:
+    // the two half-waves land in disjoint bank groups
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+      unsigned char* colp = stg_out + (32 * (wc * WN + n) + l31) * 2 + (trow0 + 4 * half) * SP;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][n][r] * scale;
+          v = v > 0.f ? v : v * oslope;      // optional activation on the way out (its only consumer applies it anyway)
+          *reinterpret_cast<uint16_t*>(colp + (32 * i + (r & 3) + 8 * (r >> 2)) * SP) = f2bf(v);
+        }
+    }
+    mark(4);
+    __syncthreads();
+    mark(5);
+    constexpr int V_ROW = NBW / 8;                            // 16-byte vectors per row
+    constexpr int NVEC = TT * V_ROW;
+    uint16_t* outb = p.out + ((int64_t)b * L * Cout + (int64_t)blockIdx.z * NBW);
+    const int ncol = min(NBW, Cout - (int)blockIdx.z * NBW);   // a partial last N-block stores its real columns only
+#pragma unroll
+    for (int k = 0; k < NVEC / 256; ++k) {
+      const int idx = k * 256 + tid;                          // tid < 256: the matrix waves
+      const int row = idx / V_ROW, c8 = (idx % V_ROW) * 8;
+      const int t = t0 + row;
+      if (t < L && c8 < ncol) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stg_out + row * SP + c8 * 2);
+        *reinterpret_cast<u32x4*>(outb + (int64_t)t * Cout + c8) = v;
+      }
+    }
+    mark(6);
+    dump();
+    return;
+  }
+  // ConvTranspose (phase_s > 1): from the accumulator layout, 32 lanes = 64 contiguous bytes.
   const int s_ph = p.phase_s > 1 ? p.phase_s : 1;
   const int Creal = Cout / s_ph;
   uint16_t* outb = p.out + (int64_t)b * L * Cout;           // L * s_ph rows of Creal channels
@@ -321,24 +422,27 @@ int launch(const ov_conv1d_bf16_params* p, hipStream_t stream) {
   const dim3 grid2 = grid;
 #define OV16_GO(DEEP_, NLD_) \
   hipLaunchKernelGGL((conv1d_bf16cl_kernel<K, DIL, WM, WN, WVT, WVC, DEEP_, NLD_>), grid2, dim3(64 * (4 + NLD_)), 0, stream, *p)
-  if (deep && four) OV16_GO(true, 4);
-  else if (deep) OV16_GO(true, 2);
-  else if (four) OV16_GO(false, 4);
+  if constexpr (32 * WN * WVC > 64) {   // (the narrow layouts never take the deep path: not instantiated)
+    if (deep && four) { OV16_GO(true, 4); goto launched; }
+    if (deep) { OV16_GO(true, 2); goto launched; }
+  }
+  if (four) OV16_GO(false, 4);
   else OV16_GO(false, 2);
+launched:
 #undef OV16_GO
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
 }
 
 // Wave layouts by output width.  Weights are streamed from L2 once per (wave, k-block) and reused for the WM time
-// sub-tiles of the wave; with a 64x64 wave tile (WM = 2) the four waves of a CU pull 64 B/clk of weights -- the
-// whole L1 fill rate -- so from 128 output columns up a wave owns 128 time rows x 32 columns (WM = 4, WN = 1):
-// half the weight traffic, twice the (cheap) LDS operand reads.  >= 128 columns: 128 t x 128 co per workgroup
-// (wider outputs in N-blocks); 64 -> 256 t x 64 co; 32 -> 256 t x 32 co (4 waves along time in both).
+// sub-tiles of the wave; from 128 output columns up a wave owns 128 time rows x 32 columns (WM = 4, WN = 1): half the
+// weight traffic of a 64x64 wave tile, twice the (cheap) LDS operand reads.  >= 128 columns: 128 t x 128 co per
+// workgroup (wider outputs in N-blocks); 64 -> 256 t x 64 co; 32 -> 256 t x 32 co (4 waves along time in both).
+// Measured and not kept (profiles/r02_s14_bf16_conv_findings.txt): 64x64 and 128 t x 64 co wave tiles, 256-row wave
+// tiles (half the weight traffic, one workgroup per CU), a weight ring of 8, LDS operand reads two k-steps ahead,
+// persistent workgroups with the next tile's first chunk requested before the epilogue.
 template <int K, int DIL>
 int launch_by_width(const ov_conv1d_bf16_params* p, hipStream_t stream) {
-  if (p->Cout > 64 && p->layout == 3)       // measurement: 128 t x 64 co per wave (half the LDS operand reads per MFMA)
-    return p->Cout % 256 == 0 ? launch<K, DIL, 4, 2, 1, 4>(p, stream) : launch<K, DIL, 4, 2, 2, 2>(p, stream);
-  if (p->Cout > 64) return p->layout == 1 ? launch<K, DIL, 2, 2, 2, 2>(p, stream) : launch<K, DIL, 4, 1, 1, 4>(p, stream);
+  if (p->Cout > 64) return launch<K, DIL, 4, 1, 1, 4>(p, stream);
   if (p->Cout > 32) return launch<K, DIL, 2, 2, 4, 1>(p, stream);
   return launch<K, DIL, 2, 1, 4, 1>(p, stream);
 }
@@ -435,7 +539,9 @@ int ov_conv1d_bf16cl(const ov_conv1d_bf16_params* p, ov_stream_t stream) {
   if (p->phase_s > 1 && (p->Cout % p->phase_s != 0 || (p->Cout / p->phase_s) % 32 != 0 || p->res || p->add))
     return OV_E_UNSUPPORTED;
 
-  if ((reinterpret_cast<uintptr_t>(p->x) & 15) || (reinterpret_cast<uintptr_t>(p->w) & 15)) return OV_E_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(p->x) & 15) || (reinterpret_cast<uintptr_t>(p->w) & 15) ||
+      (reinterpret_cast<uintptr_t>(p->out) & 15))
+    return OV_E_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define OV16_CASE(KK, DD) if (p->K == KK && p->dil == DD) return launch_by_width<KK, DD>(p, st);
   OV16_CASE(3, 1) OV16_CASE(3, 3) OV16_CASE(3, 5)
