@@ -18,6 +18,7 @@ EPI_LINEAR, EPI_GATE, EPI_RESSKIP, EPI_COUPLE, EPI_POSTERIOR, EPI_CONVT, EPI_MAG
 F_MASK_V = 1
 F_OUT2_INIT = 2
 F_CONVT_GROUPED = 4
+F_NO_XCD_MAP = 8      # measurement knob: round-robin tile order instead of XCD-contiguous (include/openvoice_amd.h)
 
 _fp = ctypes.c_void_p
 _i = ctypes.c_int

@@ -50,6 +50,29 @@ def test_resblock_conv_shapes(c, k, d):
     _close(out, ref, what=f"C={c} k={k} d={d}")
 
 
+@pytest.mark.parametrize("c,k,d,B,L,tpw", [(256, 3, 1, 3, 1000, 0), (256, 11, 5, 5, 520, -1), (128, 7, 3, 7, 1096, 2),
+                                           (64, 3, 1, 3, 2056, -1), (32, 11, 1, 9, 2312, 3)])
+def test_xcd_contiguous_tile_order_is_bit_identical_to_round_robin(c, k, d, B, L, tpw):
+    """The XCD-contiguous work order (each XCD = workgroup id % 8 owns a contiguous eighth of the (utterance, time
+    tile, M-block) list; launches padded to multiples of 8 workgroups, the surplus exits) visits every tile exactly
+    once: same bits as the round-robin order (OV_F_NO_XCD_MAP) and right against the CPU reference -- tile counts that
+    are not multiples of 8, several M-blocks per time tile (C = 256), persistent and forced tiles-per-workgroup
+    launches."""
+    x, res = _rand(B, c, L, seed=21), _rand(B, c, L, seed=22)
+    w, bias = _rand(c, c, k, seed=23, scale=(c * k) ** -0.5), _rand(c, seed=24, scale=0.1)
+    ref = F.conv1d(F.leaky_relu(x, 0.1), w, bias, dilation=d, padding=(k - 1) * d // 2) + res
+    layer = PackedConv(w, bias, DEV, K=k, dil=d)
+    xd, rd = x.to(DEV), res.to(DEV)
+    outs = []
+    for flags in (0, _lib.F_NO_XCD_MAP):
+        out = torch.full((B, c, L), float("nan"), device=DEV)
+        launch_conv(layer, xd, 0, c * L, out, 0, c * L, B, L, in_slope=0.1, res=rd, res_bs=c * L, flags=flags,
+                    tiles_per_wg=tpw)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    _close(outs[0], ref, what=f"C={c} k={k} d={d} B={B} L={L} tpw={tpw}")
+
+
 @pytest.mark.parametrize("c,k,d,L,tpw", [(32, 3, 1, 2312, 2), (32, 11, 5, 2312, 4), (64, 7, 3, 2056, 3),
                                          (128, 3, 5, 1096, 4), (256, 11, 1, 520, 2), (128, 7, 1, 1096, 16)])
 def test_resblock_conv_several_tiles_per_workgroup(c, k, d, L, tpw):
