@@ -414,20 +414,18 @@ int launch(const ov_conv1d_bf16_params* p, hipStream_t stream) {
   constexpr int TT = 32 * WM * WVT, NB = 32 * WN * WVC;
   dim3 grid((p->L + TT - 1) / TT, p->B, (p->Cout + NB - 1) / NB);
   // Deep weight prefetch for Cout > 64 (C = 64 measured 5-20 % slower with it); layout 2 = the one-step-ahead request
-  // of round 1 (measurement knob).  Loader waves: the staging pass costs ~350 instructions per lane and item (unpack,
-  // leaky-ReLU, repack) -- with 2 loader waves that is longer than a K = 3 chunk's MFMAs and than an identity round, so
-  // K = 3 and every launch with a residual get 4 (measured: -8...-18 % there, +3...+9 % on plain K >= 7 launches).
+  // of round 1 (measurement knob).  Four loader waves on every launch: one per SIMD, so that the four matrix waves of
+  // a workgroup -- which re-synchronise at every chunk barrier -- all share their SIMD with the same company.  (With
+  // the cheap packed leaky-ReLU pass, 4 loaders are 3-17 % faster than 2 on every plain K >= 7 shape as well:
+  // profiles/r02_s14_bf16_conv_findings.txt; round 1's slower pass had it the other way round.)
   const bool deep = p->Cin % (2 * CH) == 0 && p->Cout > 64 && p->layout != 2;
-  const bool four = (K == 3 || p->res != nullptr) && p->layout != 2;
   const dim3 grid2 = grid;
 #define OV16_GO(DEEP_, NLD_) \
   hipLaunchKernelGGL((conv1d_bf16cl_kernel<K, DIL, WM, WN, WVT, WVC, DEEP_, NLD_>), grid2, dim3(64 * (4 + NLD_)), 0, stream, *p)
   if constexpr (32 * WN * WVC > 64) {   // (the narrow layouts never take the deep path: not instantiated)
-    if (deep && four) { OV16_GO(true, 4); goto launched; }
-    if (deep) { OV16_GO(true, 2); goto launched; }
+    if (deep) { OV16_GO(true, 4); goto launched; }
   }
-  if (four) OV16_GO(false, 4);
-  else OV16_GO(false, 2);
+  OV16_GO(false, 4);
 launched:
 #undef OV16_GO
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;

@@ -63,10 +63,8 @@ def main():
                     kw.update(res=res, add=add, scale=1.0 / 3.0)
                     passes = 4
                 for lay in args.layouts:
-                    if lay and c <= 64:
+                    if lay not in (0, 7) and c <= 64:
                         continue
-                    if lay == 3 and mode != "plain" and c == 128:
-                        pass
                     kw["layout"] = lay
                     ms = timed(lambda: launch_conv_bf16(layer, x, out, **kw), args.reps, 100.0)   # clocks ramped
                     gbs = passes * 2.0 * B * c * L / ms / 1e6
