@@ -65,14 +65,19 @@ __device__ __forceinline__ uint32_t lrelu_bf16x2(uint32_t w, float slope) {
 // DEEP: weight fragments are requested WDEPTH - 1 k-steps ahead instead of one (see the main loop); needs an even
 // number of 32-channel chunks (Cin % 64 == 0).
 // NLD: loader waves (2 or 4).
-template <int K, int DIL, int WM, int WN, int WVT, int WVC, bool DEEP, int NLD>
+// SCH: 32-channel chunks per staging round (1 or 2): with 2 a round stages 64 channels -- half the chunk barriers
+// (where the four matrix waves of a workgroup re-synchronise: ~1 500 cycles each, profiles/r02_s14) and half the
+// identity rounds; needs Cin % 64 == 0.
+template <int K, int DIL, int WM, int WN, int WVT, int WVC, bool DEEP, int NLD, int SCH>
 __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_conv1d_bf16_params p) {
   static_assert(WVT * WVC == 4, "4 matrix waves");
   constexpr int TT = 32 * WM * WVT;             // time rows per workgroup
   constexpr int PAD = (K - 1) * DIL / 2;
   constexpr int R = TT + 2 * PAD;               // staged rows
-  constexpr int BUF = R * PITCH;                // bytes per LDS buffer
-  constexpr int NITEM = R * 4;                  // 16-byte vectors per chunk
+  constexpr int PITCHV = SCH * 64 + 16;         // bytes per LDS row: 64 / 128 data + 16 pad (conflict-free b128 reads)
+  constexpr int BUF = R * PITCHV;               // bytes per LDS buffer
+  constexpr int VPR = 4 * SCH;                  // 16-byte vectors per staged row
+  constexpr int NITEM = R * VPR;                // 16-byte vectors per round
   constexpr int PER_LANE = (NITEM + 64 * NLD - 1) / (64 * NLD);
   // one LDS block: the two chunk buffers during the main loop, the output staging tile in the epilogue
   constexpr int NBW = 32 * WN * WVC;                          // output columns per workgroup
@@ -98,7 +103,8 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
   const int nco_all = (Cout + 31) / 32;
   const int c_first = blockIdx.z * NBT;                     // first res / add chunk this N-block owns
   const int nco = min(NBT, nco_all - c_first);
-  const int rounds_x = nchunks, rounds_res = p.res ? nco : 0, rounds_add = p.add ? nco : 0;
+  const int nco_r = (nco + SCH - 1) / SCH;                  // identity rounds per operand (SCH chunks each)
+  const int rounds_x = nchunks / SCH, rounds_res = p.res ? nco_r : 0, rounds_add = p.add ? nco_r : 0;
   const int rounds = rounds_x + rounds_res + rounds_add;
   if (is_loader) {
     const int llane = (wave - 4) * 64 + lane;
@@ -110,16 +116,18 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
     auto issue = [&](int rd) {
       const uint16_t* src;
       int cw, c, rlo, rhi;
-      if (rd < rounds_x) { src = p.x + (int64_t)b * L * Cin; cw = Cin; c = rd; rlo = 0; rhi = R; }
-      else if (rd < rounds_x + rounds_res) { src = p.res + (int64_t)b * L * Cout; cw = Cout; c = c_first + rd - rounds_x; rlo = PAD; rhi = PAD + TT; }
-      else { src = p.add + (int64_t)b * L * Cout; cw = Cout; c = c_first + rd - rounds_x - rounds_res; rlo = PAD; rhi = PAD + TT; }
+      // c = first 32-channel chunk of the round (SCH chunks are staged side by side)
+      if (rd < rounds_x) { src = p.x + (int64_t)b * L * Cin; cw = Cin; c = rd * SCH; rlo = 0; rhi = R; }
+      else if (rd < rounds_x + rounds_res) { src = p.res + (int64_t)b * L * Cout; cw = Cout; c = c_first + (rd - rounds_x) * SCH; rlo = PAD; rhi = PAD + TT; }
+      else { src = p.add + (int64_t)b * L * Cout; cw = Cout; c = c_first + (rd - rounds_x - rounds_res) * SCH; rlo = PAD; rhi = PAD + TT; }
 #pragma unroll
       for (int i = 0; i < PER_LANE; ++i) {
         const int idx = i * (64 * NLD) + llane;
-        const int row = idx >> 2, q = idx & 3;
+        const int row = idx / VPR, q = idx % VPR;
         const int t = t0 - PAD + row;
-        ok[i] = (idx < NITEM && row >= rlo && row < rhi && t >= 0 && t < L) ? 1 : 0;
-        const int64_t off = ok[i] ? ((int64_t)t * cw + c * CH + q * 8) : 0;
+        const int ch = c * CH + q * 8;                        // (a partial last N-block: channels past the end read 0)
+        ok[i] = (idx < NITEM && row >= rlo && row < rhi && t >= 0 && t < L && ch < cw) ? 1 : 0;
+        const int64_t off = ok[i] ? ((int64_t)t * cw + ch) : 0;
         stg[i] = *reinterpret_cast<const u32x4*>(src + off);
       }
     };
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
               for (int e = 0; e < 4; ++e) v[e] = lrelu_bf16x2<false>(v[e], slope);
             }
           }
-          *reinterpret_cast<u32x4*>(dst + (idx >> 2) * PITCH + (idx & 3) * 16) = v;
+          *reinterpret_cast<u32x4*>(dst + (idx / VPR) * PITCHV + (idx % VPR) * 16) = v;
         }
       }
       if (rd + 1 < rounds) issue(rd + 1);   // next round's loads fly while the matrix waves work on this one
@@ -205,7 +213,7 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
   }
 
   // per-lane LDS byte offset of the A operand: row (trow0 + lane & 31), k-slot half
-  const int xl_off = (trow0 + l31) * PITCH + half * 16;
+  const int xl_off = (trow0 + l31) * PITCHV + half * 16;
 
   mark(0);
   if constexpr (DEEP) {
@@ -230,12 +238,14 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
     for (int c = 0; c < nchunks; c += 2) {
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
-        __syncthreads();
-        mark(1);
-        const unsigned char* xl = xs + ((c + cc) & 1) * BUF + xl_off;
+        if (SCH == 1 || cc == 0) {   // one hand-off per staging round (SCH chunks)
+          __syncthreads();
+          mark(1);
+        }
+        const unsigned char* xl = xs + (((c + cc) / SCH) & 1) * BUF + xl_off + ((c + cc) % SCH) * 64;
         u32x4 aq[2][WM];          // A operands of the current / next k-step, alternating by step parity (no copies)
 #pragma unroll
-        for (int i = 0; i < WM; ++i) aq[0][i] = *reinterpret_cast<const u32x4*>(xl + (32 * i) * PITCH);   // tap 0, kb 0
+        for (int i = 0; i < WM; ++i) aq[0][i] = *reinterpret_cast<const u32x4*>(xl + (32 * i) * PITCHV);   // tap 0, kb 0
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
           const int gs = cc * STEPS + s;                          // step inside the chunk pair: static
@@ -244,7 +254,7 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
             const int tap = (s + 1) >> 1, kb = (s + 1) & 1;
 #pragma unroll
             for (int i = 0; i < WM; ++i)
-              aq[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(xl + (32 * i + tap * DIL) * PITCH + kb * 32);
+              aq[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(xl + (32 * i + tap * DIL) * PITCHV + kb * 32);
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -269,13 +279,15 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
 
   int rec = 0;
   for (int c = 0; c < nchunks; ++c) {
-    __syncthreads();
-    mark(1);
-    const unsigned char* xl = xs + (c & 1) * BUF + xl_off;
+    if (c % SCH == 0) {   // one hand-off per staging round (SCH chunks)
+      __syncthreads();
+      mark(1);
+    }
+    const unsigned char* xl = xs + ((c / SCH) & 1) * BUF + xl_off + (c % SCH) * 64;
     constexpr int STEPS = 2 * K;                            // (tap, k-block) pairs of one chunk
     u32x4 aq[2][WM];          // A operands of the current / next k-step, alternating by step parity (no copies)
 #pragma unroll
-    for (int i = 0; i < WM; ++i) aq[0][i] = *reinterpret_cast<const u32x4*>(xl + (32 * i) * PITCH);   // tap 0, kb 0
+    for (int i = 0; i < WM; ++i) aq[0][i] = *reinterpret_cast<const u32x4*>(xl + (32 * i) * PITCHV);   // tap 0, kb 0
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       ++rec;   // one zero record per output tile is appended by the packer for the final prefetch
@@ -285,7 +297,7 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
         const int tap = (s + 1) >> 1, kb = (s + 1) & 1;
 #pragma unroll
         for (int i = 0; i < WM; ++i)
-          aq[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(xl + (32 * i + tap * DIL) * PITCH + kb * 32);
+          aq[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(xl + (32 * i + tap * DIL) * PITCHV + kb * 32);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -308,8 +320,10 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
   // ---- identity rounds: acc += res, acc += add ----------------------------------------------------------
   for (int rd = rounds_x; rd < rounds; ++rd) {
     __syncthreads();
-    const int c = c_first + (rd - rounds_x) % nco;          // 32-channel chunk of res / add staged this round
-    const unsigned char* xl = xs + (rd & 1) * BUF + xl_off + PAD * PITCH;
+#pragma unroll
+    for (int sub = 0; sub < SCH; ++sub) {
+    const int c = c_first + ((rd - rounds_x) % nco_r) * SCH + sub;   // 32-channel chunk of res / add in this round
+    const unsigned char* xl = xs + (rd & 1) * BUF + xl_off + PAD * PITCHV + sub * 64;
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
       if (c != ntile0 + n) continue;                        // only the wave that owns these 32 output channels
@@ -325,12 +339,13 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
         __builtin_memcpy(&bv, &idw, 16);
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
-          const u32x4 a = *reinterpret_cast<const u32x4*>(xl + (32 * i) * PITCH + kb * 32);
+          const u32x4 a = *reinterpret_cast<const u32x4*>(xl + (32 * i) * PITCHV + kb * 32);
           bf16x8 av;
           __builtin_memcpy(&av, &a, 16);
           acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][n], 0, 0, 0);
         }
       }
+    }
     }
   }
 
@@ -420,12 +435,16 @@ int launch(const ov_conv1d_bf16_params* p, hipStream_t stream) {
   // profiles/r02_s14_bf16_conv_findings.txt; round 1's slower pass had it the other way round.)
   const bool deep = p->Cin % (2 * CH) == 0 && p->Cout > 64 && p->layout != 2;
   const dim3 grid2 = grid;
-#define OV16_GO(DEEP_, NLD_) \
-  hipLaunchKernelGGL((conv1d_bf16cl_kernel<K, DIL, WM, WN, WVT, WVC, DEEP_, NLD_>), grid2, dim3(64 * (4 + NLD_)), 0, stream, *p)
+#define OV16_GO(DEEP_, NLD_, SCH_) \
+  hipLaunchKernelGGL((conv1d_bf16cl_kernel<K, DIL, WM, WN, WVT, WVC, DEEP_, NLD_, SCH_>), grid2, dim3(64 * (4 + NLD_)), 0, stream, *p)
+  // 64-channel staging rounds on the wide layout whenever Cin % 64 == 0 (layout 8: 32-channel rounds, A/B knob);
+  // on the 64-column layout they measured 0-8 % slower (profiles/r02_s14) and are not instantiated
+  const bool wide = p->Cin % (2 * CH) == 0 && p->layout != 8 && p->layout != 2;
   if constexpr (32 * WN * WVC > 64) {   // (the narrow layouts never take the deep path: not instantiated)
-    if (deep) { OV16_GO(true, 4); goto launched; }
+    if (deep && wide) { OV16_GO(true, 4, 2); goto launched; }
+    if (deep) { OV16_GO(true, 4, 1); goto launched; }
   }
-  OV16_GO(false, 4);
+  OV16_GO(false, 4, 1);
 launched:
 #undef OV16_GO
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;

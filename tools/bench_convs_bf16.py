@@ -63,7 +63,7 @@ def main():
                     kw.update(res=res, add=add, scale=1.0 / 3.0)
                     passes = 4
                 for lay in args.layouts:
-                    if lay not in (0, 7) and c <= 64:
+                    if lay not in (0, 7, 8) and c <= 64:
                         continue
                     kw["layout"] = lay
                     ms = timed(lambda: launch_conv_bf16(layer, x, out, **kw), args.reps, 100.0)   # clocks ramped
