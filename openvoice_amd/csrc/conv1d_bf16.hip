@@ -27,6 +27,8 @@ namespace ovk16 {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int CH = 32;          // input channels per LDS chunk = 2 MFMA k-blocks
 constexpr int PITCH = 80;       // bytes per LDS row: 64 data + 16 pad
@@ -36,6 +38,16 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
   __bf16 h = (__bf16)f;         // v_cvt_pk_bf16_f32: round to nearest even
   uint16_t u;
   __builtin_memcpy(&u, &h, 2);
+  return u;
+}
+
+// two floats -> packed bf16 pair (lo | hi << 16), round to nearest even: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  const b2 r = __builtin_convertvector(f2{lo, hi}, b2);
+  uint32_t u;
+  __builtin_memcpy(&u, &r, 4);
   return u;
 }
 
@@ -186,16 +198,24 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
   const int trow0 = wt * (32 * WM);                         // first time row (within the workgroup tile)
   const int ntiles_co = (Cout + 31) / 32;
 
-  // accumulators start at the bias; residual and running sum arrive as identity rounds (see above)
+  // The MFMAs run TRANSPOSED (operands swapped: D^T = W^T X^T, same products, same order), so a lane holds ONE time row
+  // (trow0 + 32 i + lane & 31) and, per 32-column tile, 16 output channels in 4 groups of 4 consecutive ones:
+  // channel 8 q + 4 (lane >> 5) + e for registers 4 q + e.  The epilogue packs a group into 8 bytes -- a quarter of the
+  // LDS / memory instructions of the channel-per-lane layout (tile -> LDS was 3 500 of a tile's 17-33 k cycles).
+  // Accumulators start at the bias; residual and running sum arrive as identity rounds (see above).
   f32x16 acc[WM][WN];
 #pragma unroll
   for (int n = 0; n < WN; ++n) {
-    const int co = 32 * (ntile0 + n) + l31;
-    const float bv = (p.bias && co < Cout) ? p.bias[(int64_t)b * p.bias_bstride + co] : 0.f;
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+    for (int q = 0; q < 4; ++q) {
+      const int co = 32 * (ntile0 + n) + 8 * q + 4 * half;
+      f32x4v bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && co < Cout) bv = *reinterpret_cast<const f32x4v*>(p.bias + (int64_t)b * p.bias_bstride + co);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][n][r] = bv;
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][n][4 * q + e] = bv[e];
+    }
   }
 
   // packed weights: record index ((nt * nchunks + c) * K + tap) * 2 + kb, 64 lanes x 16 bytes each
@@ -264,7 +284,7 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
               bf16x8 av, bv;
               __builtin_memcpy(&av, &aq[s & 1][i], 16);
               __builtin_memcpy(&bv, &bq[gs % WDEPTH][n], 16);
-              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][n], 0, 0, 0);
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc[i][n], 0, 0, 0);   // transposed: D^T = W^T X^T
             }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -307,7 +327,7 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
           bf16x8 av, bv;
           __builtin_memcpy(&av, &aq[s & 1][i], 16);
           __builtin_memcpy(&bv, &bcur[n], 16);
-          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][n], 0, 0, 0);
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc[i][n], 0, 0, 0);   // transposed: D^T = W^T X^T
         }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -342,7 +362,7 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
           const u32x4 a = *reinterpret_cast<const u32x4*>(xl + (32 * i) * PITCHV + kb * 32);
           bf16x8 av;
           __builtin_memcpy(&av, &a, 16);
-          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][n], 0, 0, 0);
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc[i][n], 0, 0, 0);   // transposed: D^T = W^T X^T
         }
       }
     }
@@ -363,19 +383,23 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
     unsigned char* stg_out = xs;
     __syncthreads();   // every matrix wave is done reading the chunk buffers (the loader waves have exited; a barrier
                        // counts the live waves only)
-    // lanes 0-31: 32 consecutive channels of row t, lanes 32-63: of row t + 4 -> 4 * SP = 64 (mod 256) bytes apart:
-    // the two half-waves land in disjoint bank groups
+    // a lane writes its time row's 4-channel groups as 8-byte pieces (ds_write_b64)
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
-      unsigned char* colp = stg_out + (32 * (wc * WN + n) + l31) * 2 + (trow0 + 4 * half) * SP;
 #pragma unroll
-      for (int i = 0; i < WM; ++i)
+      for (int i = 0; i < WM; ++i) {
+        unsigned char* rowp = stg_out + (trow0 + 32 * i + l31) * SP + (32 * (wc * WN + n) + 4 * half) * 2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[i][n][r] * scale;
-          v = v > 0.f ? v : v * oslope;      // optional activation on the way out (its only consumer applies it anyway)
-          *reinterpret_cast<uint16_t*>(colp + (32 * i + (r & 3) + 8 * (r >> 2)) * SP) = f2bf(v);
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[i][n][4 * q + e] * scale;
+            v[e] = v[e] > 0.f ? v[e] : v[e] * oslope;   // optional activation on the way out (its only consumer applies it)
+          }
+          *reinterpret_cast<u32x2*>(rowp + 16 * q) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         }
+      }
     }
     mark(4);
     __syncthreads();
@@ -398,7 +422,7 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
     dump();
     return;
   }
-  // ConvTranspose (phase_s > 1): from the accumulator layout, 32 lanes = 64 contiguous bytes.
+  // ConvTranspose (phase_s > 1): 8-byte stores from the accumulator layout (4 channels of one output row).
   const int s_ph = p.phase_s > 1 ? p.phase_s : 1;
   const int Creal = Cout / s_ph;
   uint16_t* outb = p.out + (int64_t)b * L * Cout;           // L * s_ph rows of Creal channels
@@ -406,18 +430,23 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
   const float oslope = p.out_slope > 0.f ? p.out_slope : 1.f;   // 0 (old callers) = none
 #pragma unroll
   for (int n = 0; n < WN; ++n) {
-    const int col = 32 * (ntile0 + n) + l31;
-    if (col >= Cout) continue;
-    const int ph = col / Creal, co = col - ph * Creal;
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
+    for (int q = 0; q < 4; ++q) {
+      const int col = 32 * (ntile0 + n) + 8 * q + 4 * half;   // 4 consecutive columns = 4 channels of one phase
+      if (col >= Cout) continue;
+      const int ph = col / Creal, co = col - ph * Creal;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int t = t0 + trow0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+      for (int i = 0; i < WM; ++i) {
+        const int t = t0 + trow0 + 32 * i + l31;
         if (t < L) {
-          float v = acc[i][n][r] * scale;
-          v = v > 0.f ? v : v * oslope;      // optional activation on the way out (its only consumer applies it anyway)
-          outb[((int64_t)t * s_ph + ph) * Creal + co] = f2bf(v);
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[i][n][4 * q + e] * scale;
+            v[e] = v[e] > 0.f ? v[e] : v[e] * oslope;
+          }
+          *reinterpret_cast<u32x2*>(outb + ((int64_t)t * s_ph + ph) * Creal + co) =
+              u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         }
       }
     }
@@ -557,7 +586,7 @@ int ov_conv1d_bf16cl(const ov_conv1d_bf16_params* p, ov_stream_t stream) {
     return OV_E_UNSUPPORTED;
 
   if ((reinterpret_cast<uintptr_t>(p->x) & 15) || (reinterpret_cast<uintptr_t>(p->w) & 15) ||
-      (reinterpret_cast<uintptr_t>(p->out) & 15))
+      (reinterpret_cast<uintptr_t>(p->out) & 15) || (p->bias && ((reinterpret_cast<uintptr_t>(p->bias) & 15) || p->bias_bstride % 4)))
     return OV_E_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define OV16_CASE(KK, DD) if (p->K == KK && p->dil == DD) return launch_by_width<KK, DD>(p, st);
