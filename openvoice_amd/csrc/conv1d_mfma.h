@@ -719,6 +719,7 @@ OV_DECLARE_VARIANTS(kVariantsB)
 OV_DECLARE_VARIANTS(kVariantsC)
 OV_DECLARE_VARIANTS(kVariantsD)
 OV_DECLARE_VARIANTS(kVariantsE)
+OV_DECLARE_VARIANTS(kVariantsF)
 OV_DECLARE_VARIANTS(kVariantsS)
 OV_DECLARE_VARIANTS(kVariantsW)
 

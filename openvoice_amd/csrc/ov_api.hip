@@ -126,9 +126,9 @@ __global__ __launch_bounds__(256) void frame_hops_kernel(const float* __restrict
 }
 
 static conv_launch_fn find_variant(int K, int dil, int tile, int chunk, int vec, int epi, int nld) {
-  const ConvVariant* tabs[] = {kVariantsA, kVariantsB, kVariantsC, kVariantsD, kVariantsE, kVariantsS, kVariantsW};
+  const ConvVariant* tabs[] = {kVariantsA, kVariantsB, kVariantsC, kVariantsD, kVariantsE, kVariantsF, kVariantsS, kVariantsW};
   const int ns[] = {kVariantsACount, kVariantsBCount, kVariantsCCount, kVariantsDCount,
-                    kVariantsECount, kVariantsSCount, kVariantsWCount};
+                    kVariantsECount, kVariantsFCount, kVariantsSCount, kVariantsWCount};
   for (unsigned t = 0; t < sizeof(ns) / sizeof(ns[0]); ++t)
     for (int i = 0; i < ns[t]; ++i) {
       const ConvVariant& v = tabs[t][i];
@@ -146,8 +146,10 @@ static conv_launch_fn find_variant(int K, int dil, int tile, int chunk, int vec,
 //  * channels per LDS chunk: 32 wherever the double buffer still allows >= 2 workgroups per CU
 //    (fewer chunk hand-offs: +1...10 %), 16 for the 32-row tiles.
 static void loader_preference(int tile, int K, int out[3]) {
-  if (K == 1 || tile != TILE_128x128) { out[0] = 4; out[1] = 2; out[2] = 1; return; }
-  out[0] = 2; out[1] = 4; out[2] = 1;
+  // four loader waves (one per SIMD) wherever that instance exists: every tile and K measured faster or equal with
+  // them (profiles/r02_s17_convs_loaders_2_vs_4.txt; round 1's sweep, on an earlier kernel, had 2 ahead at 128x128)
+  (void)tile; (void)K;
+  out[0] = 4; out[1] = 2; out[2] = 1;
 }
 static void chunk_preference(int tile, int K, int out[2]) {
   if (K != 1 && (tile == TILE_32x512 || tile == TILE_32x256)) { out[0] = 16; out[1] = 32; return; }
