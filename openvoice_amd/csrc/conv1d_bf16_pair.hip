@@ -416,29 +416,12 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair_bf16cl_kernel(const 
       // ---- epilogue: scale, round, store 4 consecutive channels per 8-byte store ----------------------
       const int t = t0 - P2 + trow0 + l31;
       if (t >= 0 && t < L) {
-        // A lane holds 4 groups of 4 channels (8 bytes each) of its time row, its partner lane (+-32) the 4 groups in
-        // between.  v_permlane32_swap on the group pairs (0, 1) and (2, 3) -- the upper half-wave's group-g dwords for
-        // the lower half-wave's group-(g+1) dwords -- leaves 16 contiguous bytes per lane: two 16-byte stores per lane
-        // instead of four 8-byte ones (the store path is issue-bound: the guide's T21).  Same bytes, same addresses.
+        uint16_t* orow = p.out + ((int64_t)b * L + t) * C + 32 * nt + 4 * half;
         const float scale = p.scale;
-        uint32_t o[4][2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          o[g][0] = pack2(acc[4 * g] * scale, acc[4 * g + 1] * scale);
-          o[g][1] = pack2(acc[4 * g + 2] * scale, acc[4 * g + 3] * scale);
-        }
-        // lower half: channels 16 gp .. 16 gp + 7 (own group 2 gp | partner's group 2 gp), upper half: 16 gp + 8 .. + 15
-        uint16_t* orow = p.out + ((int64_t)b * L + t) * C + 32 * nt + 8 * half;
-#pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-          u32x4 w;
-#pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(o[2 * gp][d], o[2 * gp + 1][d], false, false);
-            w[d] = sw[0];
-            w[2 + d] = sw[1];
-          }
-          *reinterpret_cast<u32x4*>(orow + 16 * gp) = w;
+          u32x2 o = {pack2(acc[4 * g] * scale, acc[4 * g + 1] * scale), pack2(acc[4 * g + 2] * scale, acc[4 * g + 3] * scale)};
+          *reinterpret_cast<u32x2*>(orow + 8 * g) = o;
         }
       }
     }
