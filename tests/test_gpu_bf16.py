@@ -39,6 +39,29 @@ def test_resblock_conv_bf16(c, k, d):
     assert err <= bound, f"C={c} k={k} d={d}: {err:.3e} > {bound:.3e}"
 
 
+@pytest.mark.parametrize("cin,cout,k,d,L,with_res", [(64, 192, 7, 1, 333, True), (64, 192, 3, 5, 50, False),
+                                                     (96, 160, 11, 3, 401, True), (128, 320, 3, 1, 129, True)])
+def test_conv_bf16_rectangular_partial_last_n_block(cin, cout, k, d, L, with_res):
+    """Cout not a multiple of the 128 columns a workgroup owns: the last N-block has 1-2 live 32-column tiles (the dead
+    ones read the packer's zero weight record, nothing of theirs is staged or stored), identity rounds of a partial
+    block in 64- and 32-channel staging rounds (Cin % 64 == 0 or not), L shorter than a time tile."""
+    B = 2
+    x = _r(_rand(B, L, cin, seed=1))
+    res, add = _r(_rand(B, L, cout, seed=2)), _r(_rand(B, L, cout, seed=3))
+    w, bias = _r(_rand(cout, cin, k, seed=4, scale=(cin * k) ** -0.5)), _rand(cout, seed=5, scale=0.1)
+    ref = F.conv1d(_r(F.leaky_relu(x, 0.1)).transpose(1, 2), w, bias, dilation=d, padding=(k - 1) * d // 2).transpose(1, 2)
+    kw = {}
+    if with_res:
+        ref = ref + res + add
+        kw = dict(res=res.to(DEV, torch.bfloat16), add=add.to(DEV, torch.bfloat16))
+    layer = PackedConvBf16(w, bias, DEV, dil=d)
+    out = torch.full((B, L, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+    launch_conv_bf16(layer, x.to(DEV, torch.bfloat16), out, in_slope=0.1, **kw)
+    err = (out.float().cpu() - ref).abs().max().item()
+    bound = 1e-2 * max(1.0, ref.abs().max().item())
+    assert err <= bound, f"{cin}->{cout} k={k} d={d} L={L}: {err:.3e} > {bound:.3e}"
+
+
 def test_plain_conv_bf16_no_bias_no_residual():
     B, L, c, k = 1, 300, 64, 7
     x = _r(_rand(B, L, c, seed=1))
