@@ -66,10 +66,9 @@ def main():
            "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
                         "frac": round(flops / dt / 157.3e12, 4), "alg_tflop_per_batch": round(flops / 1e12, 3),
                         "note": "whole infer() incl. its host sync (Ty = y_lengths.max(), as in the reference, "
-                                "models.py:478-480) and the token-rate kernels; the frame-rate convs of this batch "
-                                "run at ~55 % of peak vs 82-88 % in the converter bench: 3 760 frames per batch "
-                                "(1-4 tiles per workgroup slot per launch) and a GPU that never reaches its sustained "
-                                "clock inside a 33 ms call -- profiles/r02_tts_kernel_trace_analysis.txt"}}
+                                "models.py:478-480) and the token-rate kernels; FLOPs counted on the PADDED batch "
+                                "(B x max frames), which is what the unmasked generator computes, here and in the "
+                                "reference.  Per kernel group: profiles/r02_tts_kernel_trace_analysis.txt"}}
     if args.cpu:
         from oracle import tts_oracle
         from openvoice_amd.hostinfo import usable_cpus
