@@ -99,12 +99,14 @@ def _reference_model(sd, cfg):
         return None
 
 
-def cpu_baseline(sd, cfg, seconds, budget_s=20.0, want_reference=True):
+def cpu_baseline(sd, cfg, seconds, budget_s=20.0, want_reference=True, batch32=False):
     """CPU fp32 baseline on this box's host cores: the unmodified
     reference (``kind = "reference"``) where /root/reference is importable, else the oracle -- the CPU restatement
     of the same path in the same torch operators (``kind = "port"``; pinned to reference outputs by
     tests/test_oracle_golden.py).  Bounded sample: B = 1 utterances on all usable threads for ~budget_s (the
-    headline ``value``), then one B = 1 run on ONE thread and one B = 32 run on all threads."""
+    headline ``value``), then one B = 1 run on ONE thread; the B = 32 run on all threads (40-60 s of an otherwise idle
+    GPU lease) only with ``--cpu-batch32`` -- its figure, next to the reference's on the same host, is committed in
+    profiles/r02_cpu_reference_vs_port_build_container.json and BENCH_r02.json (0.76 utterances/s)."""
     from oracle import vc_oracle
     from openvoice_amd.hostinfo import cpu_model, usable_cpus
     cores = usable_cpus(32)
@@ -149,7 +151,10 @@ def cpu_baseline(sd, cfg, seconds, budget_s=20.0, want_reference=True):
     # the benchmark batch, B = 32 (skipped when the B = 1 rate says it would blow the budget)
     torch.set_num_threads(cores)
     est32 = 32.0 * el / n
-    if est32 <= max(30.0, 2.0 * budget_s):
+    if not batch32:
+        out["batch32"] = None
+        sample.append(f"B=32 not run (--cpu-batch32; estimated {est32:.0f} s)")
+    elif est32 <= max(30.0, 4.0 * budget_s):
         wave32 = synth_wave(32, samples, 9, "cpu")
         t0 = time.perf_counter()
         convert(wave32)
@@ -175,9 +180,15 @@ def init_ranks(args, backend):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     gpu = backend == "nccl"
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.force_dist:
         assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "MASTER_ADDR" not in os.environ:        # --force-dist without torch.distributed.run: a 1-rank rendezvous
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         if gpu:
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
@@ -190,12 +201,15 @@ def init_ranks(args, backend):
 
 def timed_steps(step, args, world, dev):
     """``args.warmup`` untimed steps, then EXACTLY ``args.steps`` steps bracketed by a barrier + device synchronise on
-    both sides; returns (seconds, max over ranks; last step's result)."""
+    both sides; returns (seconds = max over ranks, every rank's own seconds, last step's result).  With a process
+    group (N > 1, or N = 1 under --force-dist) the barriers and the all-gather of the ranks' times are real
+    collectives of the backend in use."""
     import torch.distributed as dist
     sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
+    group = dist.is_available() and dist.is_initialized()
 
     def barrier():
-        if world > 1:
+        if group:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -206,13 +220,51 @@ def timed_steps(step, args, world, dev):
     for _ in range(args.steps):
         result = step()
     sync()
+    own = time.perf_counter() - t0      # this rank's own time to finish its steps: shows a straggler
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = tmax.item()
-    return elapsed, result
+    per_rank = [own]
+    if group:
+        mine = torch.tensor([elapsed, own], dtype=torch.float64, device=dev)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        elapsed = max(t[0].item() for t in every)
+        per_rank = [t[1].item() for t in every]
+    return elapsed, per_rank, result
+
+
+def rank_stats(per_rank_s, steps):
+    """Each rank's own ms per step (device-synchronised, before the closing barrier): min / max show a straggler."""
+    ms = [round(t / steps * 1e3, 3) for t in per_rank_s]
+    return {"min": min(ms), "max": max(ms), "ranks": ms}
+
+
+PARITY_TOLERANCE = 1e-3      # BASELINE.json north_star: "output within 1e-3 max-abs of reference fp32"
+
+
+def parity_of_item(model, sd, cfg, wave, se, tau, hop_cfg, item=0, seed=77):
+    """Self-check of the measured configuration: ONE more step of the timed batch with an explicit, seeded noise
+    tensor (the timed steps draw theirs on the device), and the CPU oracle -- spectrogram included -- on ``item`` of
+    that batch with the same noise.  Utterances are independent at full length, so the oracle runs B = 1."""
+    from openvoice_amd.mel_processing import spectrogram_torch
+    from oracle import vc_oracle
+    dev = wave.device
+    d = hop_cfg
+    spec = spectrogram_torch(wave, d.filter_length, d.sampling_rate, d.hop_length, d.win_length, center=False)
+    B, _, T = spec.shape
+    noise = torch.randn(B, cfg["inter_channels"], T, generator=torch.Generator().manual_seed(seed))
+    lengths = torch.full((B,), T, dtype=torch.int64, device=dev)
+    o_hat = model.voice_conversion(spec, lengths, se[0].to(dev), se[1].to(dev), tau=tau, noise=noise.to(dev))[0]
+    got = o_hat[item, 0].cpu()
+    with torch.no_grad():
+        spec1 = vc_oracle.spectrogram(wave[item:item + 1].cpu())
+        want = vc_oracle.voice_conversion(sd, cfg, spec1, torch.tensor([T]), se[0], se[1], tau, noise[item:item + 1],
+                                          zero_g=bool(model.zero_g))[0][0, 0]
+    err = float((got - want).abs().max())
+    return {"max_abs_vs_oracle": err, "tolerance": PARITY_TOLERANCE, "item": item, "ok": bool(err <= PARITY_TOLERANCE),
+            "oracle_peak": round(float(want.abs().max()), 4),
+            "what": f"o_hat[{item}] of the timed batch (one extra step, seeded noise) vs oracle/vc_oracle.py on CPU, "
+                    f"waveform -> spectrogram -> voice_conversion"}
 
 
 def dry_run(args):
@@ -227,24 +279,25 @@ def dry_run(args):
 
     def step():
         src_se, tgt_se = broadcast_speaker_embeddings(se[0] if rank == 0 else None, se[1] if rank == 0 else None,
-                                                      256, dev) if world > 1 else (se[0], se[1])
+                                                      256, dev)      # a collective whenever a group exists
         return wave * (src_se.sum() - tgt_se.sum()), 1      # stand-in for the conversion
 
-    elapsed, (o, _) = timed_steps(step, args, world, dev)
+    elapsed, per_rank, (o, _) = timed_steps(step, args, world, dev)
     ok = bool(torch.allclose(o, wave * (se[0].sum() - se[1].sum())))   # every rank saw rank 0's embeddings
-    if world > 1:
+    if dist.is_initialized():
         flag = torch.tensor([1.0 if ok else 0.0])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item() == 1.0)
     if rank == 0:
         print(json.dumps({"metric": "real_time_factor", "value": None, "unit": "x real-time (audio s / wall s)",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                          "per_rank_ms_per_step": rank_stats(per_rank, args.steps), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "dry_run": True, "broadcast_consistent": ok,
                           "config": {"workload": "control-flow rehearsal on CPU + gloo, no conversion",
                                      "batch_per_gpu": B, "global_batch": B * world}}), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
     return 0 if ok else 1
 
@@ -257,7 +310,15 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=10.0, help="utterance length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--cpu-budget", type=float, default=20.0,
+                    help="seconds of CPU baseline sampling at B = 1 on all threads (plus one 1-thread utterance)")
+    ap.add_argument("--cpu-batch32", action="store_true",
+                    help="also time ONE B = 32 conversion on the CPU (40-60 s during which the GPU idles)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle self-check of the timed batch")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (backend nccl = RCCL) and issue the per-step speaker-embedding "
+                         "broadcast, the barriers and the all-gather of the ranks' times even at --gpus 1, so the "
+                         "multi-GPU code path runs on a one-GPU box (tests/test_gpu_dist.py)")
     ap.add_argument("--bf16-generator", action="store_true",
                     help="NOT the contract configuration: run the generator on the opt-in bf16 kernels "
                          "(BASELINE.json configs[4]); the JSON line is marked accordingly")
@@ -270,6 +331,8 @@ def main():
                          "speaker-embedding broadcast, barriers, max-over-ranks timing, one JSON line on rank 0 -- is "
                          "the code the N-GPU run executes.  The line is marked dry_run and carries no measurement")
     args = ap.parse_args()
+    if args.steps < 1 or args.warmup < 0:
+        ap.error("--steps must be >= 1 and --warmup >= 0")
     if args.dry_run:
         return dry_run(args)
 
@@ -300,14 +363,16 @@ def main():
     d = hps.data
 
     def step():
+        # a real RCCL broadcast whenever a process group exists (N > 1, or N = 1 under --force-dist); else a copy
         src_se, tgt_se = broadcast_speaker_embeddings(se[0] if rank == 0 else None, se[1] if rank == 0 else None,
-                                                      256, dev) if world > 1 else (se[0].to(dev), se[1].to(dev))
+                                                      256, dev)
         spec = spectrogram_torch(wave, d.filter_length, d.sampling_rate, d.hop_length, d.win_length, center=False)
         lengths = torch.full((B,), spec.shape[2], dtype=torch.int64, device=dev)
         o_hat, _, _ = model.voice_conversion(spec, lengths, src_se, tgt_se, tau=0.3)
         return o_hat, spec.shape[2]
 
-    elapsed, (o_hat, frames) = timed_steps(step, args, world, dev)
+    elapsed, per_rank, (o_hat, frames) = timed_steps(step, args, world, dev)
+    dist_on = dist.is_available() and dist.is_initialized()
     assert o_hat.shape == (B, 1, frames * engine.total_upsample) and bool(torch.isfinite(o_hat).all())
 
     # PCIe-inclusive rate, reported beside `value` (never as it): the same step with the waveforms coming from
@@ -381,6 +446,10 @@ def main():
             "unit": "x real-time (audio s / wall s)",
             "utterances_per_s": round(utt_s, 3),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "per_rank_ms_per_step": rank_stats(per_rank, args.steps),
+            "distributed": {"process_group": dist_on, "backend": dist.get_backend() if dist_on else None,
+                            "collectives_per_step": "1 broadcast of [2,256] fp32 (src/tgt se)" if dist_on else "none",
+                            "binding": __import__("openvoice_amd._lib", fromlist=["binding"]).binding()},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (enc_q, flow) + bf16 generator, fp32 accumulation" if args.bf16_generator else "f32",
             "data": "synthetic",
@@ -411,11 +480,22 @@ def main():
                                "kernel": "ovk16::conv1d_bf16cl_kernel (whole bf16 generator, algorithmic bytes)",
                                "generator_ms": round(t_mrf * 1e3, 3)}
             out["note"] = "opt-in configuration (--bf16-generator), not the contract line"
+        rc = 0
+        if not args.no_parity and not args.bf16_generator:
+            try:
+                out["parity"] = parity_of_item(model, sd, cfg, wave, se, 0.3, d)
+                rc = 0 if out["parity"]["ok"] else 3
+            except Exception as exc:   # noqa: BLE001 -- an unverifiable line must not look verified
+                out["parity"] = {"error": repr(exc)[:300], "ok": False, "tolerance": PARITY_TOLERANCE}
+                rc = 3
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, cfg, args.seconds, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(sd, cfg, args.seconds, args.cpu_budget, batch32=args.cpu_batch32)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    else:
+        rc = 0
+    if dist_on:
         dist.destroy_process_group()
+    return rc
 
 
 if __name__ == "__main__":

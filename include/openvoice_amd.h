@@ -193,7 +193,8 @@ typedef struct ov_wn_layer_params {
   const float* cond;     /* or NULL */
   const float* w_rs;
   const float* b_rs;
-  const float* mask;     /* [B][T] 0/1, rows mask_bstride apart (0 = ld) */
+  const float* mask;     /* [B][T] 0/1, rows mask_bstride apart (0 = ld); 16-byte aligned, mask_bstride a multiple
+                          * of 4 and >= T rounded up to 4 (read as 16-byte vectors: OV_E_ALIGN / OV_E_BADARG otherwise) */
   int64_t bstride;       /* batch stride of x / out / skip */
   int64_t cond_bstride;
   int64_t mask_bstride;

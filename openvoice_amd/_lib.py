@@ -1,8 +1,18 @@
-"""ctypes binding of libopenvoice_amd.so (the C ABI declared in include/openvoice_amd.h).
+"""The two bindings of libopenvoice_amd.so (the C ABI declared in include/openvoice_amd.h).
 
-There is no CPU fallback: if the shared library is missing or a launch fails, the caller gets
-an exception.  ``python -c "import __graft_entry__ as g; g.build()"`` (or
-``make -C openvoice_amd/csrc``) produces the library in-tree.
+* ``torch`` (default; BASELINE.json north_star "bound through a thin torch cpp_extension C-ABI"): every launch goes
+  through ``torch.ops.openvoice_amd.*`` (csrc/torch_shim.cpp -> libopenvoice_amd_torch.so, a TORCH_LIBRARY shim with one
+  op per C entry point: tensors in, device / dtype TORCH_CHECKs, current HIP stream picked up in C++, OV_E_* codes
+  raised as RuntimeError).  ctypes is not touched at all in this mode (tests/test_gpu_torch_shim.py makes ``load()``
+  raise and runs a conversion, ``extract_se`` and ``infer``).
+* ``ctypes`` (``OPENVOICE_AMD_BINDING=ctypes``): the same entry points through ``ctypes.CDLL`` -- what a consumer
+  without libtorch binds (INTEGRATION.md level C), and what the C-ABI tests use to reach the functions directly.
+
+Both drive the same kernels with the same arguments; ``call()`` is the one switch point for every entry point with a
+flat argument list, the five parameter-struct entry points have a launch helper each (engine.py, bf16.py).
+
+There is no CPU fallback: if the shared libraries are missing or a launch fails, the caller gets an exception.
+``python -c "import __graft_entry__ as g; g.build()"`` (or ``make -C openvoice_amd/csrc``) produces them in-tree.
 """
 import ctypes
 import os
@@ -152,6 +162,16 @@ def load():
     return _lib
 
 
+def torch_op(name, *args):
+    """One ``torch.ops.openvoice_amd`` op (the parameter-struct launch helpers); errors as ``OvError``."""
+    try:
+        return getattr(torch_ops(), name)(*args)
+    except RuntimeError as exc:
+        if isinstance(exc, OvError):
+            raise
+        raise OvError(str(exc).split("\n")[0]) from None
+
+
 def check(code, what):
     if code != OV_OK:
         raise OvError(f"{what} failed: {OV_ERRORS.get(code, code)}")
@@ -160,23 +180,85 @@ def check(code, what):
 # ---- the torch binding (csrc/torch_shim.cpp): `torch.ops.openvoice_amd.*` -------------------------------------------
 SHIM_PATH = os.path.join(_HERE, "libopenvoice_amd_torch.so")
 _ops = None
+# entry points whose return value is a quantity, not an OV_* status
+VALUE_FUNCS = {"ov_version", "ov_build_experiment", "ov_conv1d_pack_size", "ov_conv1d_pack_rows", "ov_wn_pack_size",
+               "ov_conv1d_bf16_pack_size", "ov_resblock_pair_supported", "ov_wn_layer_supported", "ov_wn_layer_tile",
+               "ov_resblock_pair_bf16_supported"}
+
+
+def binding():
+    """"torch" (default) or "ctypes" -- read from OPENVOICE_AMD_BINDING at every call, so a test can switch it."""
+    # a measurement build selected with OPENVOICE_AMD_LIB lives outside the tree; only ctypes can load it
+    b = os.environ.get("OPENVOICE_AMD_BINDING", "ctypes" if os.environ.get("OPENVOICE_AMD_LIB") else "torch")
+    if b not in ("torch", "ctypes"):
+        raise OvError(f"OPENVOICE_AMD_BINDING={b!r}: expected 'torch' or 'ctypes'")
+    return b
 
 
 def use_torch_binding():
-    """True when launches go through ``torch.ops.openvoice_amd`` (TORCH_LIBRARY shim: current-stream pickup,
-    TORCH_CHECK errors) instead of ctypes.  Selected with OPENVOICE_AMD_BINDING=torch; both bindings drive the same
-    C ABI with the same arguments."""
-    return os.environ.get("OPENVOICE_AMD_BINDING", "ctypes") == "torch"
+    """True when launches go through ``torch.ops.openvoice_amd`` (the TORCH_LIBRARY shim) instead of ctypes."""
+    return binding() == "torch"
 
 
 def torch_ops():
-    """Load (once) the shim and return ``torch.ops.openvoice_amd``; raises if it was not built."""
+    """Load (once) the shim and return ``torch.ops.openvoice_amd``; raises if it was not built.  The shim links
+    libopenvoice_amd.so through its ``$ORIGIN`` rpath: ctypes is not involved."""
     global _ops
     if _ops is None:
         import torch
-        load()                       # libopenvoice_amd.so first: the shim links against it by soname
-        if not os.path.exists(SHIM_PATH):
-            raise OvError(f"{SHIM_PATH} not found: make -C openvoice_amd/csrc torch_shim")
+        for path in (LIB_PATH, SHIM_PATH):
+            if not os.path.exists(path):
+                raise OvError(f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ "
+                              f"as g; g.build()'); there is no CPU fallback (OPENVOICE_AMD_BINDING=ctypes needs only "
+                              f"libopenvoice_amd.so)")
         torch.ops.load_library(SHIM_PATH)
-        _ops = torch.ops.openvoice_amd
+        ops = torch.ops.openvoice_amd
+        exp = ops.build_experiment()
+        if exp != 0 and os.environ.get("OPENVOICE_AMD_ALLOW_EXPERIMENT") != "1":
+            raise OvError(f"{LIB_PATH} is a measurement build (OV_EXP={exp}); rebuild with "
+                          f"`make -C openvoice_amd/csrc clean all`")
+        _ops = ops
     return _ops
+
+
+def _flat_view(t, off):
+    """A 1-D alias of ``t``'s storage starting ``off`` elements after its first element (what ``ptr + off`` is to C)."""
+    start = t.storage_offset() + off
+    n = t.untyped_storage().nbytes() // t.element_size() - start
+    return t.as_strided((n,), (1,), start)
+
+
+def call(name, *args):
+    """Invoke the C entry point ``name`` (e.g. ``"ov_linear_f32"``) through the selected binding.  ``args`` follow
+    the C prototype WITHOUT the trailing stream: tensors (or ``(tensor, element_offset)`` pairs, or None) where C takes
+    pointers, Python numbers elsewhere.  Device entry points launch on torch's current stream of the tensors' device.
+    Status-returning functions raise on a non-zero code; size / capability queries return their value."""
+    if use_torch_binding():
+        targs = [_flat_view(*a) if type(a) is tuple else a for a in args]
+        try:
+            return getattr(torch_ops(), name[3:])(*targs)
+        except RuntimeError as exc:       # TORCH_CHECK failures surface as the same exception type as ctypes codes
+            if isinstance(exc, OvError):
+                raise
+            raise OvError(str(exc).split("\n")[0]) from None
+    import torch
+    lib = load()
+    fn = getattr(lib, name)
+    cargs, dev = [], None
+    for a in args:
+        off = 0
+        if type(a) is tuple:
+            a, off = a
+        if isinstance(a, torch.Tensor):
+            if dev is None and a.is_cuda:
+                dev = a.device
+            a = ctypes.c_void_p(a.data_ptr() + off * a.element_size())
+        cargs.append(a)
+    if len(fn.argtypes) == len(cargs) + 1:            # device entry point: the stream is the last C parameter
+        if dev is None:
+            raise OvError(f"{name}: no device tensor among the arguments")
+        cargs.append(ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    rc = fn(*cargs)
+    if name in VALUE_FUNCS:
+        return rc
+    check(rc, name)

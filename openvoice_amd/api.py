@@ -203,22 +203,36 @@ class ToneColorConverter(OpenVoiceBaseClass):
 
     def extract_se(self, ref_wav_list, se_save_path=None):
         """Mean reference-encoder embedding over the given audio files -> ``[1, gin, 1]``
-        (reference: openvoice/api.py:114-139)."""
+        (reference: openvoice/api.py:114-139, which runs one spectrogram + one ``ref_enc`` call per file).  Here the
+        files of equal length -- the ~10 s pieces ``se_extractor.get_se`` cuts a recording into -- are stacked into ONE
+        ``[N, samples]`` spectrogram launch pair and ONE ``ref_enc`` launch sequence (the kernels take N); files of
+        other lengths keep the per-file path.  The mean runs over files in the caller's order either way."""
         if isinstance(ref_wav_list, str):
             ref_wav_list = [ref_wav_list]
-        gs = []
-        for fname in ref_wav_list:
-            audio_ref, _ = audio_io.load(fname, sr=self.hps.data.sampling_rate)
-            y = torch.from_numpy(np.ascontiguousarray(audio_ref, dtype=np.float32)).to(self.device).unsqueeze(0)
-            spec = self._spec(y)
-            with torch.no_grad():
-                g = self.model.ref_enc(spec.transpose(1, 2)).unsqueeze(-1)
-            gs.append(g.detach())
-        gs = torch.stack(gs).mean(0)
+        audios = [np.ascontiguousarray(audio_io.load(f, sr=self.hps.data.sampling_rate)[0], dtype=np.float32)
+                  for f in ref_wav_list]
+        gs = self.extract_se_from_audio(audios)
         if se_save_path is not None:
             os.makedirs(os.path.dirname(se_save_path), exist_ok=True)
             torch.save(gs.cpu(), se_save_path)
         return gs
+
+    @torch.no_grad()
+    def extract_se_from_audio(self, audios):
+        """``extract_se`` on decoded float32 waveforms (list of 1-D arrays / tensors at the model's sampling rate)."""
+        groups = {}
+        for i, a in enumerate(audios):
+            groups.setdefault(len(a), []).append(i)
+        embs = [None] * len(audios)
+        self.last_extract_se_batches = []          # (files in the ref_enc call) per call, for tests / logs
+        for length, idx in groups.items():
+            y = torch.stack([torch.as_tensor(audios[i], dtype=torch.float32) for i in idx]).to(self.device)
+            spec = self._spec(y)                                             # [n, 513, T], one launch pair
+            g = self.model.ref_enc(spec.transpose(1, 2))                     # [n, gin], one launch sequence
+            self.last_extract_se_batches.append(len(idx))
+            for row, i in enumerate(idx):
+                embs[i] = g[row]
+        return torch.stack(embs).mean(0).reshape(1, -1, 1).detach()
 
     @torch.no_grad()
     def convert_batch(self, waveforms, src_se, tgt_se, tau=0.3, noise=None):
@@ -252,6 +266,27 @@ class ToneColorConverter(OpenVoiceBaseClass):
             o_hat = self.model.voice_conversion(spec, spec_lengths, sid_src=src_se, sid_tgt=tgt_se, tau=tau,
                                                 noise=noise)[0]
         return o_hat, spec_lengths * hop
+
+    @torch.no_grad()
+    def convert_batch_sharded(self, waveforms, src_se, tgt_se, tau=0.3, noise=None, gather=True):
+        """``convert_batch`` across the GPUs of one node: call it from every rank of an
+        initialised ``torch.distributed`` process group (backend "nccl" = RCCL; one process per GPU, this converter on
+        the rank's own device) with the same ``waveforms`` ([N, samples], equal lengths).  Rank 0's speaker embeddings
+        are broadcast (2 KiB, the only collective on the path; other ranks may pass None), rank r converts utterances
+        ``parallel.shard_range(N, r, world)``, and with ``gather`` every rank receives the whole ``[N, 1, hop*T]``
+        batch (one all-gather), else ``(local_o_hat, (start, end))``.  ``noise`` [N, 192, T] is per utterance, so the
+        result does not depend on the number of ranks.  Without a process group this is ``convert_batch``."""
+        from . import parallel
+        gin = self.model.model_cfg["gin_channels"]
+
+        def convert(shard, s, t, nz):
+            if len(shard) == 0:         # more ranks than utterances: an empty shard of the right width
+                hop, d = self.hps.data.hop_length, self.hps.data
+                frames = (waveforms.shape[1] + (d.filter_length - hop) // 2 * 2 - d.filter_length) // hop + 1
+                return torch.zeros(0, 1, frames * hop, dtype=torch.float32, device=self.device)
+            return self.convert_batch(shard, s, t, tau=tau, noise=nz)[0]
+        waveforms = torch.as_tensor(waveforms, dtype=torch.float32)
+        return parallel.convert_sharded(convert, waveforms, src_se, tgt_se, gin, self.device, noise=noise, gather=gather)
 
     def convert(self, audio_src_path, src_se, tgt_se, output_path=None, tau=0.3, message="default"):
         """reference: openvoice/api.py:141-160."""

@@ -12,16 +12,14 @@ class PackedConvBf16:
     """One conv layer in bf16 kernel-ready form: B-fragment-ordered bf16 weights + fp32 bias."""
 
     def __init__(self, w_dense, bias, device, dil=1):
-        lib = _lib.load()
         w = w_dense.detach().to(torch.float32).cpu().contiguous()
         self.cout, self.cin, self.K = w.shape
         self.dil = dil
-        n = lib.ov_conv1d_bf16_pack_size(self.cout, self.cin, self.K)
+        n = _lib.call("ov_conv1d_bf16_pack_size", self.cout, self.cin, self.K)
         if n == 0:
             raise _lib.OvError(f"bf16 conv needs Cin % 32 == 0 (got {self.cin})")
         packed = torch.empty(n, dtype=torch.int16)
-        _lib.check(lib.ov_conv1d_bf16_pack(ctypes.c_void_p(w.data_ptr()), self.cout, self.cin, self.K,
-                                           ctypes.c_void_p(packed.data_ptr())), "ov_conv1d_bf16_pack")
+        _lib.call("ov_conv1d_bf16_pack", w, self.cout, self.cin, self.K, packed)
         self.w = packed.to(device)
         self.bias = None if bias is None else bias.detach().float().contiguous().to(device)
 
@@ -33,6 +31,10 @@ def launch_conv_bf16(layer, x, out, in_slope=1.0, scale=1.0, res=None, add=None,
     assert cin == layer.cin and out.shape == (B, L, layer.cout)
     for t in (x, out, res, add):
         assert t is None or (t.dtype == torch.bfloat16 and t.is_contiguous())
+    if _lib.use_torch_binding():
+        _lib.torch_op("conv1d_bf16cl", x, layer.w, layer.bias, out, res, add, dbg,
+                      [B, L, cin, layer.cout, layer.K, layer.dil, 0, 0, layout], [in_slope, scale, out_slope])
+        return
     p = ConvBf16Params()
     vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     p.x, p.w, p.bias, p.out, p.res, p.add = vp(x), vp(layer.w), vp(layer.bias), vp(out), vp(res), vp(add)
@@ -51,6 +53,10 @@ def launch_pair_bf16(c1, c2, x, out, add=None, scale=1.0, slope=0.1, nwg=0, dbg=
     assert c1.cin == c1.cout == c2.cin == c2.cout == C and c1.K == c2.K and c2.dil == 1 and out.shape == x.shape
     for t in (x, out, add):
         assert t is None or (t.dtype == torch.bfloat16 and t.is_contiguous())
+    if _lib.use_torch_binding():
+        _lib.torch_op("resblock_pair_bf16cl", x, c1.w, c1.bias, c2.w, c2.bias, out, add, dbg,
+                      [B, L, C, c1.K, c1.dil, nwg], [slope, scale])
+        return
     p = _lib.RespairBf16Params()
     vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     p.x, p.w1, p.b1, p.w2, p.b2, p.out, p.add = vp(x), vp(c1.w), vp(c1.bias), vp(c2.w), vp(c2.bias), vp(out), vp(add)
@@ -61,16 +67,27 @@ def launch_pair_bf16(c1, c2, x, out, add=None, scale=1.0, slope=0.1, nwg=0, dbg=
     _lib.check(_lib.load().ov_resblock_pair_bf16cl(ctypes.byref(p), stream), "ov_resblock_pair_bf16cl")
 
 
+_pair_supported = {}
+
+
 def pair_bf16_supported(C, K, dil):
-    return bool(_lib.load().ov_resblock_pair_bf16_supported(C, K, dil))
+    key = (C, K, dil)
+    if key not in _pair_supported:
+        _pair_supported[key] = bool(_lib.call("ov_resblock_pair_bf16_supported", C, K, dil))
+    return _pair_supported[key]
 
 
 def _launch(layer, x, out, L, in_slope=1.0, scale=1.0, res=None, add=None, phase_s=0, bias=None, bias_bstride=0,
             out_slope=1.0):
     B = x.shape[0]
+    bias = layer.bias if bias is None else bias
+    if _lib.use_torch_binding():
+        _lib.torch_op("conv1d_bf16cl", x, layer.w, bias, out, res, add, None,
+                      [B, L, layer.cin, layer.cout, layer.K, layer.dil, phase_s, bias_bstride, 0],
+                      [in_slope, scale, out_slope])
+        return
     p = ConvBf16Params()
     vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-    bias = layer.bias if bias is None else bias
     p.x, p.w, p.bias, p.out, p.res, p.add = vp(x), vp(layer.w), vp(bias), vp(out), vp(res), vp(add)
     p.B, p.L, p.Cin, p.Cout, p.K, p.dil = B, L, layer.cin, layer.cout, layer.K, layer.dil
     p.phase_s, p.bias_bstride, p.in_slope, p.scale, p.out_slope = phase_s, bias_bstride, in_slope, scale, out_slope
@@ -133,8 +150,11 @@ class GeneratorBf16:
         self.final_channels = ch
         self.post_w = sd["dec.conv_post.weight"][0].contiguous().to(dev)              # [C, 7] fp32
         self._ws = {}
-        # ResBlock pairs of the HBM-bound stages as ONE launch each (csrc/conv1d_bf16_pair.hip; bit-identical to the two
-        # launches): C = 32 every kernel size, C = 64 K = 3 -- 1.7-2.0x faster than the two launches on MI355X
+        # ResBlock pairs of the HBM-bound stages as ONE launch each (csrc/conv1d_bf16_pair.hip): C = 32 every kernel
+        # size, C = 64 K = 3 -- 1.7-2.0x faster than two launches on MI355X.  The fused kernel is bit-identical to two
+        # PLAIN launches (t = bf16(lrelu(bf16(v)))); the unfused pairs below store t activated (out_slope: one rounding,
+        # t = bf16(lrelu(v))), which can differ from that by one bf16 ulp of t on negative values -- fuse_pairs on / off
+        # therefore agree within bf16 rounding, not bit for bit (tests/test_gpu_bf16_pair.py)
         self.fuse_pairs = True
 
     def _workspace(self, B, T):
@@ -155,12 +175,16 @@ class GeneratorBf16:
         """``z`` [B, inter, T] fp32 (channels-first, as the flow produces it), ``g`` [B or 1, gin, 1] ->
         waveform [B, 1, T * prod(upsample_rates)] fp32."""
         from .engine import FINAL_LRELU_SLOPE, LRELU_SLOPE
-        lib, dev = _lib.load(), self.device
+        dev = self.device
         B, C, T = z.shape
         ws = self._workspace(B, T)
         x = z.to(dev, torch.float32).transpose(1, 2).to(torch.bfloat16).contiguous()        # [B, T, C] bf16
         g2 = g.to(dev, torch.float32).reshape(g.shape[0], -1)
-        cond = torch.addmm(self.cond_b, g2, self.cond_w.t()).expand(B, -1).contiguous()      # [B, 512] fp32, T = 1 GEMV
+        g2 = g2.contiguous()
+        cond = torch.empty(g2.shape[0], self.cond_w.shape[0], dtype=torch.float32, device=dev)
+        _lib.call("ov_linear_f32", g2, self.cond_w, self.cond_b, cond, g2.shape[0], self.cond_w.shape[0],
+                  self.cond_w.shape[1])                                                      # dec.cond, T = 1 GEMV
+        cond = cond.expand(B, -1).contiguous()                                               # [B, 512] fp32
         ch = self.cfg["upsample_initial_channel"]
         pre = ws["pre"][: B * T * ch].view(B, T, ch)
         _launch(self.conv_pre, x, pre, T, bias=cond, bias_bstride=ch)
@@ -195,8 +219,5 @@ class GeneratorBf16:
             free = [buf for buf in ws["dec"] if buf.data_ptr() != acc.data_ptr()]
             cur_x = acc
         o = torch.empty(B, 1, L, dtype=torch.float32, device=dev)
-        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(lib.ov_conv_post_tanh_bf16(ctypes.c_void_p(cur_x.data_ptr()), ctypes.c_void_p(self.post_w.data_ptr()),
-                                              ctypes.c_void_p(o.data_ptr()), B, ch, L, self.post_w.shape[1],
-                                              FINAL_LRELU_SLOPE, st), "ov_conv_post_tanh_bf16")
+        _lib.call("ov_conv_post_tanh_bf16", cur_x, self.post_w, o, B, ch, L, self.post_w.shape[1], FINAL_LRELU_SLOPE)
         return o

@@ -1,14 +1,30 @@
-// Thin torch binding of the C ABI ("thin pybind/TORCH_LIBRARY shim converts at::Tensor"):
-// `torch.ops.openvoice_amd.*` take tensors, check device / dtype / contiguity with TORCH_CHECK, pick up
-// c10::hip::getCurrentHIPStream() and call the extern "C" entry points of libopenvoice_amd.so; a non-zero OV_E_* code
-// becomes a RuntimeError.  The library itself stays free of torch types (include/openvoice_amd.h) -- this file is the
-// only one that sees both sides.  It is an ALTERNATIVE to the ctypes binding (openvoice_amd/_lib.py), selected with
-// OPENVOICE_AMD_BINDING=torch; both launch the same kernels with the same arguments (tests/test_gpu_torch_shim.py).
+// Thin torch binding of the C ABI ("thin pybind/TORCH_LIBRARY shim converts at::Tensor";
+// BASELINE.json north_star: "bound through a thin torch cpp_extension C-ABI").  `torch.ops.openvoice_amd.<name>` exists
+// for EVERY entry point `ov_<name>` of include/openvoice_amd.h -- tests/test_abi_cpu.py checks the two lists against each
+// other -- takes tensors where the C function takes pointers, checks device / dtype with TORCH_CHECK, picks up
+// c10::hip::getCurrentHIPStream() of the tensors' device and calls the extern "C" function; a non-zero OV_E_* code
+// becomes a RuntimeError.  The library itself stays free of torch types -- this file is the only one that sees both
+// sides.
 //
-// Built by `make -C openvoice_amd/csrc torch_shim` (hipcc, in-tree: openvoice_amd/libopenvoice_amd_torch.so).
+// Two kinds of wrapper:
+//  * entry points with a flat argument list are bound by ONE variadic adapter (`Bind<&ov_fn>`) that derives the torch
+//    signature and the schema string from the C prototype itself (pointer -> `Tensor?`, `T*` non-const ->
+//    `Tensor(a!)?`, int / int64_t -> `int`, float -> `float`, trailing ov_stream_t -> the current stream), so the shim
+//    cannot drift from the header: a changed prototype changes the op, a mismatch does not compile;
+//  * the five entry points that take a parameter struct (`ov_conv1d_f32`, `ov_resblock_pair_f32`, `ov_wn_layer_f32`,
+//    `ov_conv1d_bf16cl`, `ov_resblock_pair_bf16cl`) take the struct's pointers as tensors and its integers / floats as
+//    `int[]` / `float[]` in declaration order.
+// Pointer + element offset (a channel or row-block offset into a larger tensor) is expressed by the caller as a view.
+//
+// Built by `make -C openvoice_amd/csrc torch_shim` (hipcc, in-tree: openvoice_amd/libopenvoice_amd_torch.so).  This is
+// the DEFAULT binding of the Python package (openvoice_amd/_lib.py); OPENVOICE_AMD_BINDING=ctypes selects the
+// libtorch-free ctypes binding of the same C ABI.
 #include <ATen/ATen.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
+
+#include <string>
+#include <type_traits>
 
 #include "openvoice_amd.h"
 
@@ -24,39 +40,182 @@ const char* ov_strerror(int rc) {
   }
 }
 
-void check_f32(const at::Tensor& t, const char* name) {
-  TORCH_CHECK(t.is_cuda(), name, ": must be on a ROCm device (there is no CPU path)");
-  TORCH_CHECK(t.scalar_type() == at::kFloat, name, ": must be float32");
+using OptTensor = c10::optional<at::Tensor>;
+
+// Per-call context: the device every tensor argument must live on (first tensor seen decides) and whether the entry
+// point is a host function (no stream parameter: CPU tensors) or a device function.
+struct Ctx {
+  const char* name;
+  bool host;
+  bool have_dev = false;
+  c10::Device dev{c10::kCPU};
+  void see(const at::Tensor& t, int index) {
+    if (host) {
+      TORCH_CHECK(t.device().is_cpu(), name, ": argument ", index, " must be a HOST (CPU) tensor");
+      return;
+    }
+    TORCH_CHECK(t.is_cuda(), name, ": argument ", index, " must be on a ROCm device (there is no CPU path)");
+    if (!have_dev) { dev = t.device(); have_dev = true; }
+    TORCH_CHECK(t.device() == dev, name, ": argument ", index, " is on ", t.device(), ", expected ", dev);
+  }
+  ov_stream_t stream() const {
+    TORCH_CHECK(have_dev, name, ": no device tensor among the arguments");
+    return static_cast<ov_stream_t>(c10::hip::getCurrentHIPStream(dev.index()).stream());
+  }
+};
+
+template <typename E> bool dtype_ok(at::ScalarType s);
+template <> bool dtype_ok<float>(at::ScalarType s) { return s == at::kFloat; }
+template <> bool dtype_ok<int64_t>(at::ScalarType s) { return s == at::kLong; }
+template <> bool dtype_ok<int32_t>(at::ScalarType s) { return s == at::kInt; }
+template <> bool dtype_ok<uint16_t>(at::ScalarType s) { return s == at::kBFloat16 || s == at::kShort || s == at::kUInt16; }
+template <> bool dtype_ok<unsigned long long>(at::ScalarType s) { return s == at::kLong || s == at::kUInt64; }
+template <typename E> const char* dtype_name();
+template <> const char* dtype_name<float>() { return "float32"; }
+template <> const char* dtype_name<int64_t>() { return "int64"; }
+template <> const char* dtype_name<int32_t>() { return "int32"; }
+template <> const char* dtype_name<uint16_t>() { return "bfloat16 (or int16 bit patterns)"; }
+template <> const char* dtype_name<unsigned long long>() { return "int64 (tick counters)"; }
+
+template <typename E> E* tensor_ptr(const OptTensor& t, Ctx& c, int index) {
+  if (!t.has_value() || !t->defined()) return nullptr;        // the C function rejects a required NULL itself
+  c.see(*t, index);
+  TORCH_CHECK(dtype_ok<E>(t->scalar_type()), c.name, ": argument ", index, " must be ", dtype_name<E>(), ", got ",
+              t->scalar_type());
+  return static_cast<E*>(t->data_ptr());
 }
-const float* fptr(const c10::optional<at::Tensor>& t, int64_t off, const char* name) {
-  if (!t.has_value() || !t->defined()) return nullptr;
-  check_f32(*t, name);
-  return t->data_ptr<float>() + off;
+
+// C parameter type -> torch parameter type, schema fragment, conversion
+template <typename C, typename = void> struct Arg;
+template <typename E> struct Arg<const E*> {
+  using torch_t = const OptTensor&;
+  static std::string schema(int i) { return "Tensor? a" + std::to_string(i); }
+  static const E* get(const OptTensor& t, Ctx& c, int i) { return tensor_ptr<E>(t, c, i); }
+};
+template <typename E> struct Arg<E*, std::enable_if_t<!std::is_const<E>::value>> {
+  using torch_t = const OptTensor&;
+  static std::string schema(int i) { return "Tensor(a" + std::to_string(i) + "!)? a" + std::to_string(i); }
+  static E* get(const OptTensor& t, Ctx& c, int i) { return tensor_ptr<E>(t, c, i); }
+};
+template <> struct Arg<int> {
+  using torch_t = int64_t;
+  static std::string schema(int i) { return "int a" + std::to_string(i); }
+  static int get(int64_t v, Ctx& c, int i) {
+    TORCH_CHECK(v >= INT32_MIN && v <= INT32_MAX, c.name, ": argument ", i, " does not fit a 32-bit int");
+    return static_cast<int>(v);
+  }
+};
+template <> struct Arg<int64_t> {
+  using torch_t = int64_t;
+  static std::string schema(int i) { return "int a" + std::to_string(i); }
+  static int64_t get(int64_t v, Ctx&, int) { return v; }
+};
+template <> struct Arg<float> {
+  using torch_t = double;
+  static std::string schema(int i) { return "float a" + std::to_string(i); }
+  static float get(double v, Ctx&, int) { return static_cast<float>(v); }
+};
+
+template <typename... T> struct List {};
+template <typename L, typename... Acc> struct DropLast;
+template <typename T, typename... Acc> struct DropLast<List<T>, Acc...> { using type = List<Acc...>; using last = T; };
+template <typename T, typename U, typename... R, typename... Acc>
+struct DropLast<List<T, U, R...>, Acc...> : DropLast<List<U, R...>, Acc..., T> {};
+
+template <typename... C> std::string schema_of(const char* name, bool returns_int) {
+  std::string s = std::string(name) + "(";
+  int i = 0;
+  bool first = true;
+  ((s += (first ? "" : ", ") + Arg<C>::schema(i++), first = false), ...);
+  return s + (returns_int ? ") -> int" : ") -> ()");
 }
-ov_stream_t current_stream(const at::Tensor& on) {
-  return static_cast<ov_stream_t>(c10::hip::getCurrentHIPStream(on.device().index()).stream());
+
+// kind: 0 = device function returning a status (last C parameter is the stream), 1 = host function returning a
+// status, 2 = host function returning a value (sizes, capability queries, version)
+template <int Kind, typename R, typename L> struct Wrap;
+template <typename R, typename... C> struct Wrap<0, R, List<C...>> {
+  template <R (*Fn)(C..., ov_stream_t)> struct On {
+    static inline const char* name = "";
+    static void call(typename Arg<C>::torch_t... a) {
+      Ctx c{name, false};
+      int i = 0;
+      // braced init list: arguments are converted left to right
+      std::tuple<C...> v{Arg<C>::get(a, c, i++)...};
+      const int rc = std::apply([&](C... x) { return Fn(x..., c.stream()); }, v);
+      TORCH_CHECK(rc == OV_OK, "ov_", name, " failed: ", ov_strerror(rc));
+    }
+    static void def(torch::Library& m, const char* n) { name = n; m.def(schema_of<C...>(n, false).c_str(), &call); }
+  };
+};
+template <typename R, typename... C> struct Wrap<1, R, List<C...>> {
+  template <R (*Fn)(C...)> struct On {
+    static inline const char* name = "";
+    static void call(typename Arg<C>::torch_t... a) {
+      Ctx c{name, true};
+      int i = 0;
+      std::tuple<C...> v{Arg<C>::get(a, c, i++)...};
+      const int rc = std::apply(Fn, v);
+      TORCH_CHECK(rc == OV_OK, "ov_", name, " failed: ", ov_strerror(rc));
+    }
+    static void def(torch::Library& m, const char* n) { name = n; m.def(schema_of<C...>(n, false).c_str(), &call); }
+  };
+};
+template <typename R, typename... C> struct Wrap<2, R, List<C...>> {
+  template <R (*Fn)(C...)> struct On {
+    static inline const char* name = "";
+    static int64_t call(typename Arg<C>::torch_t... a) {
+      Ctx c{name, true};
+      int i = 0;
+      std::tuple<C...> v{Arg<C>::get(a, c, i++)...};
+      return static_cast<int64_t>(std::apply(Fn, v));
+    }
+    static void def(torch::Library& m, const char* n) { name = n; m.def(schema_of<C...>(n, true).c_str(), &call); }
+  };
+};
+
+template <typename F> struct Sig;
+template <typename R, typename... C> struct Sig<R (*)(C...)> { using ret = R; using args = List<C...>; };
+
+template <auto Fn> void bind_device(torch::Library& m, const char* name) {
+  using S = Sig<decltype(Fn)>;
+  using D = DropLast<typename S::args>;
+  static_assert(std::is_same<typename D::last, ov_stream_t>::value, "device entry points end with the stream");
+  Wrap<0, typename S::ret, typename D::type>::template On<Fn>::def(m, name);
 }
+template <auto Fn> void bind_host(torch::Library& m, const char* name) {
+  using S = Sig<decltype(Fn)>;
+  Wrap<1, typename S::ret, typename S::args>::template On<Fn>::def(m, name);
+}
+template <auto Fn> void bind_value(torch::Library& m, const char* name) {
+  using S = Sig<decltype(Fn)>;
+  Wrap<2, typename S::ret, typename S::args>::template On<Fn>::def(m, name);
+}
+
+// ---- the parameter-struct entry points ----------------------------------------------------------------------------
+template <typename E> E* sptr(const OptTensor& t, Ctx& c, int index, int64_t off = 0) {
+  E* p = tensor_ptr<E>(t, c, index);
+  return p ? p + off : nullptr;
+}
+void finish(int rc, const char* what) { TORCH_CHECK(rc == OV_OK, what, " failed: ", ov_strerror(rc)); }
 
 // ip = [B, Cin, L, x_ld, out_ld, M, Cout, K, dil, epi, flags, split, phase_s, tiles_per_wg, tile, loaders, chunk,
 //       x_bstride, out_bstride, res_bstride, add_bstride, out2_bstride, bias_b_bstride, mask_bstride,
 //       x_off, out_off, res_off, bias_b_off]   (strides and offsets in elements);  fp = [in_slope, scale]
-void conv1d(const at::Tensor& x, const at::Tensor& w, const at::Tensor& bias, at::Tensor out,
-            const c10::optional<at::Tensor>& res, const c10::optional<at::Tensor>& add,
-            const c10::optional<at::Tensor>& out2, const c10::optional<at::Tensor>& mask,
-            const c10::optional<at::Tensor>& bias_b, at::IntArrayRef ip, at::ArrayRef<double> fp) {
-  TORCH_CHECK(ip.size() == 28 && fp.size() == 2, "openvoice_amd::conv1d: 28 integer and 2 float parameters");
-  check_f32(x, "x"); check_f32(w, "w"); check_f32(bias, "bias"); check_f32(out, "out");
-  TORCH_CHECK(x.device() == out.device() && x.device() == w.device(), "conv1d: tensors on different devices");
+void conv1d_f32(const OptTensor& x, const OptTensor& w, const OptTensor& bias, const OptTensor& out, const OptTensor& res,
+                const OptTensor& add, const OptTensor& out2, const OptTensor& mask, const OptTensor& bias_b,
+                at::IntArrayRef ip, at::ArrayRef<double> fp) {
+  TORCH_CHECK(ip.size() == 28 && fp.size() == 2, "openvoice_amd::conv1d_f32: 28 integer and 2 float parameters");
+  Ctx c{"conv1d_f32", false};
   ov_conv1d_params p{};
-  p.x = x.data_ptr<float>() + ip[24];
-  p.w = w.data_ptr<float>();
-  p.bias = bias.data_ptr<float>();
-  p.out = out.data_ptr<float>() + ip[25];
-  p.res = fptr(res, ip[26], "res");
-  p.add = fptr(add, 0, "add");
-  p.out2 = const_cast<float*>(fptr(out2, 0, "out2"));
-  p.mask = fptr(mask, 0, "mask");
-  p.bias_b = fptr(bias_b, ip[27], "bias_b");
+  p.x = sptr<float>(x, c, 0, ip[24]);
+  p.w = sptr<float>(w, c, 1);
+  p.bias = sptr<float>(bias, c, 2);
+  p.out = sptr<float>(out, c, 3, ip[25]);
+  p.res = sptr<float>(res, c, 4, ip[26]);
+  p.add = sptr<float>(add, c, 5);
+  p.out2 = sptr<float>(out2, c, 6);
+  p.mask = sptr<float>(mask, c, 7);
+  p.bias_b = sptr<float>(bias_b, c, 8, ip[27]);
   p.B = (int32_t)ip[0]; p.Cin = (int32_t)ip[1]; p.L = (int32_t)ip[2]; p.x_ld = (int32_t)ip[3]; p.out_ld = (int32_t)ip[4];
   p.M = (int32_t)ip[5]; p.Cout = (int32_t)ip[6]; p.K = (int32_t)ip[7]; p.dil = (int32_t)ip[8]; p.epi = (int32_t)ip[9];
   p.flags = (int32_t)ip[10]; p.split = (int32_t)ip[11]; p.phase_s = (int32_t)ip[12]; p.tiles_per_wg = (int32_t)ip[13];
@@ -64,66 +223,121 @@ void conv1d(const at::Tensor& x, const at::Tensor& w, const at::Tensor& bias, at
   p.x_bstride = ip[17]; p.out_bstride = ip[18]; p.res_bstride = ip[19]; p.add_bstride = ip[20];
   p.out2_bstride = ip[21]; p.bias_b_bstride = ip[22]; p.mask_bstride = ip[23];
   p.in_slope = (float)fp[0]; p.scale = (float)fp[1];
-  const int rc = ov_conv1d_f32(&p, current_stream(x));
-  TORCH_CHECK(rc == OV_OK, "ov_conv1d_f32 failed: ", ov_strerror(rc));
+  finish(ov_conv1d_f32(&p, c.stream()), "ov_conv1d_f32");
 }
 
-void resblock_pair(const at::Tensor& x, const at::Tensor& w1, const at::Tensor& b1, const at::Tensor& w2,
-                   const at::Tensor& b2, at::Tensor out, const c10::optional<at::Tensor>& add, int64_t B, int64_t C,
-                   int64_t L, int64_t ld, int64_t K, int64_t dil, int64_t x_bstride, int64_t out_bstride,
-                   int64_t add_bstride, double slope, double scale) {
-  check_f32(x, "x"); check_f32(w1, "w1"); check_f32(b1, "b1"); check_f32(w2, "w2"); check_f32(b2, "b2"); check_f32(out, "out");
+// ip = [B, C, L, ld, K, dil, nwg, x_bstride, out_bstride, add_bstride];  fp = [slope, scale]
+void resblock_pair_f32(const OptTensor& x, const OptTensor& w1, const OptTensor& b1, const OptTensor& w2,
+                       const OptTensor& b2, const OptTensor& out, const OptTensor& add, const OptTensor& dbg,
+                       at::IntArrayRef ip, at::ArrayRef<double> fp) {
+  TORCH_CHECK(ip.size() == 10 && fp.size() == 2, "openvoice_amd::resblock_pair_f32: 10 integer and 2 float parameters");
+  Ctx c{"resblock_pair_f32", false};
   ov_respair_params p{};
-  p.x = x.data_ptr<float>(); p.w1 = w1.data_ptr<float>(); p.b1 = b1.data_ptr<float>();
-  p.w2 = w2.data_ptr<float>(); p.b2 = b2.data_ptr<float>(); p.out = out.data_ptr<float>();
-  p.add = fptr(add, 0, "add");
-  p.x_bstride = x_bstride; p.out_bstride = out_bstride; p.add_bstride = add_bstride;
-  p.B = (int32_t)B; p.C = (int32_t)C; p.L = (int32_t)L; p.ld = (int32_t)ld; p.K = (int32_t)K; p.dil = (int32_t)dil;
-  p.slope = (float)slope; p.scale = (float)scale;
-  const int rc = ov_resblock_pair_f32(&p, current_stream(x));
-  TORCH_CHECK(rc == OV_OK, "ov_resblock_pair_f32 failed: ", ov_strerror(rc));
+  p.x = sptr<float>(x, c, 0); p.w1 = sptr<float>(w1, c, 1); p.b1 = sptr<float>(b1, c, 2);
+  p.w2 = sptr<float>(w2, c, 3); p.b2 = sptr<float>(b2, c, 4); p.out = sptr<float>(out, c, 5);
+  p.add = sptr<float>(add, c, 6);
+  p.dbg = sptr<unsigned long long>(dbg, c, 7);
+  p.B = (int32_t)ip[0]; p.C = (int32_t)ip[1]; p.L = (int32_t)ip[2]; p.ld = (int32_t)ip[3]; p.K = (int32_t)ip[4];
+  p.dil = (int32_t)ip[5]; p.nwg = (int32_t)ip[6];
+  p.x_bstride = ip[7]; p.out_bstride = ip[8]; p.add_bstride = ip[9];
+  p.slope = (float)fp[0]; p.scale = (float)fp[1];
+  finish(ov_resblock_pair_f32(&p, c.stream()), "ov_resblock_pair_f32");
 }
 
-void conv_post_tanh(const at::Tensor& x, const at::Tensor& w, at::Tensor out, int64_t B, int64_t C, int64_t L, int64_t K,
-                    double in_slope) {
-  check_f32(x, "x"); check_f32(w, "w"); check_f32(out, "out");
-  TORCH_CHECK(x.is_contiguous() && out.is_contiguous() && w.is_contiguous(), "conv_post_tanh: contiguous tensors");
-  const int rc = ov_conv_post_tanh_f32(x.data_ptr<float>(), w.data_ptr<float>(), out.data_ptr<float>(), (int)B, (int)C,
-                                       (int)L, (int)K, (float)in_slope, current_stream(x));
-  TORCH_CHECK(rc == OV_OK, "ov_conv_post_tanh_f32 failed: ", ov_strerror(rc));
+// ip = [B, H, T, ld, K, first, last, width, bstride, cond_bstride, mask_bstride, cond_off]
+void wn_layer_f32(const OptTensor& x, const OptTensor& out, const OptTensor& skip, const OptTensor& w_in,
+                  const OptTensor& b_in, const OptTensor& cond, const OptTensor& w_rs, const OptTensor& b_rs,
+                  const OptTensor& mask, const OptTensor& dbg, at::IntArrayRef ip) {
+  TORCH_CHECK(ip.size() == 12, "openvoice_amd::wn_layer_f32: 12 integer parameters");
+  Ctx c{"wn_layer_f32", false};
+  ov_wn_layer_params p{};
+  p.x = sptr<float>(x, c, 0); p.out = sptr<float>(out, c, 1); p.skip = sptr<float>(skip, c, 2);
+  p.w_in = sptr<float>(w_in, c, 3); p.b_in = sptr<float>(b_in, c, 4); p.cond = sptr<float>(cond, c, 5, ip[11]);
+  p.w_rs = sptr<float>(w_rs, c, 6); p.b_rs = sptr<float>(b_rs, c, 7); p.mask = sptr<float>(mask, c, 8);
+  p.dbg = sptr<unsigned long long>(dbg, c, 9);
+  p.B = (int32_t)ip[0]; p.H = (int32_t)ip[1]; p.T = (int32_t)ip[2]; p.ld = (int32_t)ip[3]; p.K = (int32_t)ip[4];
+  p.first = (int32_t)ip[5]; p.last = (int32_t)ip[6]; p.width = (int32_t)ip[7];
+  p.bstride = ip[8]; p.cond_bstride = ip[9]; p.mask_bstride = ip[10];
+  finish(ov_wn_layer_f32(&p, c.stream()), "ov_wn_layer_f32");
 }
 
-at::Tensor linear(const at::Tensor& x, const at::Tensor& w, const at::Tensor& bias) {
-  check_f32(x, "x"); check_f32(w, "w"); check_f32(bias, "bias");
-  TORCH_CHECK(x.dim() == 2 && w.dim() == 2 && x.size(1) == w.size(1) && bias.numel() == w.size(0), "linear: shapes");
-  TORCH_CHECK(x.is_contiguous() && w.is_contiguous() && bias.is_contiguous(), "linear: contiguous tensors");
-  at::Tensor y = at::empty({x.size(0), w.size(0)}, x.options());
-  const int rc = ov_linear_f32(x.data_ptr<float>(), w.data_ptr<float>(), bias.data_ptr<float>(), y.data_ptr<float>(),
-                               (int)x.size(0), (int)w.size(0), (int)x.size(1), current_stream(x));
-  TORCH_CHECK(rc == OV_OK, "ov_linear_f32 failed: ", ov_strerror(rc));
-  return y;
+// ip = [B, L, Cin, Cout, K, dil, phase_s, bias_bstride, layout];  fp = [in_slope, scale, out_slope]
+void conv1d_bf16cl(const OptTensor& x, const OptTensor& w, const OptTensor& bias, const OptTensor& out,
+                   const OptTensor& res, const OptTensor& add, const OptTensor& dbg, at::IntArrayRef ip,
+                   at::ArrayRef<double> fp) {
+  TORCH_CHECK(ip.size() == 9 && fp.size() == 3, "openvoice_amd::conv1d_bf16cl: 9 integer and 3 float parameters");
+  Ctx c{"conv1d_bf16cl", false};
+  ov_conv1d_bf16_params p{};
+  p.x = sptr<uint16_t>(x, c, 0); p.w = sptr<uint16_t>(w, c, 1); p.bias = sptr<float>(bias, c, 2);
+  p.out = sptr<uint16_t>(out, c, 3); p.res = sptr<uint16_t>(res, c, 4); p.add = sptr<uint16_t>(add, c, 5);
+  p.dbg = sptr<unsigned long long>(dbg, c, 6);
+  p.B = (int32_t)ip[0]; p.L = (int32_t)ip[1]; p.Cin = (int32_t)ip[2]; p.Cout = (int32_t)ip[3]; p.K = (int32_t)ip[4];
+  p.dil = (int32_t)ip[5]; p.phase_s = (int32_t)ip[6]; p.bias_bstride = (int32_t)ip[7]; p.layout = (int32_t)ip[8];
+  p.in_slope = (float)fp[0]; p.scale = (float)fp[1]; p.out_slope = (float)fp[2];
+  finish(ov_conv1d_bf16cl(&p, c.stream()), "ov_conv1d_bf16cl");
 }
 
-void sequence_mask(const at::Tensor& lengths, at::Tensor mask, int64_t B, int64_t T, int64_t ld) {
-  TORCH_CHECK(lengths.is_cuda() && lengths.scalar_type() == at::kLong && lengths.is_contiguous(), "lengths: int64 on device");
-  check_f32(mask, "mask");
-  const int rc = ov_sequence_mask_f32(lengths.data_ptr<int64_t>(), mask.data_ptr<float>(), (int)B, (int)T, (int)ld,
-                                      current_stream(mask));
-  TORCH_CHECK(rc == OV_OK, "ov_sequence_mask_f32 failed: ", ov_strerror(rc));
+// ip = [B, L, C, K, dil, nwg];  fp = [slope, scale]
+void resblock_pair_bf16cl(const OptTensor& x, const OptTensor& w1, const OptTensor& b1, const OptTensor& w2,
+                          const OptTensor& b2, const OptTensor& out, const OptTensor& add, const OptTensor& dbg,
+                          at::IntArrayRef ip, at::ArrayRef<double> fp) {
+  TORCH_CHECK(ip.size() == 6 && fp.size() == 2, "openvoice_amd::resblock_pair_bf16cl: 6 integer and 2 float parameters");
+  Ctx c{"resblock_pair_bf16cl", false};
+  ov_respair_bf16_params p{};
+  p.x = sptr<uint16_t>(x, c, 0); p.w1 = sptr<uint16_t>(w1, c, 1); p.b1 = sptr<float>(b1, c, 2);
+  p.w2 = sptr<uint16_t>(w2, c, 3); p.b2 = sptr<float>(b2, c, 4); p.out = sptr<uint16_t>(out, c, 5);
+  p.add = sptr<uint16_t>(add, c, 6);
+  p.dbg = sptr<unsigned long long>(dbg, c, 7);
+  p.B = (int32_t)ip[0]; p.L = (int32_t)ip[1]; p.C = (int32_t)ip[2]; p.K = (int32_t)ip[3]; p.dil = (int32_t)ip[4];
+  p.nwg = (int32_t)ip[5];
+  p.slope = (float)fp[0]; p.scale = (float)fp[1];
+  finish(ov_resblock_pair_bf16cl(&p, c.stream()), "ov_resblock_pair_bf16cl");
 }
-
-int64_t version() { return ov_version(); }
 
 }  // namespace
 
 TORCH_LIBRARY(openvoice_amd, m) {
-  m.def("conv1d(Tensor x, Tensor w, Tensor bias, Tensor(a!) out, Tensor? res, Tensor? add, Tensor(b!)? out2, Tensor? mask, "
-        "Tensor? bias_b, int[] ip, float[] fp) -> ()", &conv1d);
-  m.def("resblock_pair(Tensor x, Tensor w1, Tensor b1, Tensor w2, Tensor b2, Tensor(a!) out, Tensor? add, int B, int C, "
-        "int L, int ld, int K, int dil, int x_bstride, int out_bstride, int add_bstride, float slope, float scale) -> ()",
-        &resblock_pair);
-  m.def("conv_post_tanh(Tensor x, Tensor w, Tensor(a!) out, int B, int C, int L, int K, float in_slope) -> ()", &conv_post_tanh);
-  m.def("linear(Tensor x, Tensor w, Tensor bias) -> Tensor", &linear);
-  m.def("sequence_mask(Tensor lengths, Tensor(a!) mask, int B, int T, int ld) -> ()", &sequence_mask);
-  m.def("version() -> int", &version);
+  // ---- parameter-struct entry points
+  m.def("conv1d_f32(Tensor? x, Tensor? w, Tensor? bias, Tensor(a!)? out, Tensor? res, Tensor? add, Tensor(b!)? out2, "
+        "Tensor? mask, Tensor? bias_b, int[] ip, float[] fp) -> ()", &conv1d_f32);
+  m.def("resblock_pair_f32(Tensor? x, Tensor? w1, Tensor? b1, Tensor? w2, Tensor? b2, Tensor(a!)? out, Tensor? add, "
+        "Tensor(b!)? dbg, int[] ip, float[] fp) -> ()", &resblock_pair_f32);
+  m.def("wn_layer_f32(Tensor? x, Tensor(a!)? out, Tensor(b!)? skip, Tensor? w_in, Tensor? b_in, Tensor? cond, Tensor? w_rs, "
+        "Tensor? b_rs, Tensor? mask, Tensor(c!)? dbg, int[] ip) -> ()", &wn_layer_f32);
+  m.def("conv1d_bf16cl(Tensor? x, Tensor? w, Tensor? bias, Tensor(a!)? out, Tensor? res, Tensor? add, Tensor(b!)? dbg, "
+        "int[] ip, float[] fp) -> ()", &conv1d_bf16cl);
+  m.def("resblock_pair_bf16cl(Tensor? x, Tensor? w1, Tensor? b1, Tensor? w2, Tensor? b2, Tensor(a!)? out, Tensor? add, "
+        "Tensor(b!)? dbg, int[] ip, float[] fp) -> ()", &resblock_pair_bf16cl);
+  // ---- device entry points with flat argument lists (schema derived from the C prototype)
+  bind_device<&ov_frame_hops_f32>(m, "frame_hops_f32");
+  bind_device<&ov_conv_post_tanh_f32>(m, "conv_post_tanh_f32");
+  bind_device<&ov_linear_f32>(m, "linear_f32");
+  bind_device<&ov_sequence_mask_f32>(m, "sequence_mask_f32");
+  bind_device<&ov_layernorm_freq_f32>(m, "layernorm_freq_f32");
+  bind_device<&ov_conv2d_s2_relu_f32>(m, "conv2d_s2_relu_f32");
+  bind_device<&ov_gru_f32>(m, "gru_f32");
+  bind_device<&ov_embed_f32>(m, "embed_f32");
+  bind_device<&ov_layernorm_ch_f32>(m, "layernorm_ch_f32");
+  bind_device<&ov_rel_attention_f32>(m, "rel_attention_f32");
+  bind_device<&ov_dwconv1d_f32>(m, "dwconv1d_f32");
+  bind_device<&ov_expand1_f32>(m, "expand1_f32");
+  bind_device<&ov_add_bias_mask_f32>(m, "add_bias_mask_f32");
+  bind_device<&ov_rq_spline_inverse_f32>(m, "rq_spline_inverse_f32");
+  bind_device<&ov_duration_f32>(m, "duration_f32");
+  bind_device<&ov_expand_prior_f32>(m, "expand_prior_f32");
+  bind_device<&ov_conv_post_tanh_bf16>(m, "conv_post_tanh_bf16");
+  // ---- host helpers: weight packers (CPU tensors), sizes, capability queries
+  bind_host<&ov_conv1d_pack_f32>(m, "conv1d_pack_f32");
+  bind_host<&ov_wn_pack_f32>(m, "wn_pack_f32");
+  bind_host<&ov_conv1d_bf16_pack>(m, "conv1d_bf16_pack");
+  bind_value<&ov_conv1d_pack_size>(m, "conv1d_pack_size");
+  bind_value<&ov_conv1d_pack_rows>(m, "conv1d_pack_rows");
+  bind_value<&ov_wn_pack_size>(m, "wn_pack_size");
+  bind_value<&ov_conv1d_bf16_pack_size>(m, "conv1d_bf16_pack_size");
+  bind_value<&ov_resblock_pair_supported>(m, "resblock_pair_supported");
+  bind_value<&ov_wn_layer_supported>(m, "wn_layer_supported");
+  bind_value<&ov_wn_layer_tile>(m, "wn_layer_tile");
+  bind_value<&ov_resblock_pair_bf16_supported>(m, "resblock_pair_bf16_supported");
+  bind_value<&ov_version>(m, "version");
+  bind_value<&ov_build_experiment>(m, "build_experiment");
 }

@@ -431,8 +431,13 @@ int ov_wn_layer_f32(const ov_wn_layer_params* pin, ov_stream_t stream) {
   if ((q.ld % 4) || (q.bstride % 4) || (q.cond_bstride % 4) || (reinterpret_cast<uintptr_t>(q.x) & 15) ||
       (reinterpret_cast<uintptr_t>(q.w_in) & 15) || (reinterpret_cast<uintptr_t>(q.w_rs) & 15) ||
       (reinterpret_cast<uintptr_t>(q.b_in) & 15) || (reinterpret_cast<uintptr_t>(q.b_rs) & 15) ||
-      (q.cond && (reinterpret_cast<uintptr_t>(q.cond) & 15)))
+      (q.cond && (reinterpret_cast<uintptr_t>(q.cond) & 15)) || (reinterpret_cast<uintptr_t>(q.out) & 15) ||
+      (reinterpret_cast<uintptr_t>(q.skip) & 15))
     return OV_E_ALIGN;
+  // the loaders read the mask as 16-byte vectors of 4 columns starting at multiples of 4: every row must start
+  // 16-byte aligned and own the whole last vector (columns T .. round_up(T, 4) - 1 are read and discarded)
+  if ((reinterpret_cast<uintptr_t>(q.mask) & 15) || (q.mask_bstride % 4)) return OV_E_ALIGN;
+  if (q.mask_bstride < (int64_t)((q.T + 3) / 4) * 4) return OV_E_BADARG;
   const int width = ov_wn_layer_tile(q.B, q.T, q.width);
   if (width == 0) return OV_E_BADARG;
   q.width = width;

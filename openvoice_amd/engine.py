@@ -35,7 +35,7 @@ def on_own_device(method):
     def wrapper(self, *args, **kwargs):
         dev = getattr(self, "device", None)
         if dev is None:      # GraphedConversion: the engine is an attribute, or the first constructor argument
-            dev = (getattr(self, "engine", None) or args[0]).device
+            dev = (getattr(self, "engine", None) or kwargs.get("engine") or args[0]).device
         with torch.cuda.device(dev):
             return method(self, *args, **kwargs)
     return wrapper
@@ -49,18 +49,17 @@ class PackedConv:
     """One conv layer in kernel-ready form: fragment-packed weights + bias in packed row order."""
 
     def __init__(self, w_dense, bias, device, K, dil=1, cout=None):
-        lib = _lib.load()
         w_dense = w_dense.detach().to(torch.float32).cpu().contiguous()
         rows, cin, k = w_dense.shape
         assert k == K
         self.rows = rows                        # meaningful packed rows (M of the launch)
         self.cout = rows if cout is None else cout
         self.cin, self.K, self.dil = cin, K, dil
-        n = lib.ov_conv1d_pack_size(rows, cin, K)
+        n = _lib.call("ov_conv1d_pack_size", rows, cin, K)
         packed = torch.empty(n, dtype=torch.float32)
-        _lib.check(lib.ov_conv1d_pack_f32(_ptr(w_dense), rows, cin, K, _ptr(packed)), "ov_conv1d_pack_f32")
+        _lib.call("ov_conv1d_pack_f32", w_dense, rows, cin, K, packed)
         self.w = packed.to(device)
-        pack_rows = lib.ov_conv1d_pack_rows(rows)
+        pack_rows = _lib.call("ov_conv1d_pack_rows", rows)
         b = torch.zeros(pack_rows, dtype=torch.float32)
         if bias is not None:
             b[:rows] = bias.detach().float().cpu()
@@ -129,6 +128,10 @@ def convt_row_order(cout, stride):
 # measurement knob (A/B runs of the same process image): flag bits OR-ed into every conv launch, e.g.
 # OPENVOICE_AMD_CONV_FLAGS=8 (OV_F_NO_XCD_MAP) restores the round-robin tile order
 _EXTRA_CONV_FLAGS = int(os.environ.get("OPENVOICE_AMD_CONV_FLAGS", "0"))
+if _EXTRA_CONV_FLAGS & ~_lib.F_NO_XCD_MAP:
+    # every other bit (MASK_V, OUT2_INIT, CONVT_GROUPED) changes RESULTS; an environment variable must not do that
+    raise _lib.OvError(f"OPENVOICE_AMD_CONV_FLAGS={_EXTRA_CONV_FLAGS}: only the measurement bit OV_F_NO_XCD_MAP "
+                       f"({_lib.F_NO_XCD_MAP}) may be set from the environment")
 
 
 def launch_conv(layer, x, x_off, x_bs, out, out_off, out_bs, B, L, epi=EPI_LINEAR, flags=0, in_slope=1.0,
@@ -142,7 +145,7 @@ def launch_conv(layer, x, x_off, x_bs, out, out_off, out_bs, B, L, epi=EPI_LINEA
         ip = [B, layer.cin if cin is None else cin, L, x_ld, out_ld, layer.rows if rows is None else rows, layer.cout,
               layer.K, layer.dil, epi, flags, split, phase_s, tiles_per_wg, tile, loaders, chunk,
               x_bs, out_bs, res_bs, add_bs, out2_bs, bias_b_bs, mask_bs, x_off, out_off, res_off, bias_b_off]
-        _lib.torch_ops().conv1d(x, layer.w, layer.bias, out, res, add, out2, mask, bias_b, ip, [in_slope, scale])
+        _lib.torch_op("conv1d_f32", x, layer.w, layer.bias, out, res, add, out2, mask, bias_b, ip, [in_slope, scale])
         return
     p = ConvParams()
     p.x, p.w = _ptr(x, x_off), _ptr(layer.w)
@@ -170,9 +173,9 @@ def launch_pair(c1, c2, x, x_bs, out, out_bs, B, L, add=None, add_bs=0, scale=1.
                 dbg=None):
     """One fused ResBlock1 iteration (``ov_resblock_pair_f32``): out = (c2(lrelu(c1(lrelu(x)))) + x [+ add]) * scale.
     ``c1`` / ``c2`` are the ``PackedConv`` layers of the two convs; ``out`` must not alias ``x``."""
-    if _lib.use_torch_binding() and dbg is None and nwg == 0:
-        _lib.torch_ops().resblock_pair(x, c1.w, c1.bias, c2.w, c2.bias, out, add, B, c1.cin, L, ld, c1.K, c1.dil,
-                                       x_bs, out_bs, add_bs, slope, scale)
+    if _lib.use_torch_binding():
+        _lib.torch_op("resblock_pair_f32", x, c1.w, c1.bias, c2.w, c2.bias, out, add, dbg,
+                      [B, c1.cin, L, ld, c1.K, c1.dil, nwg, x_bs, out_bs, add_bs], [slope, scale])
         return
     p = _lib.RespairParams()
     p.x, p.w1, p.b1, p.w2, p.b2 = _ptr(x), _ptr(c1.w), _ptr(c1.bias), _ptr(c2.w), _ptr(c2.bias)
@@ -186,8 +189,14 @@ def launch_pair(c1, c2, x, x_bs, out, out_bs, B, L, add=None, add_bs=0, scale=1.
     _lib.check(_lib.load().ov_resblock_pair_f32(ctypes.byref(p), stream), "ov_resblock_pair_f32")
 
 
+_pair_supported = {}
+
+
 def pair_supported(C, K, dil):
-    return bool(_lib.load().ov_resblock_pair_supported(C, K, dil))
+    key = (C, K, dil)
+    if key not in _pair_supported:
+        _pair_supported[key] = bool(_lib.call("ov_resblock_pair_supported", C, K, dil))
+    return _pair_supported[key]
 
 
 # Where the fused pair beats its two launches on MI355X (profiles/r02_s5_pair_vs_two_launches.txt, B = 32 x 10 s):
@@ -212,13 +221,12 @@ def wn_fused_row_order(hidden):
 
 def wn_pack(w_dense, device):
     """Dense [rows][cin][K] -> the 16x16x4 fragment order of ``ov_wn_pack_f32`` (device tensor)."""
-    lib = _lib.load()
     w_dense = w_dense.detach().to(torch.float32).cpu().contiguous()
     rows, cin, k = w_dense.shape
-    n = lib.ov_wn_pack_size(rows, cin, k)
+    n = _lib.call("ov_wn_pack_size", rows, cin, k)
     assert n > 0, (rows, cin, k)
     packed = torch.empty(n, dtype=torch.float32)
-    _lib.check(lib.ov_wn_pack_f32(_ptr(w_dense), rows, cin, k, _ptr(packed)), "ov_wn_pack_f32")
+    _lib.call("ov_wn_pack_f32", w_dense, rows, cin, k, packed)
     return packed.to(device)
 
 
@@ -226,6 +234,12 @@ def launch_wn_layer(layer, x, out, skip, mask, B, T, ld, cond=None, cond_off=0, 
                     width=0, mask_bs=0, dbg=None):
     """One fused WaveNet layer (``ov_wn_layer_f32``): out = (x + res) * mask, skip (+)= rs; ``layer`` is a dict of
     the packed tensors built by ``_WaveNet``; x / out / skip are [B][H][ld]."""
+    if _lib.use_torch_binding():
+        H = layer["hidden"]
+        _lib.torch_op("wn_layer_f32", x, out, skip, layer["w_in"], layer["b_in"], cond, layer["w_rs"], layer["b_rs"],
+                      mask, dbg, [B, H, T, ld, layer["K"], int(first), int(last), width, H * ld, cond_bs, mask_bs,
+                                  cond_off])
+        return
     p = _lib.WnLayerParams()
     p.x, p.out, p.skip = _ptr(x), _ptr(out), _ptr(skip)
     p.w_in, p.b_in, p.w_rs, p.b_rs = _ptr(layer["w_in"]), _ptr(layer["b_in"]), _ptr(layer["w_rs"]), _ptr(layer["b_rs"])
@@ -250,7 +264,7 @@ class _WaveNet:
         self.in_layers, self.rs_layers, self.fused_layers = [], [], []
         K = sd[f"{prefix}.in_layers.0.weight_v"].shape[2] if f"{prefix}.in_layers.0.weight_v" in sd else \
             sd[f"{prefix}.in_layers.0.weight"].shape[2]
-        self.fused = bool(_lib.load().ov_wn_layer_supported(hidden, K))
+        self.fused = bool(_lib.call("ov_wn_layer_supported", hidden, K))
         forder = wn_fused_row_order(hidden) if self.fused else None
         for i in range(n_layers):
             w_in = effective_weight(sd, f"{prefix}.in_layers.{i}")
@@ -282,7 +296,6 @@ class ConverterEngine:
     """Kernel-level implementation of the converter model for one device."""
 
     def __init__(self, state_dict, model_cfg, spec_channels, device, zero_g=False):
-        self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.OvError("ConverterEngine needs a ROCm device ('cuda:N'); there is no CPU path")
@@ -404,13 +417,10 @@ class ConverterEngine:
         self.profile.append(("mrf", 2 * 2.0 * c1.rows * c1.cin * c1.K * L * B, e0, e1))
 
     def _linear(self, x2d, w, b):
-        if _lib.use_torch_binding():
-            return _lib.torch_ops().linear(x2d, w, b)
         Bg, Kd = x2d.shape
         M = w.shape[0]
         y = torch.empty(Bg, M, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.ov_linear_f32(_ptr(x2d), _ptr(w), _ptr(b), _ptr(y), Bg, M, Kd, self._stream()),
-                   "ov_linear_f32")
+        _lib.call("ov_linear_f32", x2d, w, b, y, Bg, M, Kd)
         return y
 
     def _wn_cond(self, wn, g):
@@ -517,11 +527,7 @@ class ConverterEngine:
         ws = self._workspace(B, T)
         Tp, mask = ws["Tp"], ws["mask"]
         ws["noise"][:, :, :T].copy_(noise.to(dev, torch.float32))     # into the padded-row layout
-        if _lib.use_torch_binding():
-            _lib.torch_ops().sequence_mask(lengths, mask, B, T, Tp)
-        else:
-            _lib.check(self.lib.ov_sequence_mask_f32(ctypes.c_void_p(lengths.data_ptr()), _ptr(mask), B, T, Tp,
-                                                     self._stream()), "ov_sequence_mask_f32")
+        _lib.call("ov_sequence_mask_f32", lengths, mask, B, T, Tp)
         # conditioning GEMVs (T = 1): modules.py:189-190 for every WN, models.py:275 for the decoder
         g_q = torch.zeros_like(g_src) if self.zero_g else g_src
         g_d = torch.zeros_like(g_tgt) if self.zero_g else g_tgt
@@ -641,13 +647,7 @@ class ConverterEngine:
             free += [u, t1, ra]
             x = acc
         o_hat = torch.empty(B, 1, L, dtype=torch.float32, device=self.device)
-        if _lib.use_torch_binding():
-            _lib.torch_ops().conv_post_tanh(x[: B * ch * L], self.post_w, o_hat, B, ch, L, self.post_w.shape[1],
-                                            FINAL_LRELU_SLOPE)
-        else:
-            _lib.check(self.lib.ov_conv_post_tanh_f32(_ptr(x), _ptr(self.post_w), _ptr(o_hat), B, ch, L,
-                                                      self.post_w.shape[1], FINAL_LRELU_SLOPE, self._stream()),
-                       "ov_conv_post_tanh_f32")
+        _lib.call("ov_conv_post_tanh_f32", x, self.post_w, o_hat, B, ch, L, self.post_w.shape[1], FINAL_LRELU_SLOPE)
         return o_hat
 
     # ---- extract_se path -----------------------------------------------------------------------------
@@ -661,27 +661,25 @@ class ConverterEngine:
         re = self.ref_enc
         if re is None:
             raise _lib.OvError("this checkpoint has no ref_enc.* weights")
-        dev, st, lib = self.device, self._stream(), self.lib
+        dev = self.device
         x = spec_t.to(dev, torch.float32).transpose(1, 2).contiguous()     # [N, F, T]
         N, F, T = x.shape
         assert F == self.spec_channels
         cur = torch.empty_like(x)
-        _lib.check(lib.ov_layernorm_freq_f32(_ptr(x), _ptr(re["ln_w"]), _ptr(re["ln_b"]), _ptr(cur), N, F, T,
-                                             1e-5, st), "ov_layernorm_freq_f32")
+        _lib.call("ov_layernorm_freq_f32", x, re["ln_w"], re["ln_b"], cur, N, F, T, 1e-5)
         cin = 1
         for w, b in re["convs"]:
             cout = w.shape[0]
             Fo, To = (F - 1) // 2 + 1, (T - 1) // 2 + 1
             nxt = torch.empty(N, cout, Fo, To, dtype=torch.float32, device=dev)
-            _lib.check(lib.ov_conv2d_s2_relu_f32(_ptr(cur), _ptr(w), _ptr(b), _ptr(nxt), N, cin, cout, F, T, st),
-                       "ov_conv2d_s2_relu_f32")
+            _lib.call("ov_conv2d_s2_relu_f32", cur, w, b, nxt, N, cin, cout, F, T)
             cur, cin, F, T = nxt, cout, Fo, To
         feat = cin * F                                                        # 128 * 9 = 1152
         H = REF_ENC_GRU
         gi = torch.empty(N, 3 * H, T, dtype=torch.float32, device=dev)
         self._conv(re["gru_in"], cur, 0, feat * T, gi, 0, 3 * H * T, N, T, tag="gru_in")
         h = torch.empty(N, H, dtype=torch.float32, device=dev)
-        _lib.check(lib.ov_gru_f32(_ptr(gi), _ptr(re["whh_t"]), _ptr(re["bhh"]), _ptr(h), N, H, T, st), "ov_gru_f32")
+        _lib.call("ov_gru_f32", gi, re["whh_t"], re["bhh"], h, N, H, T)
         return self._linear(h, re["proj_w"], re["proj_b"])
 
 

@@ -20,7 +20,6 @@ Difference from the reference, on purpose: the reference evaluates ``torch.min(y
 syncs per call (hard part 7).  Here the range check runs only when
 ``OV_CHECK_RANGE=1`` is set.
 """
-import ctypes
 import math
 import os
 
@@ -34,9 +33,7 @@ class _NativeSpectrogram:
     """Packed DFT weights + launch logic for one (device, n_fft, hop)."""
 
     def __init__(self, device, n_fft, hop):
-        from . import _lib
         from .engine import PackedConv
-        self.lib = _lib.load()
         self.device, self.n_fft, self.hop = device, n_fft, hop
         self.bins = n_fft // 2 + 1
         tiles = (self.bins + 31) // 32
@@ -68,9 +65,7 @@ class _NativeSpectrogram:
         U = T + self.n_fft // self.hop - 1
         ldu, lds = padded_frames(U), padded_frames(T)
         hops = torch.empty(B, self.hop, ldu, dtype=torch.float32, device=y.device)
-        st = ctypes.c_void_p(torch.cuda.current_stream(y.device).cuda_stream)
-        _lib.check(self.lib.ov_frame_hops_f32(ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(hops.data_ptr()), B, N,
-                                              self.hop, pad, U, ldu, st), "ov_frame_hops_f32")
+        _lib.call("ov_frame_hops_f32", y, hops, B, N, self.hop, pad, U, ldu)
         spec = torch.zeros(B, self.bins, lds, dtype=torch.float32, device=y.device)
         launch_conv(self.layer, hops, 0, self.hop * ldu, spec, 0, self.bins * lds, B, T, epi=_lib.EPI_MAGNITUDE,
                     scale=1e-6, rows=self.layer.rows, x_ld=ldu, out_ld=lds)

@@ -15,14 +15,13 @@ single-row ``dp.proj`` and the 29-row spline projections are zero-padded to 32 r
 stores whole 32-row fragments); the Flips between the spline flows are not materialised (channel roles
 alternate); of ``sdp.flows.0`` (ElementwiseAffine) only channel 0 is ever read, so it is two scalars.
 """
-import ctypes
 import math
 
 import torch
 
 from . import _lib
 from ._lib import F_MASK_V, LN_POST_GELU, LN_PRE_RELU
-from .engine import ConverterEngine, PackedConv, _ptr, on_own_device, padded_frames
+from .engine import ConverterEngine, PackedConv, on_own_device, padded_frames
 from .params import ATTN_WINDOW, SDP_DDS_LAYERS, SDP_FLOWS, SDP_KERNEL, SDP_NUM_BINS, SDP_TAIL_BOUND
 
 LN_EPS = 1e-5   # modules.LayerNorm / attentions.LayerNorm default
@@ -56,7 +55,6 @@ class TtsEngine:
     """Kernel-level implementation of the V1 TTS model for one device."""
 
     def __init__(self, state_dict, model_cfg, spec_channels, device, n_vocab, n_speakers):
-        self.lib = _lib.load()
         self.device = torch.device(device)
         cfg = dict(model_cfg.items()) if hasattr(model_cfg, "items") else dict(model_cfg)
         self.cfg = cfg
@@ -111,26 +109,18 @@ class TtsEngine:
         self.emb_g = sd["emb_g.weight"].contiguous().to(dev)
 
     # ---- helpers ---------------------------------------------------------------------------------------
-    def _st(self):
-        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-
     def _conv(self, layer, x, xc, out, oc, B, T, ld, **kw):
         """Token-rate conv: x (B, xc, ld) -> out (B, oc, ld)."""
         self.core._conv(layer, x, 0, xc * ld, out, 0, oc * ld, B, T, x_ld=ld, out_ld=ld, tag="tts", **kw)
 
     def _ln(self, x, gamma, beta, out, B, C, T, ld, res=None, res2=None, mask=None, flags=0):
-        _lib.check(self.lib.ov_layernorm_ch_f32(_ptr(x), _ptr(res) if res is not None else None, _ptr(gamma),
-                                                _ptr(beta), _ptr(res2) if res2 is not None else None,
-                                                _ptr(mask) if mask is not None else None, _ptr(out), B, C, T, ld,
-                                                LN_EPS, flags, self._st()), "ov_layernorm_ch_f32")
+        _lib.call("ov_layernorm_ch_f32", x, res, gamma, beta, res2, mask, out, B, C, T, ld, LN_EPS, flags)
 
     def _dds(self, dds, x, tmp1, tmp2, mask, B, C, T, ld):
         """DDSConv in place on ``x`` (modules.py:117-130); ``x`` already holds ``x + g`` when conditioned."""
-        st, lib = self._st(), self.lib
         n = len(dds.layers)
         for i, L in enumerate(dds.layers):
-            _lib.check(lib.ov_dwconv1d_f32(_ptr(x), _ptr(L["w_sep"]), _ptr(L["b_sep"]), _ptr(mask), _ptr(tmp1), B, C,
-                                           T, ld, SDP_KERNEL, L["dil"], st), "ov_dwconv1d_f32")
+            _lib.call("ov_dwconv1d_f32", x, L["w_sep"], L["b_sep"], mask, tmp1, B, C, T, ld, SDP_KERNEL, L["dil"])
             self._ln(tmp1, L["g1"], L["b1"], tmp1, B, C, T, ld, flags=LN_POST_GELU)
             self._conv(L["c1x1"], tmp1, C, tmp2, C, B, T, ld)
             # x = x + gelu(LN(y)); the block's final `x * mask` rides on the last layer
@@ -145,7 +135,7 @@ class TtsEngine:
         """Same contract as the reference (models.py:467-490): returns
         ``(o [B,1,256*Ty'], attn [B,1,Ty,Tx], y_mask [B,1,Ty], (z, z_p, m_p, logs_p) [B,192,Ty])``.
         ``noise_w`` [B,2,Tx] / ``noise_z`` [B,192,>=Ty] replace the reference's two RNG draws when given."""
-        dev, lib, st = self.device, self.lib, self._st()
+        dev = self.device
         tokens = tokens.to(dev, torch.int64).contiguous()
         lengths = lengths.to(dev, torch.int64).contiguous()
         sid = sid.to(dev, torch.int64).reshape(-1)
@@ -157,11 +147,8 @@ class TtsEngine:
         H, C, Lx = self.H, self.inter, padded_frames(Tx)
         f = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
         x, y, mask = f(B, H, Lx), f(B, H, Lx), f(B, Lx)
-        _lib.check(lib.ov_sequence_mask_f32(ctypes.c_void_p(lengths.data_ptr()), _ptr(mask), B, Tx, Lx, st),
-                   "ov_sequence_mask_f32")
-        _lib.check(lib.ov_embed_f32(ctypes.c_void_p(tokens.data_ptr()), _ptr(self.emb),
-                                    ctypes.c_void_p(lengths.data_ptr()), _ptr(x), B, Tx, H, self.n_vocab, Lx,
-                                    math.sqrt(H), st), "ov_embed_f32")
+        _lib.call("ov_sequence_mask_f32", lengths, mask, B, Tx, Lx)
+        _lib.call("ov_embed_f32", tokens, self.emb, lengths, x, B, Tx, H, self.n_vocab, Lx, math.sqrt(H))
         # ---- text encoder (attentions.py:104-121) ---------------------------------------------------------
         qkv, att = f(B, 3 * H, Lx), f(B, H, Lx)
         filt = self.layers[0]["ffn1"].rows
@@ -169,9 +156,8 @@ class TtsEngine:
         dk = H // self.n_heads
         for L in self.layers:
             self._conv(L["qkv"], x, H, qkv, 3 * H, B, Tx, Lx)
-            _lib.check(lib.ov_rel_attention_f32(_ptr(qkv), _ptr(qkv, H * Lx), _ptr(qkv, 2 * H * Lx), _ptr(L["emb_k"]),
-                                                _ptr(L["emb_v"]), _ptr(mask), _ptr(att), 3 * H * Lx, H * Lx, B,
-                                                self.n_heads, dk, Tx, Lx, ATTN_WINDOW, st), "ov_rel_attention_f32")
+            _lib.call("ov_rel_attention_f32", qkv, (qkv, H * Lx), (qkv, 2 * H * Lx), L["emb_k"], L["emb_v"], mask, att,
+                      3 * H * Lx, H * Lx, B, self.n_heads, dk, Tx, Lx, ATTN_WINDOW)
             self._conv(L["o"], att, H, y, H, B, Tx, Lx)
             self._ln(x, L["g1"], L["b1"], x, B, H, Tx, Lx, res=y, mask=mask)
             self._conv(L["ffn1"], x, H, hid, filt, B, Tx, Lx, flags=F_MASK_V, mask=mask, mask_bs=Lx)
@@ -184,8 +170,7 @@ class TtsEngine:
         Fd = self.dp_filter
         xd, d1, d2, dp_out = f(B, H, Lx), f(B, Fd, Lx), f(B, Fd, Lx), f(B, 32, Lx)
         cg = self.core._linear(g, self.dp_cond_w, self.dp_cond_b)
-        _lib.check(lib.ov_add_bias_mask_f32(_ptr(x), _ptr(cg), _ptr(mask), _ptr(xd), B, H, Tx, Lx, st),
-                   "ov_add_bias_mask_f32")
+        _lib.call("ov_add_bias_mask_f32", x, cg, mask, xd, B, H, Tx, Lx)
         self._conv(self.dp_c1, xd, H, d1, Fd, B, Tx, Lx)
         self._ln(d1, *self.dp_n[0], d1, B, Fd, Tx, Lx, mask=mask, flags=LN_PRE_RELU)
         self._conv(self.dp_c2, d1, Fd, d2, Fd, B, Tx, Lx)
@@ -205,38 +190,32 @@ class TtsEngine:
         zw[:, :, :Tx].copy_(noise_w.to(dev, torch.float32) * float(noise_scale_w))
         c0, c1 = 1, 0                                                           # a Flip precedes every ConvFlow
         for fl in self.sdp_flows:
-            _lib.check(lib.ov_expand1_f32(_ptr(zw, c0 * Lx), 2 * Lx, _ptr(fl["pre_w"]), _ptr(fl["pre_b"]), _ptr(xs),
-                                          _ptr(hflow), B, Fs, Tx, Lx, st), "ov_expand1_f32")
+            _lib.call("ov_expand1_f32", (zw, c0 * Lx), 2 * Lx, fl["pre_w"], fl["pre_b"], xs, hflow, B, Fs, Tx, Lx)
             self._dds(fl["dds"], hflow, t1, t2, mask, B, Fs, Tx, Lx)
             self._conv(fl["proj"], hflow, Fs, hp, 32, B, Tx, Lx, flags=F_MASK_V, mask=mask, mask_bs=Lx)
-            _lib.check(lib.ov_rq_spline_inverse_f32(_ptr(zw), 2 * Lx, c0, c1, _ptr(hp), 32 * Lx, _ptr(mask), B, Tx, Lx,
-                                                    SDP_NUM_BINS, Fs, SDP_TAIL_BOUND, st), "ov_rq_spline_inverse_f32")
+            _lib.call("ov_rq_spline_inverse_f32", zw, 2 * Lx, c0, c1, hp, 32 * Lx, mask, B, Tx, Lx, SDP_NUM_BINS, Fs,
+                      SDP_TAIL_BOUND)
             c0, c1 = c1, c0
         # after the last Flip logical channel 0 is physical channel 0: logw_sdp = EA^-1(z)[0]
         logw = f(B, Lx)
         cum = torch.zeros(B, Lx, dtype=torch.int32, device=dev)
         y_len = torch.zeros(B, dtype=torch.int64, device=dev)
-        _lib.check(lib.ov_duration_f32(_ptr(zw), 2 * Lx, self.ea_m, self.ea_logs, _ptr(dp_out), 32 * Lx, _ptr(mask),
-                                       _ptr(logw), ctypes.c_void_p(cum.data_ptr()), ctypes.c_void_p(y_len.data_ptr()),
-                                       B, Tx, Lx, float(sdp_ratio), float(length_scale), st), "ov_duration_f32")
+        _lib.call("ov_duration_f32", zw, 2 * Lx, self.ea_m, self.ea_logs, dp_out, 32 * Lx, mask, logw, cum, y_len,
+                  B, Tx, Lx, float(sdp_ratio), float(length_scale))
         Ty = int(y_len.max())                                                   # host sync, as in the reference
         # ---- expansion + prior sample + flow (reverse) + generator ---------------------------------------
         core = self.core
         ws = core._workspace(B, Ty)
         Ly, mask_y = ws["Tp"], ws["mask"]
-        _lib.check(lib.ov_sequence_mask_f32(ctypes.c_void_p(y_len.data_ptr()), _ptr(mask_y), B, Ty, Ly, st),
-                   "ov_sequence_mask_f32")
+        _lib.call("ov_sequence_mask_f32", y_len, mask_y, B, Ty, Ly)
         if noise_z is None:
             noise_z = torch.randn(B, C, Ty, dtype=torch.float32, device=dev)
         ws["noise"][:, :, :Ty].copy_(noise_z[:, :, :Ty].to(dev, torch.float32))
         m_p, logs_p = f(B, C, Ly), f(B, C, Ly)
         attn = f(B, Ty, Tx) if return_attn else None
         z_p, z = ws["z_p"], ws["z_hat"]
-        _lib.check(lib.ov_expand_prior_f32(_ptr(stats), _ptr(stats, C * Lx), 2 * C * Lx, Lx,
-                                           ctypes.c_void_p(cum.data_ptr()), ctypes.c_void_p(lengths.data_ptr()),
-                                           ctypes.c_void_p(y_len.data_ptr()), _ptr(ws["noise"]), C * Ly, Ly, _ptr(z_p),
-                                           _ptr(m_p), _ptr(logs_p), _ptr(attn) if attn is not None else None, B, C, Tx,
-                                           Ty, Ly, float(noise_scale), st), "ov_expand_prior_f32")
+        _lib.call("ov_expand_prior_f32", stats, (stats, C * Lx), 2 * C * Lx, Lx, cum, lengths, y_len, ws["noise"],
+                  C * Ly, Ly, z_p, m_p, logs_p, attn, B, C, Tx, Ty, Ly, float(noise_scale))
         cond_flow = [core._wn_cond(cp["wn"], g) for cp in core.couplings]
         core._flow(z_p, z, ws, B, Ty, cond_flow, mask_y, reverse=True)      # z_p -> z, no copy
         cond_d = core._linear(g, core.dec_cond_w, core.dec_cond_b)

@@ -189,6 +189,45 @@ def test_torch_binding_loads_without_a_gpu_and_rejects_cpu_tensors():
     ops = _lib.torch_ops()
     assert ops.version() == _lib.load().ov_version()
     with pytest.raises(RuntimeError, match="ROCm device"):
-        ops.linear(torch.zeros(2, 4), torch.zeros(3, 4), torch.zeros(3))
-    with pytest.raises(RuntimeError, match="on device"):
-        ops.sequence_mask(torch.zeros(2, dtype=torch.long), torch.zeros(2, 8), 2, 8, 8)
+        ops.linear_f32(torch.zeros(2, 4), torch.zeros(3, 4), torch.zeros(3), torch.zeros(2, 3), 2, 3, 4)
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        ops.sequence_mask_f32(torch.zeros(2, dtype=torch.long), torch.zeros(2, 8), 2, 8, 8)
+
+
+def test_torch_binding_has_one_op_per_header_function():
+    """`torch.ops.openvoice_amd.<name>` exists for every `ov_<name>` of include/openvoice_amd.h (the shim derives the
+    flat-argument ops from the C prototypes, so the argument lists cannot drift), and the schema of a derived op maps
+    pointers to optional tensors -- mutable ones annotated -- and scalars to int / float."""
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(REPO, "include", "openvoice_amd.h")).read(), flags=re.S)
+    declared = set(re.findall(r"^(?:int|size_t)\s+(ov_\w+)\s*\(", header, flags=re.M))
+    ops = _lib.torch_ops()
+    for name in declared:
+        assert hasattr(ops, name[3:]), f"torch.ops.openvoice_amd.{name[3:]} missing"
+    schema = str(ops.gru_f32.default._schema)
+    assert schema == ("openvoice_amd::gru_f32(Tensor? a0, Tensor? a1, Tensor? a2, Tensor(a3!)? a3, int a4, int a5, "
+                      "int a6) -> ()"), schema
+    assert str(ops.wn_layer_tile.default._schema).endswith("-> int")
+
+
+def test_host_functions_agree_between_the_two_bindings(monkeypatch):
+    """Weight packers and capability queries through `_lib.call` under both bindings (host functions: no GPU needed)."""
+    import torch
+    w = torch.randn(64, 32, 3, generator=torch.Generator().manual_seed(0))
+    got = {}
+    for binding in ("ctypes", "torch"):
+        monkeypatch.setenv("OPENVOICE_AMD_BINDING", binding)
+        n = _lib.call("ov_conv1d_pack_size", 64, 32, 3)
+        dst = torch.zeros(n)
+        _lib.call("ov_conv1d_pack_f32", w, 64, 32, 3, dst)
+        nb = _lib.call("ov_conv1d_bf16_pack_size", 64, 32, 3)
+        dstb = torch.zeros(nb, dtype=torch.int16)
+        _lib.call("ov_conv1d_bf16_pack", w, 64, 32, 3, dstb)
+        got[binding] = (n, dst, nb, dstb, _lib.call("ov_resblock_pair_supported", 32, 3, 1),
+                        _lib.call("ov_wn_layer_supported", 192, 5), _lib.call("ov_conv1d_pack_rows", 64))
+        with pytest.raises(_lib.OvError):
+            _lib.call("ov_conv1d_pack_f32", None, 64, 32, 3, dst)
+    a, b = got["ctypes"], got["torch"]
+    assert a[0] == b[0] and torch.equal(a[1], b[1]) and a[2] == b[2] and torch.equal(a[3], b[3]) and a[4:] == b[4:]
+    monkeypatch.setenv("OPENVOICE_AMD_BINDING", "pybind")
+    with pytest.raises(_lib.OvError, match="expected 'torch' or 'ctypes'"):
+        _lib.binding()

@@ -40,6 +40,8 @@ def test_bench_multi_rank_control_flow_on_gloo(n):
     assert rec["broadcast_consistent"] is True
     assert rec["config"]["global_batch"] == 32 * n and rec["scaling"] == "weak"
     assert rec["ms_per_step"] >= 0
+    pr = rec["per_rank_ms_per_step"]         # every rank's own time: a straggler shows up as max >> min
+    assert len(pr["ranks"]) == n and pr["min"] <= pr["max"] <= rec["ms_per_step"] + 1e-3
 
 
 def test_bench_single_rank_dry_run_needs_no_process_group():
@@ -48,6 +50,23 @@ def test_bench_single_rank_dry_run_needs_no_process_group():
     assert res.returncode == 0, res.stderr[-2000:]
     (rec,) = _lines(res.stdout)
     assert rec["n_gpus"] == 1 and rec["dry_run"] is True
+
+
+def test_force_dist_runs_the_collectives_at_one_rank():
+    """--force-dist: process group, broadcast, barriers and the timing all-gather at world size 1, without
+    torch.distributed.run (the bench makes its own 1-rank rendezvous); on the GPU box the same flag runs RCCL
+    (tests/test_gpu_dist.py)."""
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--dry-run", "--force-dist", "--gpus", "1",
+                          "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=120, cwd=REPO)
+    assert res.returncode == 0, res.stderr[-2000:]
+    (rec,) = _lines(res.stdout)
+    assert rec["n_gpus"] == 1 and rec["broadcast_consistent"] is True and len(rec["per_rank_ms_per_step"]["ranks"]) == 1
+
+
+def test_zero_steps_is_refused():
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--dry-run", "--steps", "0"],
+                         capture_output=True, text=True, timeout=120, cwd=REPO)
+    assert res.returncode != 0 and "--steps" in res.stderr
 
 
 def test_world_size_mismatch_is_refused():

@@ -111,3 +111,28 @@ def test_pair_bf16_refuses_what_it_cannot_do():
     with pytest.raises(_lib.OvError):
         launch_pair_bf16(c1, c2, x, x)
     assert not pair_bf16_supported(128, 3, 1)
+
+
+@pytest.mark.parametrize("c,k,d", [(32, 3, 1), (32, 11, 5), (64, 3, 3)])
+def test_activated_store_two_launch_path_agrees_with_the_fused_pair_within_bf16_rounding(c, k, d):
+    """``GeneratorBf16`` runs the pairs WITHOUT a fused instance as two launches that store the intermediate ACTIVATED
+    (``out_slope``: t = bf16(lrelu(v)), one rounding) while the fused kernel -- and the plain two-launch sequence above it
+    is bit-identical to -- rounds, activates in fp32 and rounds again (t = bf16(lrelu(bf16(v)))).  The two forms are
+    NOT bit-identical (negative values can differ by one bf16 ulp of t); both are within the bf16 bound of the fp32
+    reference.  The fused form is canonical for the stages it covers; stages are never mixed within one pair."""
+    B, L = 2, 2000
+    (w1, b1, w2, b2), c1, c2 = _layers(c, k, d, seed=5)
+    x = _r(_rand(B, L, c, seed=6))
+    xd = x.to(DEV, torch.bfloat16)
+    fused = torch.full_like(xd, float("nan"))
+    launch_pair_bf16(c1, c2, xd, fused)
+    t = torch.empty_like(xd)
+    two = torch.full_like(xd, float("nan"))
+    launch_conv_bf16(c1, xd, t, in_slope=0.1, out_slope=0.1)          # the engine's sequence (bf16.py decode)
+    launch_conv_bf16(c2, t, two, in_slope=1.0, res=xd)
+    ref = _reference(x, w1, b1, w2, b2, k, d)
+    _check(two, ref)
+    _check(fused, ref)
+    scale = max(1.0, ref.abs().max().item())
+    diff = (two.float() - fused.float()).abs().max().item()
+    assert diff <= 2 ** -6 * scale, diff          # two bf16 ulps of the output scale

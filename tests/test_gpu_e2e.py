@@ -174,6 +174,7 @@ def test_tone_color_converter_api_end_to_end_from_files(tmp_path, synth_sd):
                                            src_se.cpu(), tgt_se.cpu(), 0.0, torch.zeros(1, 192, spec.shape[2]),
                                            zero_g=True)[0]
     assert len(segs) == 2 and (tgt_se.cpu() - se_ref).abs().max().item() <= 1e-4
+    assert tcc.last_extract_se_batches == [1]       # (the src.wav call above; get_se ran the two pieces as one batch)
     audio = tcc.convert(str(tmp_path / "src.wav"), src_se, tgt_se, output_path=None, tau=0.0)
     assert audio.dtype == np.float32 and audio.shape == (spec.shape[2] * 256,)
     err = np.abs(audio - o_ref[0, 0].numpy()).max()
@@ -186,6 +187,44 @@ def test_tone_color_converter_api_end_to_end_from_files(tmp_path, synth_sd):
     o_b, n_b = tcc.convert_batch([src, src[: sr]], src_se, tgt_se, tau=0.0)
     assert n_b.tolist() == [spec.shape[2] * 256, ((sr - 256) // 256 + 1) * 256]
     assert np.abs(o_b[0, 0].cpu().numpy()[: len(audio)] - audio).max() <= 1e-3
+
+
+def test_extract_se_batches_equal_length_pieces(tmp_path, synth_sd):
+    """SURVEY.md section 8f item 2, second half: ``get_se`` on a 60 s recording cuts six equal pieces and
+    ``extract_se`` runs them as ONE [6, samples] spectrogram + ONE ``ref_enc`` launch sequence (the reference loops
+    over the files, openvoice/api.py:121-133); the mean equals the per-file mean within 1e-5.  Files of other lengths
+    keep their own call, and the result is the mean over files in the caller's order."""
+    import json
+    import numpy as np
+    from openvoice_amd import api, audio_io, se_extractor
+    from openvoice_amd.utils import default_converter_hparams
+    hps = default_converter_hparams("v2")
+    cfg = {"_version_": "v2", "data": dict(hps.data.items()), "model": dict(hps.model.items())}
+    (tmp_path / "config.json").write_text(json.dumps(cfg))
+    torch.save({"model": synth_sd}, tmp_path / "checkpoint.pth")
+    sr = 22050
+    n = np.arange(60 * sr)
+    rng = np.random.default_rng(3)
+    ref = (0.4 * np.sin(2 * np.pi * (200 + 30 * np.sin(2 * np.pi * n / (7.3 * sr))) * n / sr)
+           + 0.05 * rng.standard_normal(len(n))).astype(np.float32)
+    audio_io.write(str(tmp_path / "ref60.wav"), ref, sr)
+    tcc = api.ToneColorConverter(str(tmp_path / "config.json"), device=DEV, enable_watermark=False)
+    tcc.load_ckpt(str(tmp_path / "checkpoint.pth"))
+    se, name = se_extractor.get_se(str(tmp_path / "ref60.wav"), tcc, target_dir=str(tmp_path / "processed"))
+    assert tcc.last_extract_se_batches == [6], tcc.last_extract_se_batches
+    segs = sorted(str(p) for p in (tmp_path / "processed" / name / "wavs").glob("*.wav"))
+    per_file = torch.stack([tcc.extract_se(s) for s in segs]).mean(0)
+    assert tcc.last_extract_se_batches == [1]
+    err = (se - per_file).abs().max().item()
+    print("batched extract_se vs per-file mean:", err)
+    assert se.shape == (1, 256, 1) and err <= 1e-5
+    # mixed lengths: two equal files + one shorter -> two ref_enc calls, mean over the three files
+    audio_io.write(str(tmp_path / "short.wav"), ref[: 4 * sr], sr)
+    mixed = [segs[0], str(tmp_path / "short.wav"), segs[1]]
+    se_mixed = tcc.extract_se(mixed)
+    assert sorted(tcc.last_extract_se_batches) == [1, 2]
+    want = torch.stack([tcc.extract_se(f) for f in mixed]).mean(0)
+    assert (se_mixed - want).abs().max().item() <= 1e-5
 
 
 def test_voice_conversion_matches_reference_at_benchmark_length(golden_dir, synth_sd):

@@ -118,3 +118,23 @@ def test_argument_checks():
     bad = dict(layer, hidden=128)
     with pytest.raises(_lib.OvError):
         launch_wn_layer(bad, x, torch.zeros_like(x), torch.zeros_like(x), mask, B, T, T)
+
+
+def test_mask_rows_must_be_vector_aligned():
+    """The loaders read the mask as 16-byte vectors: a mask whose rows are T (not a multiple of 4) floats apart, or that
+    starts off a 16-byte boundary, is refused (OV_E_ALIGN) instead of being read misaligned / past its last row."""
+    B, T, ld = 2, 18, 20
+    layer = _packed(*_layer(1))
+    x = torch.zeros(B, H, ld, device=DEV)
+    out, skip = torch.zeros_like(x), torch.zeros_like(x)
+    tight = torch.ones(B, T, device=DEV)                      # rows 18 floats apart
+    with pytest.raises(_lib.OvError, match="ALIGN"):
+        launch_wn_layer(layer, x, out, skip, tight, B, T, ld, mask_bs=T)
+    shifted = torch.ones(B * ld + 4, device=DEV)[1:]          # 4-byte aligned only
+    with pytest.raises(_lib.OvError, match="ALIGN"):
+        launch_wn_layer(layer, x, out, skip, shifted, B, T, ld, mask_bs=ld)
+    short = torch.ones(B, 16, device=DEV)                     # aligned rows that do not own the last vector of T = 18
+    with pytest.raises(_lib.OvError, match="BADARG"):
+        launch_wn_layer(layer, x, out, skip, short, B, T, ld, mask_bs=16)
+    launch_wn_layer(layer, x, out, skip, torch.ones(B, ld, device=DEV), B, T, ld, mask_bs=ld)     # the valid form
+    torch.cuda.synchronize()

@@ -9,8 +9,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from openvoice_amd.parallel import (broadcast_speaker_embeddings, gather_waveforms, pack_speaker_embeddings,
-                                    shard_range, unpack_speaker_embeddings)
+from openvoice_amd.parallel import (broadcast_speaker_embeddings, convert_sharded, gather_waveforms,
+                                    pack_speaker_embeddings, shard_range, unpack_speaker_embeddings)
 
 
 def test_shard_range_partitions_exactly():
@@ -69,3 +69,76 @@ def test_broadcast_and_gather_world_size_2(tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     spans = [torch.load(tmp_path / f"rank{r}.pt").tolist() for r in range(world)]
     assert spans == [[0, 3], [3, 6]]
+
+
+# ---- the composition the API uses (ToneColorConverter.convert_batch_sharded), with a REAL conversion ----------------
+N_UTT, SAMPLES = 5, 2560        # 5 utterances of 10 frames: shards of 3 and 2 (unequal: the gather pads and trims)
+
+
+def _oracle_case():
+    from openvoice_amd.params import synthetic_state_dict
+    from openvoice_amd.utils import CONVERTER_MODEL_CONFIG
+    cfg = CONVERTER_MODEL_CONFIG
+    sd = synthetic_state_dict(cfg, 513, seed=1234)
+    gen = torch.Generator().manual_seed(21)
+    waves = 0.3 * torch.randn(N_UTT, SAMPLES, generator=gen)
+    src, tgt = 0.3 * torch.randn(1, 256, 1, generator=gen), 0.3 * torch.randn(1, 256, 1, generator=gen)
+    noise = torch.randn(N_UTT, cfg["inter_channels"], 10, generator=gen)       # per utterance: shard-invariant
+    return sd, cfg, waves, src, tgt, noise
+
+
+def _oracle_convert(sd, cfg):
+    from oracle import vc_oracle
+
+    def convert(waves, src_se, tgt_se, noise):
+        with torch.no_grad():
+            spec = vc_oracle.spectrogram(waves)
+            lengths = torch.full((waves.shape[0],), spec.shape[2], dtype=torch.int64)
+            return vc_oracle.voice_conversion(sd, cfg, spec, lengths, src_se, tgt_se, 0.3, noise, zero_g=True)[0]
+    return convert
+
+
+def _sharded_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sd, cfg, waves, src, tgt, noise = _oracle_case()
+        # rank 0 alone owns the embeddings; every rank gets the whole converted batch back
+        full = convert_sharded(_oracle_convert(sd, cfg), waves, src if rank == 0 else None, tgt if rank == 0 else None,
+                               256, "cpu", noise=noise, gather=True)
+        local, span = convert_sharded(_oracle_convert(sd, cfg), waves, src if rank == 0 else None,
+                                      tgt if rank == 0 else None, 256, "cpu", noise=noise, gather=False)
+        assert torch.equal(local, full[span[0]:span[1]])
+        torch.save(dict(full=full, span=span), os.path.join(out_dir, f"sharded{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_conversion_equals_unsharded_world_size_2(tmp_path):
+    """shard_range -> broadcast of rank 0's embeddings -> oracle conversion of the local shard -> all-gather, against
+    the same conversion of the whole batch in one process: the composition, not a stand-in."""
+    world = 2
+    mp.spawn(_sharded_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sd, cfg, waves, src, tgt, noise = _oracle_case()
+    want = _oracle_convert(sd, cfg)(waves, src, tgt, noise)
+    assert want.shape == (N_UTT, 1, 2560) and float(want.abs().max()) > 1e-3
+    recs = [torch.load(tmp_path / f"sharded{r}.pt") for r in range(world)]
+    assert [tuple(r["span"]) for r in recs] == [(0, 3), (3, 5)]
+    for r in recs:
+        assert r["full"].shape == want.shape
+        assert torch.allclose(r["full"], want, atol=2e-6, rtol=0)     # batch composition changes only the GEMM blocking
+    assert torch.equal(recs[0]["full"], recs[1]["full"])
+
+
+def test_convert_sharded_without_process_group_is_the_plain_call():
+    calls = []
+
+    def convert(w, s, t, n):
+        calls.append((len(w), n))
+        return torch.as_tensor(w).reshape(len(w), 1, -1) * s.sum()
+    waves = torch.arange(12.0).reshape(3, 4)
+    src, tgt = torch.ones(1, 4, 1), torch.zeros(1, 4, 1)
+    out = convert_sharded(convert, waves, src, tgt, 4, "cpu")
+    assert torch.equal(out, waves.reshape(3, 1, 4) * 4) and calls == [(3, None)]

@@ -21,7 +21,7 @@ layer = dict(hidden=H, K=5, w_in=wn_pack((torch.randn(2 * H, H, 5) * (5 * H) ** 
              b_in=torch.zeros(2 * H, device=dev), w_rs=wn_pack(torch.randn(2 * H, H, 1) * H ** -0.5, dev),
              b_rs=torch.zeros(2 * H, device=dev))
 for width in widths:
-    w = _lib.load().ov_wn_layer_tile(B, T, width)
+    w = _lib.call("ov_wn_layer_tile", B, T, width)
     nwg = B * ((T + w - 1) // w)
     for _ in range(300):
         launch_wn_layer(layer, x, out, skip, mask, B, T, ld, cond=cond, cond_bs=2 * H, width=width, mask_bs=ld)
