@@ -274,6 +274,25 @@ def effective_weight(sd, prefix):
     return v * (g / norm)
 
 
+def stress_state_dict(sd, gain=4.0):
+    """High-dynamic-range variant of a synthetic converter state dict (parity stress case):
+    the posterior mean head and every coupling's ``post`` are scaled by ``gain`` -- latents ``z`` / ``z_p`` and the flow
+    shifts grow ``gain``-fold, so the forward/reverse flow cancellation runs at ``gain`` times the magnitude -- and
+    ``dec.conv_pre`` by 1/``gain`` so the generator still sees an O(1) input and the waveform stays unsaturated (an
+    error would otherwise hide behind tanh)."""
+    out = OrderedDict((k, v.clone()) for k, v in sd.items())
+    inter = out["enc_q.proj.weight"].shape[0] // 2
+    out["enc_q.proj.weight"][:inter] *= gain
+    out["enc_q.proj.bias"][:inter] *= gain
+    for k in out:
+        if k.startswith("flow.flows.") and (k.endswith(".post.weight") or k.endswith(".post.bias")):
+            out[k] *= gain
+    for k in ("dec.conv_pre.weight_g", "dec.conv_pre.weight"):
+        if k in out:
+            out[k] = out[k] / gain
+    return out
+
+
 def synthetic_state_dict(hps_model, spec_channels=513, seed=1234, perturb_g=True):
     """Calibrated random converter weights.
 

@@ -23,7 +23,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 REFERENCE = "/root/reference"
 
-from openvoice_amd.params import synthetic_state_dict, synthetic_tts_state_dict  # noqa: E402
+from openvoice_amd.params import stress_state_dict, synthetic_state_dict, synthetic_tts_state_dict  # noqa: E402
 from openvoice_amd.utils import CONVERTER_MODEL_CONFIG  # noqa: E402
 
 GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
@@ -70,6 +70,11 @@ CASES = [
     # test needs (waveform in, o_hat + latent checksums out) to keep the fixture small
     dict(name="vc_b1_t861_benchmark_length", batch=1, frames=861, lengths=None, zero_g=True, per_item_g=False,
          tau=0.3, compact=True),
+    # high dynamic range: params.stress_state_dict(gain 4) -- latents and flow shifts 4x larger,
+    # so the flow's forward / reverse cancellation and every accumulation run at 4x the magnitude; tau = 1 adds the
+    # full posterior noise; ragged so the masks are exercised at that magnitude too
+    dict(name="vc_b2_t64_stress_gain4", batch=2, frames=64, lengths=[64, 41], zero_g=True, per_item_g=True, tau=1.0,
+         stress=4.0),
 ]
 
 
@@ -147,9 +152,12 @@ def main():
     if "--tts-only" in sys.argv:
         return
     for case in CASES:
+        if only and case["name"] not in only:
+            continue
         model = ref_models.SynthesizerTrn(0, 513, n_speakers=0, zero_g=case["zero_g"],
                                           **CONVERTER_MODEL_CONFIG).eval()
-        missing, unexpected = model.load_state_dict(sd, strict=True)
+        sd_case = stress_state_dict(sd, case["stress"]) if case.get("stress") else sd
+        missing, unexpected = model.load_state_dict(sd_case, strict=True)
         b, t = case["batch"], case["frames"]
         seed = 100 + len(case["name"])
         wave = synth_wave(b, 256 * t, seed)

@@ -14,7 +14,7 @@ from openvoice_amd.models import SynthesizerTrn  # noqa: E402
 from openvoice_amd.utils import CONVERTER_MODEL_CONFIG  # noqa: E402
 
 DEV = "cuda:0"
-VC_CASES = ["vc_b2_t17", "vc_b3_t65_ragged_zero_g", "vc_b1_t40_tau0"]
+VC_CASES = ["vc_b2_t17", "vc_b3_t65_ragged_zero_g", "vc_b1_t40_tau0", "vc_b2_t64_stress_gain4"]
 O_HAT_TOL = 1e-3
 LATENT_TOL = 2e-4
 
@@ -28,8 +28,9 @@ def _model(sd, zero_g):
 @pytest.mark.parametrize("name", VC_CASES)
 def test_voice_conversion_matches_reference_golden(golden_dir, synth_sd, name):
     rec = torch.load(os.path.join(golden_dir, name + ".pt"), weights_only=False)
+    from test_oracle_golden import case_state_dict
     case = rec["case"]
-    model = _model(synth_sd, case["zero_g"])
+    model = _model(case_state_dict(rec, synth_sd), case["zero_g"])
     o_hat, y_mask, (z, z_p, z_hat) = model.voice_conversion(
         rec["spec"].to(DEV), rec["lengths"].to(DEV), rec["g_src"].to(DEV), rec["g_tgt"].to(DEV),
         tau=case["tau"], noise=rec["noise"].to(DEV))
@@ -37,8 +38,11 @@ def test_voice_conversion_matches_reference_golden(golden_dir, synth_sd, name):
     assert torch.equal(y_mask.cpu(), rec["y_mask"])
     errs = {k: (v.cpu() - rec[k]).abs().max().item() for k, v in
             dict(z=z, z_p=z_p, z_hat=z_hat, o_hat=o_hat).items()}
-    print(name, errs)
-    assert errs["z"] <= LATENT_TOL and errs["z_p"] <= LATENT_TOL and errs["z_hat"] <= LATENT_TOL, errs
+    # the latent bar is relative to the latents' magnitude: |z| <= ~4 in the calibrated cases, ~17 in the
+    # high-dynamic-range case (params.stress_state_dict), where fp32 summation-order noise grows in proportion
+    lat_tol = LATENT_TOL * max(1.0, rec["z"].abs().max().item() / 4.0)
+    print(name, errs, "| |z|max", rec["z"].abs().max().item(), "latent bar", lat_tol)
+    assert errs["z"] <= lat_tol and errs["z_p"] <= lat_tol and errs["z_hat"] <= lat_tol, errs
     assert errs["o_hat"] <= O_HAT_TOL, errs
     assert o_hat.shape == rec["o_hat"].shape
 
@@ -187,6 +191,61 @@ def test_tone_color_converter_api_end_to_end_from_files(tmp_path, synth_sd):
     o_b, n_b = tcc.convert_batch([src, src[: sr]], src_se, tgt_se, tau=0.0)
     assert n_b.tolist() == [spec.shape[2] * 256, ((sr - 256) // 256 + 1) * 256]
     assert np.abs(o_b[0, 0].cpu().numpy()[: len(audio)] - audio).max() <= 1e-3
+
+
+def test_ragged_batch_at_benchmark_length_matches_oracle_on_the_same_padded_batch(synth_sd):
+    """B = 3 x T = 861 with lengths 861 / 600 / 100: the generator is unmasked, so a padded batch
+    differs from per-utterance runs near each utterance's end (hard part 6) -- the oracle therefore
+    converts the SAME padded batch.  Every time tile of the short utterances beyond their length is exercised."""
+    from oracle import vc_oracle
+    B, T = 3, 861
+    gen = torch.Generator().manual_seed(861600100)
+    spec = torch.rand(B, 513, T, generator=gen) * torch.linspace(3, 0.05, 513)[None, :, None]
+    lengths = torch.tensor([861, 600, 100])
+    g_src, g_tgt = 0.3 * torch.randn(1, 256, 1, generator=gen), 0.3 * torch.randn(B, 256, 1, generator=gen)
+    noise = torch.randn(B, 192, T, generator=gen)
+    torch.set_num_threads(usable_cpus(32))
+    with torch.no_grad():
+        o_ref, mask_ref, (z_r, zp_r, zh_r) = vc_oracle.voice_conversion(
+            synth_sd, CONVERTER_MODEL_CONFIG, spec, lengths, g_src, g_tgt, 0.3, noise, zero_g=True)
+    model = _model(synth_sd, True)
+    o_hat, y_mask, (z, z_p, z_hat) = model.voice_conversion(spec.to(DEV), lengths.to(DEV), g_src.to(DEV),
+                                                            g_tgt.to(DEV), tau=0.3, noise=noise.to(DEV))
+    torch.cuda.synchronize()
+    errs = dict(z=(z.cpu() - z_r).abs().max().item(), z_p=(z_p.cpu() - zp_r).abs().max().item(),
+                z_hat=(z_hat.cpu() - zh_r).abs().max().item(), o_hat=(o_hat.cpu() - o_ref).abs().max().item())
+    print("ragged 861/600/100:", errs)
+    assert torch.equal(y_mask.cpu(), mask_ref)
+    assert max(errs["z"], errs["z_p"], errs["z_hat"]) <= LATENT_TOL and errs["o_hat"] <= O_HAT_TOL, errs
+    assert z_hat[2, :, 100:].abs().max().item() == 0.0 and z_hat[1, :, 600:].abs().max().item() == 0.0
+    # the padded tail of a short utterance is NOT silence (unmasked generator: biases propagate) -- and matches
+    tail = o_hat[2, 0, 256 * 200:].cpu()
+    assert tail.abs().max().item() > 0 and (tail - o_ref[2, 0, 256 * 200:]).abs().max().item() <= O_HAT_TOL
+
+
+def test_device_rng_path_is_deterministic_under_a_seed(synth_sd):
+    """What bench.py times: waveform -> spectrogram_torch -> voice_conversion with ``noise=None`` (drawn on the device
+    from torch's generator).  Under the same ``torch.manual_seed`` two runs at B = 32 are bit-identical; another seed
+    changes the waveform (tau > 0), and an explicit draw from the same seed reproduces the implicit one."""
+    from openvoice_amd.mel_processing import spectrogram_torch
+    model = _model(synth_sd, True)
+    B, N = 32, 256 * 120
+    gen = torch.Generator().manual_seed(12)
+    wave = (0.5 * torch.rand(B, N, generator=gen) - 0.25).to(DEV)
+    g = (0.3 * torch.randn(1, 256, 1, generator=gen)).to(DEV)
+
+    def run(seed, explicit=False):
+        torch.manual_seed(seed)
+        spec = spectrogram_torch(wave, 1024, 22050, 256, 1024, center=False)
+        lengths = torch.full((B,), spec.shape[2], dtype=torch.int64, device=DEV)
+        noise = torch.randn(B, 192, spec.shape[2], dtype=torch.float32, device=DEV) if explicit else None
+        return model.voice_conversion(spec, lengths, g, g, tau=0.3, noise=noise)[0].clone()
+
+    a, b, c, d = run(7), run(7), run(8), run(7, explicit=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all() and torch.equal(a, b), "same seed, same batch: must be bit-identical"
+    assert not torch.equal(a, c), "another seed must change the posterior sample"
+    assert torch.equal(a, d), "the implicit draw is torch.randn(B, 192, T) on the device from the global generator"
 
 
 def test_extract_se_batches_equal_length_pieces(tmp_path, synth_sd):

@@ -25,6 +25,12 @@ def main():
     ap.add_argument("--frames", type=int, default=861)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--no-fp32", action="store_true")
+    ap.add_argument("--pmc-calibration", action="store_true",
+                    help="after the timed region, three 1 GiB device-to-device copies (a known byte count) so that a "
+                         "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass over this command can be calibrated")
+    ap.add_argument("--counters", default=None,
+                    help="JSON written by tools/bf16_counters.py from rocprofv3 --pmc passes over THIS command: its "
+                         "measured HBM traffic / matrix-busy / clock are reported next to the algorithmic figures")
     args = ap.parse_args()
     from openvoice_amd.bf16 import GeneratorBf16
     from openvoice_amd.engine import ConverterEngine
@@ -55,6 +61,24 @@ def main():
            "alg_hbm_GBps": round(alg_bytes(CFG, B, T, 2) / dt / 1e9, 1), "hbm_peak_GBps": 8000, "hbm_achievable_GBps": 6300,
            "frac_of_hbm_peak": round(alg_bytes(CFG, B, T, 2) / dt / 8e12, 3),
            "alg_tflops": round(529.44e9 * B * T / 861 / dt / 1e12, 1), "bf16_mfma_peak_tflops": 2500}
+    out["decode_passes_in_process"] = 2 + args.steps
+    if args.counters and os.path.exists(args.counters):
+        with open(args.counters) as fh:
+            c = json.load(fh)
+        out["traffic_hbm_GB"] = c.get("traffic_GB_per_pass")
+        out["traffic_over_algorithmic"] = (round(c["traffic_GB_per_pass"] / out["alg_hbm_GB"], 3)
+                                           if c.get("traffic_GB_per_pass") else None)
+        out["traffic_hbm_GBps"] = round(c["traffic_GB_per_pass"] / dt, 1) if c.get("traffic_GB_per_pass") else None
+        out["mfma_busy"] = c.get("mfma_busy")
+        out["shader_clock_ghz"] = c.get("shader_clock_ghz")
+        out["counters_source"] = c.get("source")
+    if args.pmc_calibration:
+        src = torch.zeros(1 << 28, dtype=torch.float32, device=dev)   # 1 GiB
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        del src, dst
     if not args.no_fp32:
         eng = ConverterEngine(sd, CFG, 513, dev, zero_g=False)
         cond = eng._linear(g.reshape(1, -1), eng.dec_cond_w, eng.dec_cond_b)
