@@ -118,6 +118,16 @@ typedef struct ov_conv1d_params {
   int32_t chunk;         /* input channels per LDS fill: 0 = default (32 for 1x1, else 16), or 16/32 */
   float in_slope;        /* leaky-ReLU slope applied to x while staging (1.0f = identity)        */
   float scale;
+  /* Length-aware work list (padded batches: ragged convert_batch, batched TTS -- reference openvoice/models.py:477-489
+   * pads every utterance to the longest).  col_limit[b] * col_limit_scale = the output columns of utterance b that
+   * matter (clamped to [0, L]); time tiles wholly beyond it are dropped from the work list -- their columns of out
+   * are NOT written -- and the remaining tiles are dealt evenly over the workgroups.  Every computed value is
+   * bit-identical to the full launch.  NULL = the whole tensor.  DEVICE pointer, int32 [B]; ignored (whole tensor)
+   * when B > 256.  The caller owns the margin: the generator's receptive field is 13.3 frames, so a limit of
+   * length + 16 frames leaves every valid sample unchanged (ov_frame_limits_i32). */
+  const int32_t* col_limit;
+  int32_t col_limit_scale; /* columns of this launch per unit of col_limit (e.g. the stage's upsampling factor) */
+  int32_t reserved0;
 } ov_conv1d_params;
 
 /* ---- host-side helpers -------------------------------------------------------------------- */
@@ -234,6 +244,16 @@ int ov_frame_hops_f32(const float* wave, float* hops, int B, int N, int hop, int
  * w is the dense [C][K] DEVICE weight. */
 int ov_conv_post_tanh_f32(const float* x, const float* w, float* out, int B, int C, int L, int K,
                           float in_slope, ov_stream_t stream);
+/* The same with a length-aware tail: samples t >= col_limit[b] * col_limit_scale of utterance b are written as 0
+ * without reading x there (the generator launches before it left those columns unwritten, see
+ * ov_conv1d_params.col_limit).  col_limit NULL = ov_conv_post_tanh_f32. */
+int ov_conv_post_tanh_limited_f32(const float* x, const float* w, float* out, int B, int C, int L, int K,
+                                  float in_slope, const int32_t* col_limit, int col_limit_scale, ov_stream_t stream);
+/* limits[b] = min(T, max(0, lengths[b]) + margin): the frames of utterance b the generator has to produce so that
+ * every sample of its first lengths[b] frames is unaffected by what lies beyond (margin >= 14: the generator's
+ * one-sided receptive field is 13.3 frames -- conv_pre 3, ups 1 + 1/8 + 1/64 + 1/128, MRF 60 samples per stage,
+ * conv_post 3 samples; reference openvoice/models.py:225-291). */
+int ov_frame_limits_i32(const int64_t* lengths, int32_t* limits, int B, int T, int margin, ov_stream_t stream);
 
 /* y[b][m] = bias[m] + sum_k w[m][k] * x[b][k]  (dense row-major w, all DEVICE).  The T=1
  * conditioning convs, reference openvoice/modules.py:189-190 (cond_layer) and
@@ -391,7 +411,8 @@ typedef struct ov_respair_bf16_params {
 int ov_resblock_pair_bf16cl(const ov_respair_bf16_params* p, ov_stream_t stream);
 int ov_resblock_pair_bf16_supported(int C, int K, int dil);
 
-/* Library/ABI version (major*100 + minor). */
+/* Library/ABI version (major*100 + minor).  2.01: ov_conv1d_params.col_limit, ov_conv_post_tanh_limited_f32,
+ * ov_frame_limits_i32. */
 int ov_version(void);
 /* 0 for a production build; non-zero = a measurement build with parts of the kernels compiled out (results are
  * meaningless; openvoice_amd/_lib.py refuses to load it unless OPENVOICE_AMD_ALLOW_EXPERIMENT=1). */

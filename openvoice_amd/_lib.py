@@ -51,6 +51,7 @@ class ConvParams(ctypes.Structure):
         ("tiles_per_wg", ctypes.c_int32), ("tile", ctypes.c_int32), ("loaders", ctypes.c_int32),
         ("chunk", ctypes.c_int32),
         ("in_slope", ctypes.c_float), ("scale", ctypes.c_float),
+        ("col_limit", _fp), ("col_limit_scale", ctypes.c_int32), ("reserved0", ctypes.c_int32),
     ]
 
 
@@ -106,6 +107,9 @@ SIGNATURES = {
     "ov_wn_layer_tile": (ctypes.c_int, [_i, _i, _i]),
     "ov_conv_post_tanh_f32": (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_float, _fp]),
+    "ov_conv_post_tanh_limited_f32": (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                     ctypes.c_int, ctypes.c_float, _fp, ctypes.c_int, _fp]),
+    "ov_frame_limits_i32": (ctypes.c_int, [_fp, _fp, _i, _i, _i, _fp]),
     "ov_linear_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
     "ov_sequence_mask_f32": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
     "ov_layernorm_freq_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,

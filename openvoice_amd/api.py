@@ -127,8 +127,10 @@ class BaseSpeakerTTS(OpenVoiceBaseClass):
         for i, s in enumerate(seqs):
             x[i, :s.numel()] = s
         sid = torch.full((len(seqs),), int(speaker_id), dtype=torch.long)
+        # padded batch: the generator computes length + 16 frames per sentence, not the longest one's (the samples
+        # returned below are bit-identical either way)
         o, _, y_mask, _ = self.model.infer(x.to(device), lengths.to(device), sid=sid.to(device), noise_scale=noise_scale,
-                                           noise_scale_w=noise_scale_w, length_scale=1.0 / speed)
+                                           noise_scale_w=noise_scale_w, length_scale=1.0 / speed, skip_padding=True)
         frames = y_mask[:, 0].sum(1).long().cpu().tolist()
         o = o[:, 0].data.cpu().float().numpy()
         return [o[i, :frames[i] * hop] for i in range(len(seqs))]
@@ -246,7 +248,8 @@ class ToneColorConverter(OpenVoiceBaseClass):
         differ from a per-utterance run (hard part 6); trim with the returned
         lengths."""
         hop = self.hps.data.hop_length
-        if isinstance(waveforms, (list, tuple)):
+        ragged = isinstance(waveforms, (list, tuple))
+        if ragged:
             specs = [self._spec(torch.as_tensor(w, dtype=torch.float32).to(self.device).reshape(1, -1))[0]
                      for w in waveforms]
             frames = [s.shape[1] for s in specs]
@@ -261,10 +264,12 @@ class ToneColorConverter(OpenVoiceBaseClass):
         if self.use_graphs:
             # the graph's outputs are static buffers: hand the caller its own copy
             o_hat = self.model.voice_conversion(spec, spec_lengths, sid_src=src_se, sid_tgt=tgt_se, tau=tau,
-                                                noise=noise, graph=True)[0].clone()
+                                                noise=noise, graph=True, skip_padding=ragged)[0].clone()
         else:
+            # ragged batch: the generator skips what lies beyond length + 16 frames of each utterance (the samples
+            # within the returned lengths are bit-identical to the full computation; the padded tail is zero)
             o_hat = self.model.voice_conversion(spec, spec_lengths, sid_src=src_se, sid_tgt=tgt_se, tau=tau,
-                                                noise=noise)[0]
+                                                noise=noise, skip_padding=ragged)[0]
         return o_hat, spec_lengths * hop
 
     @torch.no_grad()

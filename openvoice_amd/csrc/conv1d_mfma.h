@@ -52,6 +52,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int UNIT = 8;    // input channels per unrolled unit (4 ci-pairs x K taps)
 constexpr int REC = 256;   // floats per packed-weight record (64 lanes x 4 k-steps)
 constexpr int LB_MAX = 12;  // loader: at most this many 16-byte (or 4-byte) loads in flight per lane
+constexpr int LIMIT_MAX_BATCH = 256;   // length-aware work lists (ov_conv1d_params.col_limit): utterances per launch
 
 // units are padded to a multiple of 4 (the largest units-per-chunk of any kernel variant)
 __host__ __device__ inline int packed_units(int cin) { return ((cin + UNIT - 1) / UNIT + 3) / 4 * 4; }
@@ -419,7 +420,54 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
   // neighbouring time tiles (shared halo lines) are neighbours in the list.
   const int ntiles = (L + N_BLK - 1) / N_BLK;
   const int mblocks = (p.M + 32 * WM * WVM - 1) / (32 * WM * WVM);
-  const int total = ntiles * mblocks * p.B;
+  int total = ntiles * mblocks * p.B;
+  // Length-aware work list (ov_conv1d_params.col_limit): utterance b contributes only the time tiles that start
+  // before its column limit; lim_pref[b] = tiles of the utterances before b, so the list stays dense and is dealt
+  // evenly whatever the lengths are.  One wave computes the prefix sums (<= 256 utterances) once per workgroup.
+  __shared__ int lim_pref[LIMIT_MAX_BATCH + 1];
+  const bool limited = p.col_limit != nullptr;
+  if (limited) {
+    if (wave == 0) {
+      int carry = 0;
+      for (int base = 0; base < p.B; base += 64) {
+        const int bb = base + lane;
+        int n = 0;
+        if (bb < p.B) {
+          long long c = (long long)p.col_limit[bb] * p.col_limit_scale;
+          c = c < 0 ? 0 : (c > L ? L : c);
+          n = ((int)c + N_BLK - 1) / N_BLK;
+        }
+        int s = n;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int v = __shfl_up(s, d, 64);
+          if (lane >= d) s += v;
+        }
+        if (bb < p.B) lim_pref[bb + 1] = carry + s;
+        carry += __shfl(s, 63, 64);
+      }
+      if (lane == 0) lim_pref[0] = 0;
+    }
+    __syncthreads();
+    total = __builtin_amdgcn_readfirstlane(lim_pref[p.B]) * mblocks;
+  }
+  // work item -> (utterance, time tile, M-block)
+  auto decode = [&](int w, int& ub, int& utile, int& umblk) {
+    const int g = w / mblocks;
+    umblk = w - g * mblocks;
+    if (!limited) {
+      ub = g / ntiles;
+      utile = g - ub * ntiles;
+      return;
+    }
+    int lo = 0, hi = p.B;                      // lim_pref[lo] <= g < lim_pref[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (__builtin_amdgcn_readfirstlane(lim_pref[mid]) <= g) lo = mid; else hi = mid;
+    }
+    ub = lo;
+    utile = g - __builtin_amdgcn_readfirstlane(lim_pref[lo]);
+  };
   // XCD-contiguous order: block j runs on XCD j % 8 (observed placement, a speed assumption only), and every XCD has
   // its own L2.  XCD x therefore owns the contiguous eighth [x * total / 8, (x + 1) * total / 8) of the list and its
   // workgroups stride through it together, so that list neighbours -- which share the 128-byte lines at their tile
@@ -453,8 +501,10 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
     const int Lin = L + ((K % 2 == 1) ? 0 : (K - 1) * DIL);
     int it = 0;
     for (int wid = wid0; wid < wend; wid += wstride) {
-      const int t0 = ((wid / mblocks) % ntiles) * N_BLK;
-      const float* __restrict__ xb = p.x + (int64_t)(wid / (ntiles * mblocks)) * p.x_bstride;
+      int lb, ltile, lmblk;
+      decode(wid, lb, ltile, lmblk);
+      const int t0 = ltile * N_BLK;
+      const float* __restrict__ xb = p.x + (int64_t)lb * p.x_bstride;
       for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
         float* dst = xs + (it & 1) * BUF;
 #pragma unroll 1   // one batch of LB loads per lane in flight at a time: bounds the loader's VGPRs
@@ -518,7 +568,8 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
   const int wm = wave / WVN, wn = wave % WVN;
   const int recs_per_mtile = nunits * K + 1;
   int wid = wid0;
-  int mblk = wid % mblocks, tile = (wid / mblocks) % ntiles, b = wid / (ntiles * mblocks);
+  int mblk, tile, b;
+  decode(wid, b, tile, mblk);
   int mtile0 = (mblk * WVM + wm) * WM;
 
   // weight fragments: scalar base + per-lane 32-bit index (in 16-byte units), record stride 64
@@ -601,7 +652,8 @@ __global__ __launch_bounds__(64 * (4 + NLD), (EPI == OV_EPI_GATE || EPI == EPI_C
     // next work item; its first weight record is in flight while the epilogue of this one runs
     const int nwid = wid + wstride;
     const bool more = nwid < wend;
-    const int nmblk = nwid % mblocks, ntile = (nwid / mblocks) % ntiles, nb = nwid / (ntiles * mblocks);
+    int nmblk = 0, ntile = 0, nb = 0;
+    if (more) decode(nwid, nb, ntile, nmblk);
     const int nmtile0 = (nmblk * WVM + wm) * WM;
     uint32_t nwidx[WM];
 #pragma unroll

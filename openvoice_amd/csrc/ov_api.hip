@@ -20,7 +20,8 @@ template <int K>
 __global__ __launch_bounds__(256) void conv_post_tanh_vec_kernel(const float* __restrict__ x,
                                                                  const float* __restrict__ w,
                                                                  float* __restrict__ out, int C, int L,
-                                                                 float slope) {
+                                                                 float slope, const int32_t* __restrict__ col_limit,
+                                                                 int limit_scale) {
   constexpr int PAD = (K - 1) / 2;
   static_assert(PAD <= 4, "halo must fit one float4 on each side");
   extern __shared__ float wsm[];
@@ -29,6 +30,10 @@ __global__ __launch_bounds__(256) void conv_post_tanh_vec_kernel(const float* __
   const int b = blockIdx.y;
   const int64_t t = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (t >= L) return;
+  if (col_limit && t >= (int64_t)col_limit[b] * limit_scale) {   // beyond the utterance: silence, x is not read
+    *reinterpret_cast<f32x4*>(out + (int64_t)b * L + t) = f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
   const float* xb = x + (int64_t)b * C * L;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int c = 0; c < C; ++c) {
@@ -54,13 +59,19 @@ __global__ __launch_bounds__(256) void conv_post_tanh_vec_kernel(const float* __
 __global__ __launch_bounds__(256) void conv_post_tanh_scalar_kernel(const float* __restrict__ x,
                                                                     const float* __restrict__ w,
                                                                     float* __restrict__ out, int C, int L,
-                                                                    int K, float slope) {
+                                                                    int K, float slope,
+                                                                    const int32_t* __restrict__ col_limit,
+                                                                    int limit_scale) {
   extern __shared__ float wsm[];
   for (int i = threadIdx.x; i < C * K; i += 256) wsm[i] = w[i];
   __syncthreads();
   const int b = blockIdx.y;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= L) return;
+  if (col_limit && t >= (int64_t)col_limit[b] * limit_scale) {
+    out[(int64_t)b * L + t] = 0.f;
+    return;
+  }
   const int pad = (K - 1) / 2;
   const float* xb = x + (int64_t)b * C * L;
   float acc = 0.f;
@@ -89,6 +100,15 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
   if (lane == 0) y[(int64_t)b * M + m] = acc + (bias ? bias[m] : 0.f);
+}
+
+__global__ void frame_limits_kernel(const int64_t* __restrict__ lengths, int32_t* __restrict__ limits, int B, int T,
+                                    int margin) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  int64_t n = lengths[b];
+  n = (n < 0 ? 0 : n) + margin;
+  limits[b] = (int32_t)(n < T ? n : T);
 }
 
 __global__ void sequence_mask_kernel(const int64_t* __restrict__ lengths, float* __restrict__ mask, int T,
@@ -162,7 +182,7 @@ using namespace ovk;
 
 extern "C" {
 
-int ov_version(void) { return 200; }
+int ov_version(void) { return 201; }
 
 // 0 in every shippable build; the measurement builds of scripts/exp_sync.sh (OV_EXP = 1 / 2: staging loads and / or
 // barriers compiled out, numerically meaningless) report their number so that the Python binding can refuse them.
@@ -230,6 +250,8 @@ int ov_conv1d_f32(const ov_conv1d_params* pin, ov_stream_t stream) {
       return OV_E_ALIGN;
   }
   if ((reinterpret_cast<uintptr_t>(p->w) & 15)) return OV_E_ALIGN;
+  if (p->col_limit && (p->col_limit_scale <= 0 || (reinterpret_cast<uintptr_t>(p->col_limit) & 3))) return OV_E_BADARG;
+  if (p->col_limit && p->B > ovk::LIMIT_MAX_BATCH) p->col_limit = nullptr;   // documented: whole tensor
   if (p->chunk != 0 && p->chunk != 16 && p->chunk != 32) return OV_E_BADARG;
   if (p->tile < 0 || p->tile > 4 ||
       (p->loaders != 0 && p->loaders != 1 && p->loaders != 2 && p->loaders != 4))
@@ -277,17 +299,32 @@ int ov_frame_hops_f32(const float* wave, float* hops, int B, int N, int hop, int
 
 int ov_conv_post_tanh_f32(const float* x, const float* w, float* out, int B, int C, int L, int K,
                           float in_slope, ov_stream_t stream) {
+  return ov_conv_post_tanh_limited_f32(x, w, out, B, C, L, K, in_slope, nullptr, 0, stream);
+}
+
+int ov_frame_limits_i32(const int64_t* lengths, int32_t* limits, int B, int T, int margin, ov_stream_t stream) {
+  if (!lengths || !limits || B <= 0 || T <= 0 || margin < 0) return OV_E_BADARG;
+  hipLaunchKernelGGL(frame_limits_kernel, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     lengths, limits, B, T, margin);
+  return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
+}
+
+int ov_conv_post_tanh_limited_f32(const float* x, const float* w, float* out, int B, int C, int L, int K,
+                                  float in_slope, const int32_t* col_limit, int col_limit_scale, ov_stream_t stream) {
   if (!x || !w || !out || B <= 0 || C <= 0 || L <= 0 || K <= 0 || (K & 1) == 0 || B > 65535) return OV_E_BADARG;
+  if (col_limit && col_limit_scale <= 0) return OV_E_BADARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t smem = (size_t)C * K * sizeof(float);
   const bool vec = (K == 7) && (L % 4 == 0) && !(reinterpret_cast<uintptr_t>(x) & 15) &&
                    !(reinterpret_cast<uintptr_t>(out) & 15);
   if (vec) {
     dim3 grid((L / 4 + 255) / 256, B);
-    hipLaunchKernelGGL(conv_post_tanh_vec_kernel<7>, grid, dim3(256), smem, st, x, w, out, C, L, in_slope);
+    hipLaunchKernelGGL(conv_post_tanh_vec_kernel<7>, grid, dim3(256), smem, st, x, w, out, C, L, in_slope, col_limit,
+                       col_limit_scale);
   } else {
     dim3 grid((L + 255) / 256, B);
-    hipLaunchKernelGGL(conv_post_tanh_scalar_kernel, grid, dim3(256), smem, st, x, w, out, C, L, K, in_slope);
+    hipLaunchKernelGGL(conv_post_tanh_scalar_kernel, grid, dim3(256), smem, st, x, w, out, C, L, K, in_slope,
+                       col_limit, col_limit_scale);
   }
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
 }

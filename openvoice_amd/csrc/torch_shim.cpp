@@ -200,11 +200,12 @@ void finish(int rc, const char* what) { TORCH_CHECK(rc == OV_OK, what, " failed:
 
 // ip = [B, Cin, L, x_ld, out_ld, M, Cout, K, dil, epi, flags, split, phase_s, tiles_per_wg, tile, loaders, chunk,
 //       x_bstride, out_bstride, res_bstride, add_bstride, out2_bstride, bias_b_bstride, mask_bstride,
-//       x_off, out_off, res_off, bias_b_off]   (strides and offsets in elements);  fp = [in_slope, scale]
+//       x_off, out_off, res_off, bias_b_off, col_limit_scale]   (strides and offsets in elements);
+// fp = [in_slope, scale]
 void conv1d_f32(const OptTensor& x, const OptTensor& w, const OptTensor& bias, const OptTensor& out, const OptTensor& res,
                 const OptTensor& add, const OptTensor& out2, const OptTensor& mask, const OptTensor& bias_b,
-                at::IntArrayRef ip, at::ArrayRef<double> fp) {
-  TORCH_CHECK(ip.size() == 28 && fp.size() == 2, "openvoice_amd::conv1d_f32: 28 integer and 2 float parameters");
+                const OptTensor& col_limit, at::IntArrayRef ip, at::ArrayRef<double> fp) {
+  TORCH_CHECK(ip.size() == 29 && fp.size() == 2, "openvoice_amd::conv1d_f32: 29 integer and 2 float parameters");
   Ctx c{"conv1d_f32", false};
   ov_conv1d_params p{};
   p.x = sptr<float>(x, c, 0, ip[24]);
@@ -216,6 +217,8 @@ void conv1d_f32(const OptTensor& x, const OptTensor& w, const OptTensor& bias, c
   p.out2 = sptr<float>(out2, c, 6);
   p.mask = sptr<float>(mask, c, 7);
   p.bias_b = sptr<float>(bias_b, c, 8, ip[27]);
+  p.col_limit = sptr<int32_t>(col_limit, c, 9);
+  p.col_limit_scale = (int32_t)ip[28];
   p.B = (int32_t)ip[0]; p.Cin = (int32_t)ip[1]; p.L = (int32_t)ip[2]; p.x_ld = (int32_t)ip[3]; p.out_ld = (int32_t)ip[4];
   p.M = (int32_t)ip[5]; p.Cout = (int32_t)ip[6]; p.K = (int32_t)ip[7]; p.dil = (int32_t)ip[8]; p.epi = (int32_t)ip[9];
   p.flags = (int32_t)ip[10]; p.split = (int32_t)ip[11]; p.phase_s = (int32_t)ip[12]; p.tiles_per_wg = (int32_t)ip[13];
@@ -299,7 +302,7 @@ void resblock_pair_bf16cl(const OptTensor& x, const OptTensor& w1, const OptTens
 TORCH_LIBRARY(openvoice_amd, m) {
   // ---- parameter-struct entry points
   m.def("conv1d_f32(Tensor? x, Tensor? w, Tensor? bias, Tensor(a!)? out, Tensor? res, Tensor? add, Tensor(b!)? out2, "
-        "Tensor? mask, Tensor? bias_b, int[] ip, float[] fp) -> ()", &conv1d_f32);
+        "Tensor? mask, Tensor? bias_b, Tensor? col_limit, int[] ip, float[] fp) -> ()", &conv1d_f32);
   m.def("resblock_pair_f32(Tensor? x, Tensor? w1, Tensor? b1, Tensor? w2, Tensor? b2, Tensor(a!)? out, Tensor? add, "
         "Tensor(b!)? dbg, int[] ip, float[] fp) -> ()", &resblock_pair_f32);
   m.def("wn_layer_f32(Tensor? x, Tensor(a!)? out, Tensor(b!)? skip, Tensor? w_in, Tensor? b_in, Tensor? cond, Tensor? w_rs, "
@@ -311,6 +314,8 @@ TORCH_LIBRARY(openvoice_amd, m) {
   // ---- device entry points with flat argument lists (schema derived from the C prototype)
   bind_device<&ov_frame_hops_f32>(m, "frame_hops_f32");
   bind_device<&ov_conv_post_tanh_f32>(m, "conv_post_tanh_f32");
+  bind_device<&ov_conv_post_tanh_limited_f32>(m, "conv_post_tanh_limited_f32");
+  bind_device<&ov_frame_limits_i32>(m, "frame_limits_i32");
   bind_device<&ov_linear_f32>(m, "linear_f32");
   bind_device<&ov_sequence_mask_f32>(m, "sequence_mask_f32");
   bind_device<&ov_layernorm_freq_f32>(m, "layernorm_freq_f32");

@@ -20,6 +20,13 @@ from ._lib import (ConvParams, EPI_CONVT, EPI_COUPLE, EPI_GATE, EPI_LINEAR, EPI_
                    F_CONVT_GROUPED, F_MASK_V, F_OUT2_INIT)
 from .params import ENC_Q_LAYERS, FLOW_LAYERS, N_FLOWS, REF_ENC_FILTERS, REF_ENC_GRU, effective_weight
 
+# Length-aware work lists (``skip_padding``): the generator's one-sided receptive field is 13.3 frames -- conv_pre 3,
+# the four transposed convs 1 + 1/8 + 1/64 + 1/128, the MRF 60 samples per stage (k = 11: dilations 1, 3, 5 + three
+# dilation-1 convs = 5 * (1 + 3 + 5 + 3)) at 8 / 64 / 128 / 256 samples per frame, conv_post 3 samples (reference:
+# openvoice/models.py:225-291, modules.py:221-309) -- so computing length + 16 frames leaves the first ``length``
+# frames bit-identical to the full computation.
+GENERATOR_MARGIN = 16
+LIMIT_MAX_BATCH = 256   # ovk::LIMIT_MAX_BATCH: utterances per launch the kernels' prefix table holds
 LRELU_SLOPE = 0.1       # reference: openvoice/modules.py:14
 FINAL_LRELU_SLOPE = 0.01  # F.leaky_relu default at openvoice/models.py:287
 
@@ -137,15 +144,18 @@ if _EXTRA_CONV_FLAGS & ~_lib.F_NO_XCD_MAP:
 def launch_conv(layer, x, x_off, x_bs, out, out_off, out_bs, B, L, epi=EPI_LINEAR, flags=0, in_slope=1.0,
                 scale=1.0, res=None, res_off=0, res_bs=0, add=None, add_bs=0, out2=None, out2_bs=0, mask=None,
                 bias_b=None, bias_b_off=0, bias_b_bs=0, split=0, phase_s=1, cin=None, rows=None, tiles_per_wg=0,
-                x_ld=0, out_ld=0, mask_bs=0, tile=0, loaders=0, chunk=0):
+                x_ld=0, out_ld=0, mask_bs=0, tile=0, loaders=0, chunk=0, col_limit=None, col_limit_scale=1):
     """Fill ``ov_conv1d_params`` and launch on torch's current stream of ``x``'s device.
-    Offsets, row strides (``*_ld``, 0 = dense) and batch strides are in elements."""
+    Offsets, row strides (``*_ld``, 0 = dense) and batch strides are in elements.  ``col_limit`` (int32 [B] on the
+    device) x ``col_limit_scale`` = output columns per utterance that matter: tiles beyond are not computed."""
     flags |= _EXTRA_CONV_FLAGS
     if _lib.use_torch_binding():
         ip = [B, layer.cin if cin is None else cin, L, x_ld, out_ld, layer.rows if rows is None else rows, layer.cout,
               layer.K, layer.dil, epi, flags, split, phase_s, tiles_per_wg, tile, loaders, chunk,
-              x_bs, out_bs, res_bs, add_bs, out2_bs, bias_b_bs, mask_bs, x_off, out_off, res_off, bias_b_off]
-        _lib.torch_op("conv1d_f32", x, layer.w, layer.bias, out, res, add, out2, mask, bias_b, ip, [in_slope, scale])
+              x_bs, out_bs, res_bs, add_bs, out2_bs, bias_b_bs, mask_bs, x_off, out_off, res_off, bias_b_off,
+              col_limit_scale]
+        _lib.torch_op("conv1d_f32", x, layer.w, layer.bias, out, res, add, out2, mask, bias_b, col_limit, ip,
+                      [in_slope, scale])
         return
     p = ConvParams()
     p.x, p.w = _ptr(x, x_off), _ptr(layer.w)
@@ -165,6 +175,8 @@ def launch_conv(layer, x, x_off, x_bs, out, out_off, out_bs, B, L, epi=EPI_LINEA
     p.in_slope, p.scale = in_slope, scale
     p.tiles_per_wg, p.tile, p.loaders, p.chunk = tiles_per_wg, tile, loaders, chunk
     p.x_ld, p.out_ld, p.mask_bstride = x_ld, out_ld, mask_bs
+    p.col_limit = ctypes.c_void_p(col_limit.data_ptr()) if col_limit is not None else None
+    p.col_limit_scale = col_limit_scale
     stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(_lib.load().ov_conv1d_f32(ctypes.byref(p), stream), "ov_conv1d_f32")
 
@@ -506,11 +518,15 @@ class ConverterEngine:
     # ---- the path ----------------------------------------------------------------------------------
     @torch.no_grad()
     @on_own_device
-    def voice_conversion(self, spec, spec_lengths, sid_src, sid_tgt, tau=1.0, noise=None):
+    def voice_conversion(self, spec, spec_lengths, sid_src, sid_tgt, tau=1.0, noise=None, skip_padding=False):
         """Same contract as the reference seam (openvoice/models.py:492-499):
         ``(o_hat [B,1,256T], y_mask [B,1,T], (z, z_p, z_hat) [B,192,T])``.  ``noise`` [B,192,T]
         replaces the reference's ``torch.randn_like`` draw (models.py:220); when omitted it is drawn
-        from torch's generator on the device."""
+        from torch's generator on the device.  ``skip_padding``: the generator -- 98 % of the work, and unmasked in
+        the reference, so a padded batch costs as if every utterance had the longest length -- computes only the
+        first ``length + GENERATOR_MARGIN`` frames of each utterance (length-aware work lists,
+        ``ov_conv1d_params.col_limit``); every sample of the first ``length`` frames is bit-identical to the full
+        computation, the rest of ``o_hat`` is zero instead of the reference's bias-driven junk."""
         dev = self.device
         spec = spec.to(dev, torch.float32)
         B, F, T = spec.shape
@@ -551,7 +567,8 @@ class ConverterEngine:
                 e1.record()
                 self.profile.append(("gen_bf16", 0.0, e0, e1))
         else:
-            o_hat = self.decode(z_hat, cond_d, ws, T=T)
+            limits = self.frame_limits(lengths, T) if skip_padding else None
+            o_hat = self.decode(z_hat, cond_d, ws, T=T, limits=limits)
         # fresh dense tensors for the caller (the workspace is reused by the next call)
         outs = tuple(t[:, :, :T].contiguous() for t in (z, z_p, z_hat))
         return o_hat, mask[:, :T].unsqueeze(1).contiguous(), outs
@@ -575,14 +592,15 @@ class ConverterEngine:
         self._flow(z, z_p, sub, nb, T, [rows(c) for c in conds["src"]], mask, reverse=False)
         self._flow(z_p, z_hat, sub, nb, T, [rows(c) for c in conds["tgt"]], mask, reverse=True)
 
-    def graphed(self, B, T, tau, src_rows=1, tgt_rows=1, max_cached=4):
+    def graphed(self, B, T, tau, src_rows=1, tgt_rows=1, max_cached=4, skip_padding=False):
         """``voice_conversion`` for one fixed (B, T, tau) as a captured HIP graph (see ``GraphedConversion``);
         the most recent ``max_cached`` shapes stay resident."""
-        key = (int(B), int(T), float(tau), int(src_rows), int(tgt_rows), bool(getattr(self, "_bf16_on", False)))
+        key = (int(B), int(T), float(tau), int(src_rows), int(tgt_rows), bool(getattr(self, "_bf16_on", False)),
+               bool(skip_padding))
         cache = self.__dict__.setdefault("_graphs", {})
         g = cache.pop(key, None)
         if g is None:
-            g = GraphedConversion(self, B, T, tau, src_rows, tgt_rows)
+            g = GraphedConversion(self, B, T, tau, src_rows, tgt_rows, skip_padding=skip_padding)
             while len(cache) >= max_cached:
                 cache.pop(next(iter(cache)))
         cache[key] = g     # re-inserted last: the dict is the LRU order
@@ -597,9 +615,18 @@ class ConverterEngine:
         self._bf16_on = bool(enable)
         return self
 
-    def decode(self, z_hat, cond_d, ws=None, T=None):
+    def frame_limits(self, lengths, T):
+        """int32 [B] on the device: frames of each utterance the generator must produce so that the first ``lengths[b]``
+        frames are unaffected by what lies beyond (``ov_frame_limits_i32``); no host sync."""
+        B = lengths.shape[0]
+        limits = torch.empty(B, dtype=torch.int32, device=self.device)
+        _lib.call("ov_frame_limits_i32", lengths, limits, B, int(T), GENERATOR_MARGIN)
+        return limits
+
+    def decode(self, z_hat, cond_d, ws=None, T=None, limits=None):
         """Generator (models.py:272-291).  ``z_hat`` is [B, C, ld] with ``T`` valid frames per row
-        (``T`` defaults to the full row, i.e. a dense tensor)."""
+        (``T`` defaults to the full row, i.e. a dense tensor).  ``limits`` (``frame_limits``): frames per utterance
+        to compute -- time tiles wholly beyond are dropped from every launch's work list."""
         B, C, ld = z_hat.shape
         T = ld if T is None else T
         if ws is None:
@@ -607,18 +634,25 @@ class ConverterEngine:
         Tp = ws["Tp"]
         cfg = self.cfg
         ch = cfg["upsample_initial_channel"]
+        if limits is not None and B > LIMIT_MAX_BATCH:
+            limits = None                       # the kernels' prefix table holds 256 utterances: whole tensors beyond
+        lim = lambda scale: dict(col_limit=limits, col_limit_scale=scale) if limits is not None else {}
         self._conv(self.conv_pre, z_hat, 0, C * ld, ws["pre"], 0, ch * Tp, B, T, bias_b=cond_d,
-                   bias_b_bs=0 if cond_d.shape[0] == 1 else cond_d.shape[1], x_ld=ld, out_ld=Tp, tag="conv_pre")
+                   bias_b_bs=0 if cond_d.shape[0] == 1 else cond_d.shape[1], x_ld=ld, out_ld=Tp, tag="conv_pre",
+                   **lim(1))
         x, L, x_ld = ws["pre"], T, Tp
         free = list(ws["dec"])
         nk = len(cfg["resblock_kernel_sizes"])
+        rate = 1                                  # columns per frame at the current stage
         for i, up in enumerate(self.ups):
             s = up["stride"]
             cin, ch = ch, ch // 2
             u = free.pop()
             # leaky_relu(0.1) + ConvTranspose1d (models.py:278-279)
             self._conv(up["conv"], x, 0, cin * x_ld, u, 0, ch * L * s, B, L, epi=EPI_CONVT, in_slope=LRELU_SLOPE,
-                       flags=up["flags"], phase_s=s, x_ld=x_ld, tag="ups", alg_flops=2.0 * cin * ch * 2 * s * L * B)
+                       flags=up["flags"], phase_s=s, x_ld=x_ld, tag="ups", alg_flops=2.0 * cin * ch * 2 * s * L * B,
+                       **lim(rate))
+            rate *= s
             if i > 0:
                 free.append(x)
             L *= s
@@ -628,8 +662,10 @@ class ConverterEngine:
             # MRF: mean of the 3 ResBlock1 outputs (models.py:280-286, modules.py:296-306)
             for j, pairs in enumerate(self.resblocks[i]):
                 cur = u
-                fused = self.fuse_pairs and all((ch, c1.K) in PAIR_POLICY and pair_supported(ch, c1.K, c1.dil)
-                                                for c1, _ in pairs) and L % 4 == 0
+                # (the fused-pair kernel walks whole utterances: with a length-aware work list the pair is two launches,
+                # bit-identical by construction)
+                fused = self.fuse_pairs and limits is None and L % 4 == 0 and all(
+                    (ch, c1.K) in PAIR_POLICY and pair_supported(ch, c1.K, c1.dil) for c1, _ in pairs)
                 for n, (c1, c2) in enumerate(pairs):
                     last = n == len(pairs) - 1
                     add = acc if (last and j > 0) else None
@@ -639,15 +675,19 @@ class ConverterEngine:
                         dst = acc if last else (t1 if cur is ra else ra)
                         self._pair(c1, c2, cur, dst, bs, B, L, add, scale)
                     else:
-                        self._conv(c1, cur, 0, bs, t1, 0, bs, B, L, in_slope=LRELU_SLOPE, tag="mrf")
+                        self._conv(c1, cur, 0, bs, t1, 0, bs, B, L, in_slope=LRELU_SLOPE, tag="mrf", **lim(rate))
                         dst = acc if last else ra
                         self._conv(c2, t1, 0, bs, dst, 0, bs, B, L, in_slope=LRELU_SLOPE, res=cur, res_bs=bs,
-                                   add=add, add_bs=bs, scale=scale, tag="mrf")
+                                   add=add, add_bs=bs, scale=scale, tag="mrf", **lim(rate))
                     cur = dst
             free += [u, t1, ra]
             x = acc
         o_hat = torch.empty(B, 1, L, dtype=torch.float32, device=self.device)
-        _lib.call("ov_conv_post_tanh_f32", x, self.post_w, o_hat, B, ch, L, self.post_w.shape[1], FINAL_LRELU_SLOPE)
+        if limits is not None:
+            _lib.call("ov_conv_post_tanh_limited_f32", x, self.post_w, o_hat, B, ch, L, self.post_w.shape[1],
+                      FINAL_LRELU_SLOPE, limits, rate)
+        else:
+            _lib.call("ov_conv_post_tanh_f32", x, self.post_w, o_hat, B, ch, L, self.post_w.shape[1], FINAL_LRELU_SLOPE)
         return o_hat
 
     # ---- extract_se path -----------------------------------------------------------------------------
@@ -694,7 +734,7 @@ class GraphedConversion:
     this shape is pinned for the life of the graph.  Reference contract unchanged: openvoice/models.py:492-499."""
 
     @on_own_device
-    def __init__(self, engine, B, T, tau, src_rows=1, tgt_rows=1):
+    def __init__(self, engine, B, T, tau, src_rows=1, tgt_rows=1, skip_padding=False):
         dev = engine.device
         self.engine, self.B, self.T, self.tau = engine, int(B), int(T), float(tau)
         f = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
@@ -703,7 +743,7 @@ class GraphedConversion:
         self.g_src, self.g_tgt = f(src_rows, engine.gin, 1), f(tgt_rows, engine.gin, 1)
         self.noise = f(B, engine.inter, T)
         run = lambda: engine.voice_conversion(self.spec, self.lengths, self.g_src, self.g_tgt, tau=self.tau,
-                                              noise=self.noise)
+                                              noise=self.noise, skip_padding=skip_padding)
         saved, engine.profile = engine.profile, None       # event records are not capturable
         try:
             side = torch.cuda.Stream(dev)                      # torch's rule: warm up off the default stream

@@ -95,25 +95,27 @@ class SynthesizerTrn(nn.Module):
             self._engine_key = key
         return self._engine
 
-    def voice_conversion(self, y, y_lengths, sid_src, sid_tgt, tau=1.0, noise=None, graph=False):
+    def voice_conversion(self, y, y_lengths, sid_src, sid_tgt, tau=1.0, noise=None, graph=False, skip_padding=False):
         """reference: openvoice/models.py:492-499; ``noise`` is the explicit form of the
         reference's ``randn_like`` draw (optional).  ``graph=True`` replays the launch sequence of this
         (B, T, tau) shape from a captured HIP graph (``engine.GraphedConversion``); the returned tensors are
-        then static buffers, valid until the next graphed call of the same shape."""
+        then static buffers, valid until the next graphed call of the same shape.  ``skip_padding=True`` (ragged
+        batches): the generator computes only ``length + 16`` frames per utterance -- valid samples bit-identical,
+        the padded tail of ``o_hat`` zero (``ConverterEngine.voice_conversion``)."""
         eng = self.engine()
         if self.n_speakers != 0:
             eng = eng.core      # a TTS checkpoint also carries enc_q / flow / dec
         if graph:
-            g = eng.graphed(y.shape[0], y.shape[2], tau, sid_src.shape[0], sid_tgt.shape[0])
+            g = eng.graphed(y.shape[0], y.shape[2], tau, sid_src.shape[0], sid_tgt.shape[0], skip_padding=skip_padding)
             return g(y, y_lengths, sid_src, sid_tgt, noise=noise)
-        return eng.voice_conversion(y, y_lengths, sid_src, sid_tgt, tau=tau, noise=noise)
+        return eng.voice_conversion(y, y_lengths, sid_src, sid_tgt, tau=tau, noise=noise, skip_padding=skip_padding)
 
     def infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1., sdp_ratio=0.2,
-              max_len=None, noise_w=None, noise_z=None):
+              max_len=None, noise_w=None, noise_z=None, skip_padding=False):
         """reference: openvoice/models.py:467-490; ``noise_w`` / ``noise_z`` are the explicit forms of the
         reference's two RNG draws (optional).  Returns ``(o, attn, y_mask, (z, z_p, m_p, logs_p))``."""
         if self.n_speakers == 0:
             raise RuntimeError("infer() needs the TTS model (n_speakers > 0); this is the converter variant")
         return self.engine().infer(x, x_lengths, sid, noise_scale=noise_scale, length_scale=length_scale,
                                    noise_scale_w=noise_scale_w, sdp_ratio=sdp_ratio, max_len=max_len,
-                                   noise_w=noise_w, noise_z=noise_z)
+                                   noise_w=noise_w, noise_z=noise_z, skip_padding=skip_padding)

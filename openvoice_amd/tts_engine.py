@@ -131,10 +131,12 @@ class TtsEngine:
     @torch.no_grad()
     @on_own_device
     def infer(self, tokens, lengths, sid, noise_scale=1.0, length_scale=1.0, noise_scale_w=1.0, sdp_ratio=0.2,
-              max_len=None, noise_w=None, noise_z=None, return_attn=True):
+              max_len=None, noise_w=None, noise_z=None, return_attn=True, skip_padding=False):
         """Same contract as the reference (models.py:467-490): returns
         ``(o [B,1,256*Ty'], attn [B,1,Ty,Tx], y_mask [B,1,Ty], (z, z_p, m_p, logs_p) [B,192,Ty])``.
-        ``noise_w`` [B,2,Tx] / ``noise_z`` [B,192,>=Ty] replace the reference's two RNG draws when given."""
+        ``noise_w`` [B,2,Tx] / ``noise_z`` [B,192,>=Ty] replace the reference's two RNG draws when given.
+        ``skip_padding``: the generator computes only ``y_length + 16`` frames of each utterance of a padded batch
+        (valid samples bit-identical, the padded tail of ``o`` zero; ``ConverterEngine.voice_conversion``)."""
         dev = self.device
         tokens = tokens.to(dev, torch.int64).contiguous()
         lengths = lengths.to(dev, torch.int64).contiguous()
@@ -220,7 +222,7 @@ class TtsEngine:
         core._flow(z_p, z, ws, B, Ty, cond_flow, mask_y, reverse=True)      # z_p -> z, no copy
         cond_d = core._linear(g, core.dec_cond_w, core.dec_cond_b)
         Td = Ty if max_len is None else min(Ty, int(max_len))
-        o = core.decode(z, cond_d, ws, T=Td)
+        o = core.decode(z, cond_d, ws, T=Td, limits=core.frame_limits(y_len, Td) if skip_padding else None)
         outs = tuple(t[:, :, :Ty].contiguous() for t in (z, z_p, m_p, logs_p))
         self.last_logw = logw[:, :Tx]
         return (o, attn.unsqueeze(1) if attn is not None else None, mask_y[:, :Ty].unsqueeze(1).contiguous(), outs)
