@@ -22,6 +22,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle on one utterance")
+    ap.add_argument("--full-padding", action="store_true",
+                    help="compute the generator on the whole padded batch, as the reference does (round-2 figure); "
+                         "default: length-aware work lists (infer(skip_padding=True): length + 16 frames per "
+                         "utterance, valid samples bit-identical -- tests/test_gpu_limits.py)")
     args = ap.parse_args()
     from openvoice_amd.models import SynthesizerTrn
     from openvoice_amd.params import synthetic_tts_state_dict
@@ -39,18 +43,21 @@ def main():
     noise_w = torch.randn(B, 2, Tx, generator=gen).to(dev)
     noise_z = torch.randn(B, 192, 16 * Tx, generator=gen).to(dev)
 
-    def step():
-        return model.infer(tokens, lengths, sid=sid, noise_scale=0.667, noise_scale_w=0.6, length_scale=1.0,
-                           noise_w=noise_w, noise_z=noise_z)
+    def timed(skip):
+        def step():
+            return model.infer(tokens, lengths, sid=sid, noise_scale=0.667, noise_scale_w=0.6, length_scale=1.0,
+                               noise_w=noise_w, noise_z=noise_z, skip_padding=skip)
+        for _ in range(args.warmup):
+            o, _, y_mask, _ = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            o, _, y_mask, _ = step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / args.steps, o, y_mask
 
-    for _ in range(args.warmup):
-        o, _, y_mask, _ = step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        o, _, y_mask, _ = step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
+    dt_full, o_full, y_mask = timed(False)
+    dt, o, y_mask = (dt_full, o_full, y_mask) if args.full_padding else timed(True)
     frames = int(y_mask.sum())
     audio_s = frames * 256 / 22050.0
     # Algorithmic FLOPs (2 x MACs of the convs; SURVEY.md section 8d's per-frame hand count): the generator and the
@@ -58,17 +65,30 @@ def main():
     # token rate (enc_p 4.4, sdp 0.33, dp 0.21 GFLOP per ~100-symbol utterance).
     Ty = int(y_mask.shape[2])
     per_frame = 614.8e6 + 4 * 3.54e6            # generator + 4 coupling layers (one flow direction)
-    flops = per_frame * B * Ty + (4.4e9 + 0.33e9 + 0.21e9) * B * Tx / 100.0
-    out = {"workload": f"SynthesizerTrn.infer, batch {B} x {Tx} symbols, fp32, synthetic weights",
+    token_rate = (4.4e9 + 0.33e9 + 0.21e9) * B * Tx / 100.0
+    flops_padded = per_frame * B * Ty + token_rate
+    # with length-aware work lists the generator computes min(Ty, length + 16) frames per utterance (flow: all)
+    per_utt = y_mask[:, 0].sum(1)
+    gen_frames = float(torch.clamp(per_utt + 16, max=Ty).sum()) if not args.full_padding else float(B * Ty)
+    flops = 614.8e6 * gen_frames + 4 * 3.54e6 * B * Ty + token_rate
+    valid_equal = None
+    if not args.full_padding:
+        valid_equal = all(torch.equal(o[b, :, :256 * int(n)], o_full[b, :, :256 * int(n)]) for b, n in enumerate(per_utt))
+    out = {"workload": f"SynthesizerTrn.infer, batch {B} x {Tx} symbols, fp32, synthetic weights"
+                       + ("" if args.full_padding else ", length-aware generator work lists (skip_padding)"),
            "ms_per_batch": round(dt * 1e3, 3), "utterances_per_s": round(B / dt, 2),
+           "ms_per_batch_full_padding": round(dt_full * 1e3, 3),
+           "valid_samples_bit_identical_to_full_padding": valid_equal,
+           "generator_frames_computed": int(gen_frames), "generator_frames_padded_batch": B * Ty,
            "audio_s_per_batch": round(audio_s, 2), "real_time_factor": round(audio_s / dt, 1),
            "frames_per_utterance": round(frames / B, 1), "padded_frames": Ty,
            "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
                         "frac": round(flops / dt / 157.3e12, 4), "alg_tflop_per_batch": round(flops / 1e12, 3),
+                        "alg_tflop_per_padded_batch": round(flops_padded / 1e12, 3),
                         "note": "whole infer() incl. its host sync (Ty = y_lengths.max(), as in the reference, "
-                                "models.py:478-480) and the token-rate kernels; FLOPs counted on the PADDED batch "
-                                "(B x max frames), which is what the unmasked generator computes, here and in the "
-                                "reference.  Per kernel group: profiles/r02_tts_kernel_trace_analysis.txt"}}
+                                "models.py:478-480) and the token-rate kernels; FLOPs counted on the frames the "
+                                "generator actually computes (length + 16 per utterance with skip_padding; the "
+                                "whole padded batch with --full-padding, as the reference's unmasked generator)"}}
     if args.cpu:
         from oracle import tts_oracle
         from openvoice_amd.hostinfo import usable_cpus
