@@ -175,6 +175,12 @@ typedef struct ov_respair_params {
   float scale;
   unsigned long long* dbg; /* measurement only, NULL in production: [workgroups][4 waves][8] shader-clock ticks per
                           * phase (residual issue, chunk wait, c1, h store, h barrier, c2, epilogue, tail) */
+  const int32_t* col_limit; /* length-aware work list, as ov_conv1d_params.col_limit: utterance b is walked only up
+                          * to column col_limit[b] * col_limit_scale (steps beyond are neither computed nor written;
+                          * what is computed is bit-identical to the full launch); NULL = whole tensor; DEVICE int32 [B],
+                          * B <= 256 */
+  int32_t col_limit_scale;
+  int32_t reserved0;
 } ov_respair_params;
 int ov_resblock_pair_f32(const ov_respair_params* p, ov_stream_t stream);
 /* 1 when (C, K, dil) has a fused instance, else 0 (callers then issue the two ov_conv1d_f32 launches). */

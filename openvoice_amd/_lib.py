@@ -69,7 +69,8 @@ class RespairParams(ctypes.Structure):
                 ("x_bstride", ctypes.c_int64), ("out_bstride", ctypes.c_int64), ("add_bstride", ctypes.c_int64),
                 ("B", ctypes.c_int32), ("C", ctypes.c_int32), ("L", ctypes.c_int32), ("ld", ctypes.c_int32),
                 ("K", ctypes.c_int32), ("dil", ctypes.c_int32), ("nwg", ctypes.c_int32),
-                ("slope", ctypes.c_float), ("scale", ctypes.c_float), ("dbg", _fp)]
+                ("slope", ctypes.c_float), ("scale", ctypes.c_float), ("dbg", _fp),
+                ("col_limit", _fp), ("col_limit_scale", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
 
 
 class RespairBf16Params(ctypes.Structure):

@@ -41,10 +41,27 @@ struct PairSeq {
   long left;      // real steps left, including the current one
   int b, i, nsteps;
   bool warm;
-  __device__ __forceinline__ PairSeq(long g0, long g1, int nsteps_)
-      : left(g1 - g0), b((int)(g0 / nsteps_)), i((int)(g0 - (long)(g0 / nsteps_) * nsteps_)), nsteps(nsteps_),
-        warm(false) {
-    warm = left > 0 && i != 0;
+  const int* pref;   // length-aware list: LDS prefix table of the utterances' step counts (else NULL: nsteps each)
+  __device__ __forceinline__ int count(int u) const {
+    return __builtin_amdgcn_readfirstlane(pref[u + 1]) - __builtin_amdgcn_readfirstlane(pref[u]);
+  }
+  __device__ __forceinline__ PairSeq(long g0, long g1, int nsteps_, const int* pref_, int B)
+      : left(g1 - g0), b(0), i(0), nsteps(nsteps_), warm(false), pref(pref_) {
+    if (left <= 0) return;
+    if (!pref) {
+      b = (int)(g0 / nsteps_);
+      i = (int)(g0 - (long)b * nsteps_);
+    } else {
+      int lo = 0, hi = B;                     // pref[lo] <= g0 < pref[hi]
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (__builtin_amdgcn_readfirstlane(pref[mid]) <= (int)g0) lo = mid; else hi = mid;
+      }
+      b = lo;
+      i = (int)g0 - __builtin_amdgcn_readfirstlane(pref[lo]);
+      nsteps = count(lo);
+    }
+    warm = i != 0;
   }
   __device__ __forceinline__ bool valid() const { return left > 0; }
   __device__ __forceinline__ int batch() const { return b; }
@@ -53,7 +70,13 @@ struct PairSeq {
   __device__ __forceinline__ void advance() {
     if (warm) { warm = false; return; }
     --left;
-    if (++i == nsteps) { i = 0; ++b; }
+    if (++i == nsteps) {
+      i = 0;
+      ++b;
+      if (pref && left > 0) {                 // utterances whose limit is 0 have no steps at all
+        while ((nsteps = count(b)) == 0) ++b;
+      }
+    }
   }
 };
 
@@ -88,10 +111,42 @@ __global__ __launch_bounds__(64 * (4 + NLD), 4) void respair_mfma_kernel(const o
   const int L = p.L;
   const uint32_t ld = (uint32_t)p.ld;
   const int nsteps = (L + P2 + NT - 1) / NT;
-  const long S = (long)p.B * nsteps;
+  long S = (long)p.B * nsteps;
+  // Length-aware work list (ov_respair_params.col_limit): utterance b walks only the steps that produce columns before
+  // its limit -- ceil((limit + P2) / NT) of them, none when the limit is 0; the prefix sums of the step counts (<= 256
+  // utterances) are built once per workgroup and the flattened list stays dense.
+  __shared__ int lim_pref[LIMIT_MAX_BATCH + 1];
+  const int* pref = nullptr;
+  if (p.col_limit != nullptr) {
+    if (wave == 0) {
+      int carry = 0;
+      for (int base = 0; base < p.B; base += 64) {
+        const int bb = base + lane;
+        int n = 0;
+        if (bb < p.B) {
+          long long c = (long long)p.col_limit[bb] * p.col_limit_scale;
+          c = c < 0 ? 0 : (c > L ? L : c);
+          n = c > 0 ? ((int)c + P2 + NT - 1) / NT : 0;
+        }
+        int sc = n;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int v = __shfl_up(sc, d, 64);
+          if (lane >= d) sc += v;
+        }
+        if (bb < p.B) lim_pref[bb + 1] = carry + sc;
+        carry += __shfl(sc, 63, 64);
+      }
+      if (lane == 0) lim_pref[0] = 0;
+    }
+    __syncthreads();
+    pref = lim_pref;
+    S = __builtin_amdgcn_readfirstlane(lim_pref[p.B]);
+  }
   const long g0 = S * blockIdx.x / gridDim.x, g1 = S * (blockIdx.x + 1) / gridDim.x;
   if (g0 >= g1) return;
-  const long npseudo = (g1 - g0) + ((g0 % nsteps) != 0 ? 1 : 0);
+  const PairSeq first(g0, g1, nsteps, pref, p.B);
+  const long npseudo = (g1 - g0) + (first.warm ? 1 : 0);
 
   bool is_loader = false;
 #pragma unroll
@@ -102,7 +157,7 @@ __global__ __launch_bounds__(64 * (4 + NLD), 4) void respair_mfma_kernel(const o
     const float slope = p.slope;
     const int llane = (wave - 4) * 64 + lane;
     const long total = npseudo * NCH;
-    PairSeq st(g0, g1, nsteps);
+    PairSeq st = first;
     int st_chunk = 0;
     long staged = 0, begun = 0;
     auto stage_one = [&]() {
@@ -240,7 +295,7 @@ __global__ __launch_bounds__(64 * (4 + NLD), 4) void respair_mfma_kernel(const o
   };
   if (dbg) tlast = __builtin_readcyclecounter();
   long it = 0;
-  for (PairSeq tk(g0, g1, nsteps); tk.valid();) {
+  for (PairSeq tk = first; tk.valid();) {
     const int b = tk.batch();
     const bool warm = tk.warm;
     const int t0 = tk.tile() * NT;

@@ -46,6 +46,8 @@ int ov_resblock_pair_f32(const ov_respair_params* pin, ov_stream_t stream) {
   if ((q.ld % 4) || (q.x_bstride % 4) || (reinterpret_cast<uintptr_t>(q.x) & 15) ||
       (reinterpret_cast<uintptr_t>(q.w1) & 15) || (reinterpret_cast<uintptr_t>(q.w2) & 15))
     return OV_E_ALIGN;
+  if (q.col_limit && (q.col_limit_scale <= 0 || q.B > LIMIT_MAX_BATCH || (reinterpret_cast<uintptr_t>(q.col_limit) & 3)))
+    return OV_E_BADARG;
   pair_launch_fn fn = find_pair(q.C, q.K, q.dil);
   if (!fn) return OV_E_UNSUPPORTED;
   return fn(&q, static_cast<hipStream_t>(stream));

@@ -229,20 +229,21 @@ void conv1d_f32(const OptTensor& x, const OptTensor& w, const OptTensor& bias, c
   finish(ov_conv1d_f32(&p, c.stream()), "ov_conv1d_f32");
 }
 
-// ip = [B, C, L, ld, K, dil, nwg, x_bstride, out_bstride, add_bstride];  fp = [slope, scale]
+// ip = [B, C, L, ld, K, dil, nwg, x_bstride, out_bstride, add_bstride, col_limit_scale];  fp = [slope, scale]
 void resblock_pair_f32(const OptTensor& x, const OptTensor& w1, const OptTensor& b1, const OptTensor& w2,
                        const OptTensor& b2, const OptTensor& out, const OptTensor& add, const OptTensor& dbg,
-                       at::IntArrayRef ip, at::ArrayRef<double> fp) {
-  TORCH_CHECK(ip.size() == 10 && fp.size() == 2, "openvoice_amd::resblock_pair_f32: 10 integer and 2 float parameters");
+                       const OptTensor& col_limit, at::IntArrayRef ip, at::ArrayRef<double> fp) {
+  TORCH_CHECK(ip.size() == 11 && fp.size() == 2, "openvoice_amd::resblock_pair_f32: 11 integer and 2 float parameters");
   Ctx c{"resblock_pair_f32", false};
   ov_respair_params p{};
   p.x = sptr<float>(x, c, 0); p.w1 = sptr<float>(w1, c, 1); p.b1 = sptr<float>(b1, c, 2);
   p.w2 = sptr<float>(w2, c, 3); p.b2 = sptr<float>(b2, c, 4); p.out = sptr<float>(out, c, 5);
   p.add = sptr<float>(add, c, 6);
   p.dbg = sptr<unsigned long long>(dbg, c, 7);
+  p.col_limit = sptr<int32_t>(col_limit, c, 8);
   p.B = (int32_t)ip[0]; p.C = (int32_t)ip[1]; p.L = (int32_t)ip[2]; p.ld = (int32_t)ip[3]; p.K = (int32_t)ip[4];
   p.dil = (int32_t)ip[5]; p.nwg = (int32_t)ip[6];
-  p.x_bstride = ip[7]; p.out_bstride = ip[8]; p.add_bstride = ip[9];
+  p.x_bstride = ip[7]; p.out_bstride = ip[8]; p.add_bstride = ip[9]; p.col_limit_scale = (int32_t)ip[10];
   p.slope = (float)fp[0]; p.scale = (float)fp[1];
   finish(ov_resblock_pair_f32(&p, c.stream()), "ov_resblock_pair_f32");
 }
@@ -304,7 +305,7 @@ TORCH_LIBRARY(openvoice_amd, m) {
   m.def("conv1d_f32(Tensor? x, Tensor? w, Tensor? bias, Tensor(a!)? out, Tensor? res, Tensor? add, Tensor(b!)? out2, "
         "Tensor? mask, Tensor? bias_b, Tensor? col_limit, int[] ip, float[] fp) -> ()", &conv1d_f32);
   m.def("resblock_pair_f32(Tensor? x, Tensor? w1, Tensor? b1, Tensor? w2, Tensor? b2, Tensor(a!)? out, Tensor? add, "
-        "Tensor(b!)? dbg, int[] ip, float[] fp) -> ()", &resblock_pair_f32);
+        "Tensor(b!)? dbg, Tensor? col_limit, int[] ip, float[] fp) -> ()", &resblock_pair_f32);
   m.def("wn_layer_f32(Tensor? x, Tensor(a!)? out, Tensor(b!)? skip, Tensor? w_in, Tensor? b_in, Tensor? cond, Tensor? w_rs, "
         "Tensor? b_rs, Tensor? mask, Tensor(c!)? dbg, int[] ip) -> ()", &wn_layer_f32);
   m.def("conv1d_bf16cl(Tensor? x, Tensor? w, Tensor? bias, Tensor(a!)? out, Tensor? res, Tensor? add, Tensor(b!)? dbg, "

@@ -182,12 +182,12 @@ def launch_conv(layer, x, x_off, x_bs, out, out_off, out_bs, B, L, epi=EPI_LINEA
 
 
 def launch_pair(c1, c2, x, x_bs, out, out_bs, B, L, add=None, add_bs=0, scale=1.0, slope=LRELU_SLOPE, ld=0, nwg=0,
-                dbg=None):
+                dbg=None, col_limit=None, col_limit_scale=1):
     """One fused ResBlock1 iteration (``ov_resblock_pair_f32``): out = (c2(lrelu(c1(lrelu(x)))) + x [+ add]) * scale.
     ``c1`` / ``c2`` are the ``PackedConv`` layers of the two convs; ``out`` must not alias ``x``."""
     if _lib.use_torch_binding():
-        _lib.torch_op("resblock_pair_f32", x, c1.w, c1.bias, c2.w, c2.bias, out, add, dbg,
-                      [B, c1.cin, L, ld, c1.K, c1.dil, nwg, x_bs, out_bs, add_bs], [slope, scale])
+        _lib.torch_op("resblock_pair_f32", x, c1.w, c1.bias, c2.w, c2.bias, out, add, dbg, col_limit,
+                      [B, c1.cin, L, ld, c1.K, c1.dil, nwg, x_bs, out_bs, add_bs, col_limit_scale], [slope, scale])
         return
     p = _lib.RespairParams()
     p.x, p.w1, p.b1, p.w2, p.b2 = _ptr(x), _ptr(c1.w), _ptr(c1.bias), _ptr(c2.w), _ptr(c2.bias)
@@ -197,6 +197,8 @@ def launch_pair(c1, c2, x, x_bs, out, out_bs, B, L, add=None, add_bs=0, scale=1.
     p.B, p.C, p.L, p.ld, p.K, p.dil, p.nwg = B, c1.cin, L, ld, c1.K, c1.dil, nwg
     p.slope, p.scale = slope, scale
     p.dbg = ctypes.c_void_p(dbg.data_ptr()) if dbg is not None else None
+    p.col_limit = ctypes.c_void_p(col_limit.data_ptr()) if col_limit is not None else None
+    p.col_limit_scale = col_limit_scale
     stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(_lib.load().ov_resblock_pair_f32(ctypes.byref(p), stream), "ov_resblock_pair_f32")
 
@@ -416,15 +418,15 @@ class ConverterEngine:
             alg_flops = 2.0 * layer.rows * (kwargs.get("cin") or layer.cin) * layer.K * L * B
         self.profile.append((tag, alg_flops, e0, e1))
 
-    def _pair(self, c1, c2, x, out, bs, B, L, add, scale):
+    def _pair(self, c1, c2, x, out, bs, B, L, add, scale, **lim):
         """One fused ResBlock1 iteration; profiled under the same tag as the two launches it replaces, with their
         algorithmic FLOPs (both convs)."""
         if self.profile is None:
-            launch_pair(c1, c2, x, bs, out, bs, B, L, add=add, add_bs=bs, scale=scale)
+            launch_pair(c1, c2, x, bs, out, bs, B, L, add=add, add_bs=bs, scale=scale, **lim)
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        launch_pair(c1, c2, x, bs, out, bs, B, L, add=add, add_bs=bs, scale=scale)
+        launch_pair(c1, c2, x, bs, out, bs, B, L, add=add, add_bs=bs, scale=scale, **lim)
         e1.record()
         self.profile.append(("mrf", 2 * 2.0 * c1.rows * c1.cin * c1.K * L * B, e0, e1))
 
@@ -662,9 +664,7 @@ class ConverterEngine:
             # MRF: mean of the 3 ResBlock1 outputs (models.py:280-286, modules.py:296-306)
             for j, pairs in enumerate(self.resblocks[i]):
                 cur = u
-                # (the fused-pair kernel walks whole utterances: with a length-aware work list the pair is two launches,
-                # bit-identical by construction)
-                fused = self.fuse_pairs and limits is None and L % 4 == 0 and all(
+                fused = self.fuse_pairs and L % 4 == 0 and all(
                     (ch, c1.K) in PAIR_POLICY and pair_supported(ch, c1.K, c1.dil) for c1, _ in pairs)
                 for n, (c1, c2) in enumerate(pairs):
                     last = n == len(pairs) - 1
@@ -673,7 +673,7 @@ class ConverterEngine:
                     if fused:
                         # one launch per pair, intermediate in LDS; out must not alias x: ra / t1 ping-pong
                         dst = acc if last else (t1 if cur is ra else ra)
-                        self._pair(c1, c2, cur, dst, bs, B, L, add, scale)
+                        self._pair(c1, c2, cur, dst, bs, B, L, add, scale, **lim(rate))
                     else:
                         self._conv(c1, cur, 0, bs, t1, 0, bs, B, L, in_slope=LRELU_SLOPE, tag="mrf", **lim(rate))
                         dst = acc if last else ra

@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from openvoice_amd import _lib  # noqa: E402
-from openvoice_amd.engine import GENERATOR_MARGIN, PackedConv, launch_conv  # noqa: E402
+from openvoice_amd.engine import GENERATOR_MARGIN, PackedConv, launch_conv, launch_pair  # noqa: E402
 from openvoice_amd.models import SynthesizerTrn  # noqa: E402
 from openvoice_amd.utils import CONVERTER_MODEL_CONFIG  # noqa: E402
 
@@ -53,6 +53,35 @@ def test_limited_conv_computes_the_same_bits_and_skips_the_rest(c, k, d, L, tpw,
         computed = min(L, -(-lim // tile_cols) * tile_cols)           # whole tiles that start before the limit
         assert torch.equal(out[b, :, :computed], full[b, :, :computed]), f"utterance {b}: computed columns differ"
         assert torch.isnan(out[b, :, computed:]).all(), f"utterance {b}: columns beyond tile {computed} were written"
+
+
+@pytest.mark.parametrize("c,k,d,L,nwg,nt", [(32, 3, 1, 9000, 0, 256), (32, 7, 5, 5000, 7, 256), (64, 3, 3, 3000, 0, 128),
+                                              (32, 11, 3, 2600, 3, 256), (64, 3, 1, 1000, 100000, 128)])
+def test_limited_fused_pair_computes_the_same_bits_and_skips_the_rest(c, k, d, L, nwg, nt):
+    """The fused ResBlock pair (sliding window along time) with per-utterance limits: utterance b is walked for
+    ceil((limit + P2) / NT) steps -- none at limit 0 -- so the columns [0, steps * NT - P2) equal the full launch bit for
+    bit and nothing beyond is written; runs that start mid-utterance and span utterances of different step counts
+    (forced workgroup counts), with the MRF addend."""
+    B, p2 = 6, (k - 1) // 2
+    gen_w = lambda seed, scale: _rand(c, c, k, seed=seed, scale=scale * (c * k) ** -0.5)
+    c1 = PackedConv(gen_w(3, 1.0), _rand(c, seed=4, scale=0.1), DEV, K=k, dil=d)
+    c2 = PackedConv(gen_w(5, 0.5), _rand(c, seed=6, scale=0.1), DEV, K=k, dil=1)
+    x, add = _rand(B, c, L, seed=1).to(DEV), _rand(B, c, L, seed=2).to(DEV)
+    full = torch.full((B, c, L), float("nan"), device=DEV)
+    launch_pair(c1, c2, x, c * L, full, c * L, B, L, add=add, add_bs=c * L, scale=0.5, nwg=nwg)
+    cols = [0, 1, L // 3 + 7, 2 * nt, L + 10, L // 2]
+    limits = torch.tensor(cols, dtype=torch.int32, device=DEV)
+    out = torch.full((B, c, L), float("nan"), device=DEV)
+    launch_pair(c1, c2, x, c * L, out, c * L, B, L, add=add, add_bs=c * L, scale=0.5, nwg=nwg, col_limit=limits,
+                col_limit_scale=1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(full).all()
+    for b, lim in enumerate(min(n, L) for n in cols):
+        steps = -(-(lim + p2) // nt) if lim > 0 else 0
+        computed = max(0, min(L, steps * nt - p2))
+        assert computed >= lim
+        assert torch.equal(out[b, :, :computed], full[b, :, :computed]), f"utterance {b}: computed columns differ"
+        assert torch.isnan(out[b, :, computed:]).all(), f"utterance {b}: columns beyond {computed} were written"
 
 
 def test_limit_argument_checks():
