@@ -528,7 +528,7 @@ class ConverterEngine:
         the reference, so a padded batch costs as if every utterance had the longest length -- computes only the
         first ``length + GENERATOR_MARGIN`` frames of each utterance (length-aware work lists,
         ``ov_conv1d_params.col_limit``); every sample of the first ``length`` frames is bit-identical to the full
-        computation, the rest of ``o_hat`` is zero instead of the reference's bias-driven junk."""
+        computation, and everything beyond them in ``o_hat`` is zero instead of the reference's bias-driven junk."""
         dev = self.device
         spec = spec.to(dev, torch.float32)
         B, F, T = spec.shape
@@ -618,12 +618,16 @@ class ConverterEngine:
         return self
 
     def frame_limits(self, lengths, T):
-        """int32 [B] on the device: frames of each utterance the generator must produce so that the first ``lengths[b]``
-        frames are unaffected by what lies beyond (``ov_frame_limits_i32``); no host sync."""
+        """Two int32 [B] device vectors (``ov_frame_limits_i32``, no host sync): the frames of each utterance the
+        generator must COMPUTE so that its first ``lengths[b]`` frames are unaffected by what lies beyond
+        (``length + GENERATOR_MARGIN``), and the frames it KEEPS (``length``): ``conv_post`` writes zeros beyond them, so
+        the whole of ``o_hat`` is defined -- what lies between the two is computed from neighbours that were skipped
+        and must not leak into the result."""
         B = lengths.shape[0]
-        limits = torch.empty(B, dtype=torch.int32, device=self.device)
-        _lib.call("ov_frame_limits_i32", lengths, limits, B, int(T), GENERATOR_MARGIN)
-        return limits
+        lim = torch.empty(2, B, dtype=torch.int32, device=self.device)
+        _lib.call("ov_frame_limits_i32", lengths, lim[0], B, int(T), GENERATOR_MARGIN)
+        _lib.call("ov_frame_limits_i32", lengths, lim[1], B, int(T), 0)
+        return lim
 
     def decode(self, z_hat, cond_d, ws=None, T=None, limits=None):
         """Generator (models.py:272-291).  ``z_hat`` is [B, C, ld] with ``T`` valid frames per row
@@ -638,6 +642,9 @@ class ConverterEngine:
         ch = cfg["upsample_initial_channel"]
         if limits is not None and B > LIMIT_MAX_BATCH:
             limits = None                       # the kernels' prefix table holds 256 utterances: whole tensors beyond
+        keep = None
+        if limits is not None:
+            limits, keep = limits[0], limits[1]
         lim = lambda scale: dict(col_limit=limits, col_limit_scale=scale) if limits is not None else {}
         self._conv(self.conv_pre, z_hat, 0, C * ld, ws["pre"], 0, ch * Tp, B, T, bias_b=cond_d,
                    bias_b_bs=0 if cond_d.shape[0] == 1 else cond_d.shape[1], x_ld=ld, out_ld=Tp, tag="conv_pre",
@@ -685,7 +692,7 @@ class ConverterEngine:
         o_hat = torch.empty(B, 1, L, dtype=torch.float32, device=self.device)
         if limits is not None:
             _lib.call("ov_conv_post_tanh_limited_f32", x, self.post_w, o_hat, B, ch, L, self.post_w.shape[1],
-                      FINAL_LRELU_SLOPE, limits, rate)
+                      FINAL_LRELU_SLOPE, keep, rate)
         else:
             _lib.call("ov_conv_post_tanh_f32", x, self.post_w, o_hat, B, ch, L, self.post_w.shape[1], FINAL_LRELU_SLOPE)
         return o_hat

@@ -143,7 +143,7 @@ def test_respair_params_struct_matches_header_field_order_and_size():
         names += [r.strip() for r in rest]
     assert names == [f[0] for f in _lib.RespairParams._fields_]
     import ctypes
-    assert ctypes.sizeof(_lib.RespairParams) == 128          # 7 pointers, 3 int64, 7 int32, 2 float, pad, 1 pointer
+    assert ctypes.sizeof(_lib.RespairParams) == 144          # 7 pointers, 3 int64, 7 int32, 2 float, pad, 2 pointers, 2 int32
     lib = _lib.load()
     assert lib.ov_resblock_pair_f32(None, None) == -1
     assert lib.ov_resblock_pair_supported(32, 3, 1) == 1 and lib.ov_resblock_pair_supported(128, 3, 1) == 0
