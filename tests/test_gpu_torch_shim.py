@@ -61,8 +61,8 @@ def test_errors_are_runtime_errors(monkeypatch):
     x = torch.zeros(1, 32, 66, device=DEV)        # rows not 16-byte aligned: OV_E_ALIGN from the library
     w = torch.zeros(8192, device=DEV)
     with pytest.raises(RuntimeError, match="ov_resblock_pair_f32 failed"):
-        ops.resblock_pair_f32(x, w, w, w, w, torch.zeros_like(x), None, None, [1, 32, 66, 66, 3, 1, 0, 32 * 66, 32 * 66, 0],
-                              [0.1, 1.0])
+        ops.resblock_pair_f32(x, w, w, w, w, torch.zeros_like(x), None, None, None,
+                              [1, 32, 66, 66, 3, 1, 0, 32 * 66, 32 * 66, 0, 1], [0.1, 1.0])
     # through the package's call layer both bindings raise the same exception type
     monkeypatch.setenv("OPENVOICE_AMD_BINDING", "torch")
     with pytest.raises(_lib.OvError, match="OV_E_BADARG"):
