@@ -3,13 +3,14 @@
 // GEMM view of y[b][co][t] = sum_{ci,j} W[co][ci][j] * act(x[b][ci][t + j*DIL - PAD]):
 //   M = output rows (co), N = time, K_gemm = (ci, tap).
 //
-// One workgroup = 5 wave64: four MATRIX waves (one per SIMD) that own an M_BLK x N_BLK output tile
-// of one utterance, and one LOADER wave.  Input channels are walked in chunks of CHUNK rows; the
-// loader brings chunk c+1 -- rows with their (K-1)*DIL receptive-field halo, leaky-ReLU applied on
-// the way in, zero-filled outside [0, L) -- from HBM through registers into one half of a
-// double-buffered LDS tile while the matrix waves run the MFMAs of chunk c out of the other half;
-// one s_barrier per chunk hands a buffer over.  Every tap of every MFMA B operand is then a
-// conflict-free ds_read_b32 at a compile-time offset.
+// One workgroup = four MATRIX waves (one per SIMD) that own an M_BLK x N_BLK output tile of one utterance + NLD
+// LOADER waves (4 on every shipped instance: one per SIMD, so the four matrix waves -- which re-synchronise at every
+// chunk barrier -- all share their SIMD with the same company; 8 wave64 in all).  Input channels are walked in
+// chunks of CHUNK rows; the loaders bring chunk c+1 -- rows with their (K-1)*DIL receptive-field halo, leaky-ReLU
+// applied on the way in, zero-filled outside [0, L), the staging items dealt round-robin over the loader lanes so a
+// whole chunk is in flight at once -- from HBM through registers into one half of a double-buffered LDS tile while
+// the matrix waves run the MFMAs of chunk c out of the other half; one s_barrier per chunk hands a buffer over.
+// Every tap of every MFMA B operand is then a conflict-free ds_read_b32 at a compile-time offset.
 //
 // Why a separate loader wave: the A operand (weights) never touches LDS -- weights are pre-packed at
 // load time into MFMA fragment order, so a wave fetches the fragments of 4 consecutive k-steps with
@@ -20,8 +21,9 @@
 // pipe on the k=3 convs.  With the roles split, the matrix waves' vmcnt queue holds weight
 // fragments only.
 //
-// Workgroups are persistent: the launch puts as many workgroups on the chip as fit at once and each walks
-// the flattened (utterance, M-block, time-tile) list with the grid as stride.  The loaders run one chunk
+// Large launches are persistent: the launch puts as many workgroups on the chip as fit at once and each walks
+// the flattened (utterance, time-tile, M-block) list -- dense per-utterance tile counts when a length-aware column
+// limit is given (ov_conv1d_params.col_limit) -- in XCD-contiguous ranges.  The loaders run one chunk
 // ahead across tile boundaries and the first weight record of the next tile is requested before the
 // epilogue of the current one, so only the first tile of a workgroup pays the launch / first-round-trip
 // cost (~9 us per workgroup, measured; 20-30 % of a k = 3 tile).
