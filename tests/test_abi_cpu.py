@@ -231,3 +231,22 @@ def test_host_functions_agree_between_the_two_bindings(monkeypatch):
     monkeypatch.setenv("OPENVOICE_AMD_BINDING", "pybind")
     with pytest.raises(_lib.OvError, match="expected 'torch' or 'ctypes'"):
         _lib.binding()
+
+
+def test_header_is_plain_c_and_cxx(tmp_path):
+    """include/openvoice_amd.h is the contract a non-Python host binds: it must compile as C (gcc -std=c99, what cgo /
+    JNI / any FFI generator feeds on) and as C++, with no torch or HIP headers in sight."""
+    import shutil
+    import subprocess
+    header = os.path.join(REPO, "include", "openvoice_amd.h")
+    src = tmp_path / "use.c"
+    src.write_text('#include "openvoice_amd.h"\n'
+                   'int probe(void) { ov_conv1d_params p; ov_respair_params q; ov_wn_layer_params w;\n'
+                   '  p.col_limit = 0; q.col_limit = 0; w.dbg = 0; (void)p; (void)q; (void)w;\n'
+                   '  return (int)sizeof(ov_conv1d_params) + OV_E_ALIGN + OV_EPI_MAGNITUDE; }\n')
+    for cc, std, lang in (("gcc", "-std=c99", "c"), ("g++", "-std=c++11", "c++")):
+        if shutil.which(cc) is None:
+            pytest.skip(f"{cc} not installed")
+        r = subprocess.run([cc, std, "-x", lang, "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only",
+                            "-I", os.path.dirname(header), str(src)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr

@@ -142,3 +142,29 @@ def test_convert_sharded_without_process_group_is_the_plain_call():
     src, tgt = torch.ones(1, 4, 1), torch.zeros(1, 4, 1)
     out = convert_sharded(convert, waves, src, tgt, 4, "cpu")
     assert torch.equal(out, waves.reshape(3, 1, 4) * 4) and calls == [(3, None)]
+
+
+def _more_ranks_than_utterances_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        waves = torch.arange(2 * 6, dtype=torch.float32).reshape(2, 6)
+        src, tgt = torch.full((1, 4, 1), 0.5), torch.zeros(1, 4, 1)
+
+        def convert(shard, s, t, nz):          # an empty shard still has to produce an (empty) tensor of the right width
+            return torch.as_tensor(shard, dtype=torch.float32).reshape(len(shard), 1, 6) * s.sum()
+        full = convert_sharded(convert, waves, src if rank == 0 else None, tgt if rank == 0 else None, 4, "cpu")
+        torch.save(full, os.path.join(out_dir, f"few{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_more_ranks_than_utterances(tmp_path):
+    """3 ranks, 2 utterances: shards of 1, 1 and 0 -- the empty shard takes part in the broadcast and the (padded)
+    all-gather and every rank still receives the whole batch."""
+    world = 3
+    mp.spawn(_more_ranks_than_utterances_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    want = torch.arange(12, dtype=torch.float32).reshape(2, 1, 6) * 2.0
+    for r in range(world):
+        assert torch.equal(torch.load(tmp_path / f"few{r}.pt"), want)
