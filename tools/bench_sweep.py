@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Throughput of the converter path over batch sizes (fixed 10 s utterances, the contract workload at B = 32) and on a
+RAGGED batch with / without the length-aware work lists (skip_padding).  Measurement tool, not the bench.py contract
+line:  python tools/bench_sweep.py [--batches 1 2 4 8 16 32 64] [--steps 5]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batches", type=int, nargs="+", default=[1, 2, 4, 8, 16, 32, 64])
+    ap.add_argument("--steps", type=int, default=5)
+    args = ap.parse_args()
+    from bench import SAMPLE_RATE, synth_wave
+    from openvoice_amd.mel_processing import spectrogram_torch
+    from openvoice_amd.models import SynthesizerTrn
+    from openvoice_amd.params import synthetic_state_dict
+    from openvoice_amd.utils import default_converter_hparams
+    dev = torch.device("cuda:0")
+    hps = default_converter_hparams("v2")
+    cfg = dict(hps.model.items())
+    sd = synthetic_state_dict(cfg, 513, seed=1234)
+    model = SynthesizerTrn(0, 513, n_speakers=0, **cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    gen = torch.Generator().manual_seed(1)
+    se = [(0.1 * torch.randn(1, 256, 1, generator=gen)).to(dev) for _ in range(2)]
+    d = hps.data
+
+    def timeit(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t_end = time.perf_counter() + 0.2            # clocks ramped before timing
+        while time.perf_counter() < t_end:
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / args.steps
+
+    rows = []
+    for B in args.batches:
+        wave = synth_wave(B, 10 * SAMPLE_RATE, 1000 + B, dev)
+
+        def step():
+            spec = spectrogram_torch(wave, d.filter_length, d.sampling_rate, d.hop_length, d.win_length, center=False)
+            lengths = torch.full((B,), spec.shape[2], dtype=torch.int64, device=dev)
+            return model.voice_conversion(spec, lengths, se[0], se[1], tau=0.3)[0]
+        dt = timeit(step)
+        rows.append({"batch": B, "ms_per_batch": round(dt * 1e3, 3), "real_time_factor": round(B * 10.0 / dt, 1),
+                     "utterances_per_s": round(B / dt, 2), "tflops": round(566.24e9 * B / dt / 1e12, 1)})
+        print(json.dumps(rows[-1]), flush=True)
+    # ragged batch: 32 utterances of 3 ... 10 s, padded to the longest as the reference would
+    B = 32
+    gen = torch.Generator().manual_seed(5)
+    secs = 3.0 + 7.0 * torch.rand(B, generator=gen)
+    secs[0] = 10.0
+    wave = synth_wave(B, 10 * SAMPLE_RATE, 77, dev)
+    spec = spectrogram_torch(wave, d.filter_length, d.sampling_rate, d.hop_length, d.win_length, center=False)
+    T = spec.shape[2]
+    lengths = torch.clamp((secs * SAMPLE_RATE / 256).long(), max=T).to(dev)
+    noise = torch.randn(B, 192, T, generator=gen).to(dev)
+    out = {}
+    for skip in (False, True):
+        fn = lambda: model.voice_conversion(spec, lengths, se[0], se[1], tau=0.3, noise=noise, skip_padding=skip)[0]
+        out[skip] = (timeit(fn), fn().clone())
+    same = all(torch.equal(out[True][1][b, :, :256 * int(n)], out[False][1][b, :, :256 * int(n)])
+               for b, n in enumerate(lengths.tolist()))
+    audio_s = float(lengths.sum()) * 256 / SAMPLE_RATE
+    print(json.dumps({"ragged_batch": B, "frames_padded": T, "frames_mean": round(float(lengths.float().mean()), 1),
+                      "ms_full_padding": round(out[False][0] * 1e3, 3), "ms_skip_padding": round(out[True][0] * 1e3, 3),
+                      "real_time_factor_on_real_audio_full": round(audio_s / out[False][0], 1),
+                      "real_time_factor_on_real_audio_skip": round(audio_s / out[True][0], 1),
+                      "valid_samples_bit_identical": same}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
