@@ -165,3 +165,54 @@ def test_tts_infer_skip_padding_keeps_every_valid_sample(synth_tts_sd):
     for b, n in enumerate(frames):
         assert torch.equal(o_skip[b, :, :256 * n], o_full[b, :, :256 * n]), f"utterance {b}"
         assert (o_skip[b, :, 256 * n:] == 0).all()
+
+
+def test_large_batches_at_and_beyond_the_prefix_table(synth_sd):
+    """B = 256 is the most utterances the kernels' per-workgroup prefix table holds; B = 257 must fall back to whole
+    tensors (``skip_padding`` is an optimisation, never a correctness requirement).  Short utterances (T = 40) keep the
+    288 GB card far from full; items are compared with their own batch-1 conversion (utterances are independent)."""
+    T = 40
+    gen = torch.Generator().manual_seed(256)
+    model = _model(synth_sd)
+    g = (0.3 * torch.randn(1, 256, 1, generator=gen)).to(DEV)
+    for B in (256, 257):
+        spec = (torch.rand(B, 513, T, generator=gen) * torch.linspace(3, 0.05, 513)[None, :, None]).to(DEV)
+        lengths = torch.randint(1, T + 1, (B,), generator=gen).to(DEV)
+        lengths[0] = T
+        noise = torch.randn(B, 192, T, generator=gen).to(DEV)
+        o = model.voice_conversion(spec, lengths, g, g, tau=0.3, noise=noise, skip_padding=True)[0]
+        torch.cuda.synchronize()
+        assert torch.isfinite(o).all()
+        for b in (0, 1, B // 2, B - 1):
+            n = int(lengths[b])
+            one = model.voice_conversion(spec[b:b + 1, :, :], lengths[b:b + 1], g, g, tau=0.3, noise=noise[b:b + 1])[0]
+            assert torch.equal(o[b, :, :256 * n], one[0, :, :256 * n]), (B, b)
+            if B <= 256:
+                assert (o[b, :, 256 * n:] == 0).all()
+
+
+def test_one_minute_utterances(synth_sd):
+    """T = 5 168 frames (60 s): 1.3 M samples per utterance, every 32-bit offset computation of the kernels at 6x the
+    benchmark length; against the oracle on the first and the last second and through the flow's round trip."""
+    from oracle import vc_oracle
+    B, T = 2, 5168
+    gen = torch.Generator().manual_seed(60)
+    spec = torch.rand(B, 513, T, generator=gen) * torch.linspace(3, 0.05, 513)[None, :, None]
+    lengths = torch.tensor([T, T - 999])
+    g1, g2 = 0.3 * torch.randn(1, 256, 1, generator=gen), 0.3 * torch.randn(1, 256, 1, generator=gen)
+    noise = torch.randn(B, 192, T, generator=gen)
+    model = _model(synth_sd)
+    o, _, (z, z_p, z_hat) = model.voice_conversion(spec.to(DEV), lengths.to(DEV), g1.to(DEV), g2.to(DEV), tau=0.3,
+                                                   noise=noise.to(DEV))
+    o_same, _, (_, _, z_rt) = model.voice_conversion(spec.to(DEV), lengths.to(DEV), g1.to(DEV), g1.to(DEV), tau=0.3,
+                                                     noise=noise.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.isfinite(o).all() and o.shape == (B, 1, 256 * T)
+    assert (z_rt - z).abs().max().item() <= 2e-4          # same speaker both ways: the flow inverts itself
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        o_ref = vc_oracle.voice_conversion(synth_sd, CONVERTER_MODEL_CONFIG, spec, lengths, g1, g2, 0.3, noise,
+                                           zero_g=True)[0]
+    err = (o.cpu() - o_ref).abs().max().item()
+    print("60 s utterances vs oracle:", err)
+    assert err <= 1e-3
