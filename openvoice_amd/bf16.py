@@ -156,6 +156,14 @@ class GeneratorBf16:
         # t = bf16(lrelu(v))), which can differ from that by one bf16 ulp of t on negative values -- fuse_pairs on / off
         # therefore agree within bf16 rounding, not bit for bit (tests/test_gpu_bf16_pair.py)
         self.fuse_pairs = True
+        # independent ResBlock chains of a stage on this many HIP streams (1 = one stream, the serial order)
+        self.chain_streams = 3
+        self._streams = []
+
+    def _side_streams(self, n):
+        while len(self._streams) < n:
+            self._streams.append(torch.cuda.Stream(self.device))
+        return self._streams[:n]
 
     def _workspace(self, B, T):
         key = (B, T)
@@ -167,7 +175,9 @@ class GeneratorBf16:
                 L *= u
                 biggest = max(biggest, ch * L)
             f = lambda n: torch.empty(n, dtype=torch.bfloat16, device=self.device)
-            self._ws[key] = dict(pre=f(B * T * self.cfg["upsample_initial_channel"]), dec=[f(B * biggest) for _ in range(5)])
+            # stage input, ups output, running sum + (t1, ra) per concurrent chain
+            nbuf = 3 + 2 * max(1, len(self.cfg["resblock_kernel_sizes"]))
+            self._ws[key] = dict(pre=f(B * T * self.cfg["upsample_initial_channel"]), dec=[f(B * biggest) for _ in range(nbuf)])
         return self._ws[key]
 
     @torch.no_grad()
@@ -191,30 +201,65 @@ class GeneratorBf16:
         cur_x, L = pre, T
         free = list(ws["dec"])
         nk = len(self.cfg["resblock_kernel_sizes"])
+        # The three ResBlocks of a stage (k = 3, 7, 11) are independent chains until the MRF sum.  In bf16 they bound
+        # DIFFERENT resources -- the k = 3 convs HBM (3.4 TB/s at 33 % matrix-busy), the k = 11 convs the power-limited
+        # matrix pipe (60 % busy at 1.5 TB/s) -- so they are issued on three HIP streams and run side by side; the sum
+        # keeps its order (chain j's last launch waits for chain j - 1's), so the result is bit-identical to the
+        # serial order.  Not under graph capture (the engine captures on one stream).
+        concurrent = self.chain_streams > 1 and nk > 1 and not torch.cuda.is_current_stream_capturing()
+        main = torch.cuda.current_stream(dev)
+        side = self._side_streams(nk) if concurrent else None
         for i, up in enumerate(self.ups):
             s = up["stride"]
             cin, ch = ch, ch // 2
             u = free.pop()[: B * L * s * ch].view(B, L * s, ch)
             _launch(up["conv"], cur_x, u, L, in_slope=LRELU_SLOPE, phase_s=s)
             L *= s
-            t1, ra, acc = (free.pop()[: B * L * ch].view(B, L, ch) for _ in range(3))
-            for j, pairs in enumerate(self.resblocks[i]):
-                cur = u
-                fused = self.fuse_pairs and all(pair_bf16_supported(ch, c1.K, c1.dil) for c1, _ in pairs)
-                for n, (c1, c2) in enumerate(pairs):
-                    last = n == len(pairs) - 1
-                    add = acc if (last and j > 0) else None
-                    scale = 1.0 / nk if (last and j == nk - 1) else 1.0
-                    if fused:      # one launch per pair, intermediate in LDS; out must not alias x: ra / t1 ping-pong
-                        dst = acc if last else (t1 if cur is ra else ra)
-                        launch_pair_bf16(c1, c2, cur, dst, add=add, scale=scale, slope=LRELU_SLOPE)
-                    else:
-                        # t1 is consumed by c2 only, which activates it: store it activated (one rounding instead of
-                        # two) and let c2's loaders copy it as is
-                        _launch(c1, cur, t1, L, in_slope=LRELU_SLOPE, out_slope=LRELU_SLOPE)
-                        dst = acc if last else ra
-                        _launch(c2, t1, dst, L, in_slope=1.0, res=cur, add=add, scale=scale)
-                    cur = dst
+            acc = free.pop()[: B * L * ch].view(B, L, ch)
+            nchains = nk if concurrent else 1
+            scratch = [tuple(free.pop()[: B * L * ch].view(B, L, ch) for _ in range(2)) for _ in range(nchains)]
+            cur = [u] * nk
+            fused = [self.fuse_pairs and all(pair_bf16_supported(ch, c1.K, c1.dil) for c1, _ in pairs)
+                     for pairs in self.resblocks[i]]
+            npairs = len(self.resblocks[i][0])
+
+            def pair(j, n):
+                c1, c2 = self.resblocks[i][j][n]
+                t1, ra = scratch[j if concurrent else 0]
+                last = n == npairs - 1
+                add = acc if (last and j > 0) else None
+                scale = 1.0 / nk if (last and j == nk - 1) else 1.0
+                if fused[j]:       # one launch per pair, intermediate in LDS; out must not alias x: ra / t1 ping-pong
+                    dst = acc if last else (t1 if cur[j] is ra else ra)
+                    launch_pair_bf16(c1, c2, cur[j], dst, add=add, scale=scale, slope=LRELU_SLOPE)
+                else:
+                    # t1 is consumed by c2 only, which activates it: store it activated (one rounding instead of
+                    # two) and let c2's loaders copy it as is
+                    _launch(c1, cur[j], t1, L, in_slope=LRELU_SLOPE, out_slope=LRELU_SLOPE)
+                    dst = acc if last else ra
+                    _launch(c2, t1, dst, L, in_slope=1.0, res=cur[j], add=add, scale=scale)
+                cur[j] = dst
+
+            if not concurrent:
+                for j in range(nk):
+                    for n in range(npairs):
+                        pair(j, n)
+            else:
+                fork = torch.cuda.Event()
+                fork.record(main)
+                done = [None] * nk
+                for n in range(npairs):                 # round-robin over the chains: every queue has work early
+                    for j in range(nk):
+                        with torch.cuda.stream(side[j]):
+                            if n == 0:
+                                side[j].wait_event(fork)
+                            if n == npairs - 1 and j > 0:
+                                side[j].wait_event(done[j - 1])      # the running sum is accumulated in chain order
+                            pair(j, n)
+                            if n == npairs - 1:
+                                done[j] = torch.cuda.Event()
+                                done[j].record(side[j])
+                main.wait_event(done[nk - 1])
             # every scratch buffer except the one holding this stage's output is free again
             free = [buf for buf in ws["dec"] if buf.data_ptr() != acc.data_ptr()]
             cur_x = acc

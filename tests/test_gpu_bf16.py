@@ -168,3 +168,31 @@ def test_voice_conversion_with_the_opt_in_bf16_generator(synth_sd):
     m.engine().use_bf16_generator(False)
     o32 = m.voice_conversion(spec.to(DEV), lengths.to(DEV), g1.to(DEV), g2.to(DEV), tau=0.3, noise=noise.to(DEV))[0]
     assert (o32.cpu() - o_r).abs().max().item() <= 1e-3
+
+
+def test_concurrent_resblock_chains_are_bit_identical_to_the_serial_order(synth_sd):
+    """``GeneratorBf16.chain_streams``: the three ResBlock chains of a stage on three HIP streams (the k = 3 chain is
+    HBM-bound, the k = 11 chain matrix-bound: side by side they fill each other's idle resource); the MRF sum keeps its
+    order through events, so the waveform equals the one-stream order bit for bit -- fused and unfused pairs, twice in
+    a row (buffers are reused across calls), and under a non-default current stream."""
+    from openvoice_amd.bf16 import GeneratorBf16
+    from openvoice_amd.utils import CONVERTER_MODEL_CONFIG as CFG
+    gen = torch.Generator().manual_seed(3)
+    z = torch.randn(3, 192, 90, generator=gen).to(DEV)
+    g = (0.3 * torch.randn(3, 256, 1, generator=gen)).to(DEV)
+    dec = GeneratorBf16(synth_sd, CFG, DEV)
+    for fuse in (True, False):
+        dec.fuse_pairs = fuse
+        dec.chain_streams = 1
+        serial = dec.decode(z, g).clone()
+        dec.chain_streams = 3
+        a = dec.decode(z, g).clone()
+        b = dec.decode(z, g).clone()
+        side = torch.cuda.Stream(DEV)
+        side.wait_stream(torch.cuda.current_stream(DEV))
+        with torch.cuda.stream(side):
+            c = dec.decode(z, g).clone()
+        side.synchronize()
+        torch.cuda.synchronize()
+        assert torch.isfinite(serial).all()
+        assert torch.equal(a, serial) and torch.equal(b, serial) and torch.equal(c, serial), f"fuse_pairs={fuse}"

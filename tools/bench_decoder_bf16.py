@@ -25,6 +25,10 @@ def main():
     ap.add_argument("--frames", type=int, default=861)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--no-fp32", action="store_true")
+    ap.add_argument("--chain-streams", type=int, default=None,
+                    help="HIP streams for the independent ResBlock chains of a stage (default: GeneratorBf16's, 3; "
+                         "1 = the serial one-stream order, which is what the rocprofv3 --pmc passes see anyway: "
+                         "counter collection serialises kernels)")
     ap.add_argument("--pmc-calibration", action="store_true",
                     help="after the timed region, three 1 GiB device-to-device copies (a known byte count) so that a "
                          "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass over this command can be calibrated")
@@ -42,6 +46,8 @@ def main():
     z = torch.randn(B, 192, T, generator=gen).to(dev)
     g = (0.3 * torch.randn(1, 256, 1, generator=gen)).to(dev)
     dec = GeneratorBf16(sd, CFG, dev)
+    if args.chain_streams is not None:
+        dec.chain_streams = args.chain_streams
 
     def timeit(fn):
         for _ in range(2):
@@ -54,8 +60,16 @@ def main():
         return (time.perf_counter() - t0) / args.steps, o
 
     dt, o16 = timeit(lambda: dec.decode(z, g))
+    dt_serial = None
+    if dec.chain_streams > 1:          # the same generator on one stream, same process: what the concurrency buys
+        keep, dec.chain_streams = dec.chain_streams, 1
+        dt_serial, o_serial = timeit(lambda: dec.decode(z, g))
+        dec.chain_streams = keep
+        assert torch.equal(o_serial, o16), "concurrent chains must not change the result"
     out = {"workload": f"HiFi-GAN generator, bf16 activations (channels-last), batch {B} x {T} frames (10 s), one MI355X",
            "ms_per_batch": round(dt * 1e3, 3), "utterances_per_s": round(B / dt, 1),
+           "chain_streams": dec.chain_streams,
+           "ms_per_batch_one_stream": round(dt_serial * 1e3, 3) if dt_serial else None,
            "real_time_factor": round(B * T * 256 / 22050.0 / dt, 1),
            "alg_hbm_GB": round(alg_bytes(CFG, B, T, 2) / 1e9, 2),
            "alg_hbm_GBps": round(alg_bytes(CFG, B, T, 2) / dt / 1e9, 1), "hbm_peak_GBps": 8000, "hbm_achievable_GBps": 6300,
