@@ -156,8 +156,11 @@ class GeneratorBf16:
         # t = bf16(lrelu(v))), which can differ from that by one bf16 ulp of t on negative values -- fuse_pairs on / off
         # therefore agree within bf16 rounding, not bit for bit (tests/test_gpu_bf16_pair.py)
         self.fuse_pairs = True
-        # independent ResBlock chains of a stage on this many HIP streams (1 = one stream, the serial order)
-        self.chain_streams = 3
+        # independent ResBlock chains of a stage on this many HIP streams (1 = one stream, the serial order).  Measured
+        # (round 3, batch 64): 3 streams 45.46 ms vs 45.86 ms on one -- a launch of 2 workgroups per CU owns the chip,
+        # so kernels of different streams overlap only at their ramps and tails -- 0.9 %, not worth a default that makes
+        # per-kernel profiles harder to read: off unless asked for
+        self.chain_streams = 1
         self._streams = []
 
     def _side_streams(self, n):
@@ -203,9 +206,9 @@ class GeneratorBf16:
         nk = len(self.cfg["resblock_kernel_sizes"])
         # The three ResBlocks of a stage (k = 3, 7, 11) are independent chains until the MRF sum.  In bf16 they bound
         # DIFFERENT resources -- the k = 3 convs HBM (3.4 TB/s at 33 % matrix-busy), the k = 11 convs the power-limited
-        # matrix pipe (60 % busy at 1.5 TB/s) -- so they are issued on three HIP streams and run side by side; the sum
-        # keeps its order (chain j's last launch waits for chain j - 1's), so the result is bit-identical to the
-        # serial order.  Not under graph capture (the engine captures on one stream).
+        # matrix pipe (60 % busy at 1.5 TB/s) -- so with chain_streams > 1 they are issued on separate HIP streams;
+        # the sum keeps its order (chain j's last launch waits for chain j - 1's), so the result is bit-identical to
+        # the serial order.  Not under graph capture (the engine captures on one stream).
         concurrent = self.chain_streams > 1 and nk > 1 and not torch.cuda.is_current_stream_capturing()
         main = torch.cuda.current_stream(dev)
         side = self._side_streams(nk) if concurrent else None
