@@ -74,7 +74,11 @@ def main():
            "alg_hbm_GB": round(alg_bytes(CFG, B, T, 2) / 1e9, 2),
            "alg_hbm_GBps": round(alg_bytes(CFG, B, T, 2) / dt / 1e9, 1), "hbm_peak_GBps": 8000, "hbm_achievable_GBps": 6300,
            "frac_of_hbm_peak": round(alg_bytes(CFG, B, T, 2) / dt / 8e12, 3),
-           "alg_tflops": round(529.44e9 * B * T / 861 / dt / 1e12, 1), "bf16_mfma_peak_tflops": 2500}
+           "alg_tflops": round(529.44e9 * B * T / 861 / dt / 1e12, 1), "bf16_mfma_peak_tflops": 2500,
+           # what the bf16 pipe sustains on random operands under the power limit (tools/micro/mfma_bf16_ceiling.hip,
+           # profiles/r03_s2_mfma_bf16_power_limited_ceiling.txt: 1.66-1.73 PFLOP/s over three boxes)
+           "bf16_mfma_sustained_tflops_measured": 1700,
+           "frac_of_sustained_mfma": round(529.44e9 * B * T / 861 / dt / 1700e12, 3)}
     out["decode_passes_in_process"] = 2 + args.steps
     if args.counters and os.path.exists(args.counters):
         with open(args.counters) as fh:
