@@ -173,14 +173,18 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair_bf16cl_kernel(const 
       okm[SL] = m;
       if (more && ++st_round == nrounds) { st_round = 0; st.advance(); ++st_pstep; more = st.valid(); }
     };
-    auto write = [&](auto slot) {
+    // `part`: 0 / 1 = the even / odd vectors of the lane (the write of one item is split around a barrier, see the
+    // main loop), 2 = all of them
+    auto write = [&](auto slot, auto part) {
       constexpr int SL = decltype(slot)::value;
+      constexpr int PART = decltype(part)::value;
       unsigned char* dst = xs + (written & 1) * BUF;
       unsigned char* raw = xr + (pd_par[SL] * NCH + pd_c[SL]) * RBUF - (P1 - P2) * PITCH;   // output-window rows
       const int nrows = pd_kind[SL] == 0 ? R1 : (pd_kind[SL] == 1 ? TT : 0);
       const bool is_x = pd_kind[SL] == 0;
 #pragma unroll
       for (int i = 0; i < PER_LANE; ++i) {
+        if (PART != 2 && (i & 1) != PART) continue;
         if (vrow[i] < nrows) {
           u32x4 v = stg[SL][i];
           if (!((okm[SL] >> i) & 1)) v = u32x4{0u, 0u, 0u, 0u};
@@ -188,15 +192,21 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair_bf16cl_kernel(const 
             if (vrow[i] >= P1 - P2 && vrow[i] < P1 - P2 + TT) *reinterpret_cast<u32x4*>(raw + loff[i]) = v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
-              // leaky ReLU: for 0 < slope <= 1 (checked by the dispatcher) it is max(x, slope x)
-              v[e] = pack2(fmaxf(lo, lo * slope), fmaxf(hi, hi * slope));
+              // leaky ReLU on a packed bf16 pair, evaluated in fp32 and rounded to nearest even: for 0 < slope <= 1
+              // (checked by the dispatcher) it is max(x, slope x).  6 instructions per pair -- shift, and,
+              // v_pk_mul_f32, two v_max_f32 (as asm: fmaxf() canonicalises both operands first, three v_max_f32 per
+              // value), v_cvt_pk_bf16_f32 -- the loaders' pass is what a step waits for (profiles/r02_s8)
+              f32x2_t w = {__uint_as_float(v[e] << 16), __uint_as_float(v[e] & 0xffff0000u)};
+              const f32x2_t sw = w * slope;
+              asm("v_max_f32 %0, %1, %2" : "=v"(w[0]) : "v"(w[0]), "v"(sw[0]));
+              asm("v_max_f32 %0, %1, %2" : "=v"(w[1]) : "v"(w[1]), "v"(sw[1]));
+              v[e] = pack2(w[0], w[1]);
             }
           }
           *reinterpret_cast<u32x4*>(dst + loff[i]) = v;
         }
       }
-      ++written;
+      if (PART != 0) ++written;
     };
     // The barrier sequence of the matrix waves, replayed: next_item_tick() passes every barrier up to and including
     // the one at which the next item starts being consumed (false when the sequence is over).
@@ -223,29 +233,45 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair_bf16cl_kernel(const 
         llast = now;
       }
     };
+    // If the NEXT barrier of the sequence is not an item tick (the "t in LDS" barrier after the x chunks, the end-of-step
+    // barrier), pass it.  The write of item k + 1 is split around it: per step the matrix waves run c1 | barrier | c2 +
+    // residual + epilogue, and a loader that does its whole pass (write + issue, ~3 300 ticks at C = 32, K = 3:
+    // profiles/r02_s8) in front of that barrier leaves them waiting there for ~3 000 ticks and then waits itself
+    // through c2 -- the two were running one after the other.  Both halves go to the chunk buffer (and raw buffer) that
+    // nothing reads before item k + 1's own tick, so the split needs no extra synchronisation.
+    auto pass_nontick = [&]() {
+      if (!tk.valid()) return;
+      const int n_a = tk.warm ? 0 : n_add;
+      if (pos == NCH) { __syncthreads(); ++pos; }
+      else if (pos == NCH + 1 + n_a) { __syncthreads(); pos = 0; tk.advance(); }
+    };
     static_assert(DEPTH == 4, "the loop below is unrolled over four register slots");
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     using S2 = std::integral_constant<int, 2>;
     using S3 = std::integral_constant<int, 3>;
+    using PA = std::integral_constant<int, 0>;
+    using PB = std::integral_constant<int, 1>;
+    using PALL = std::integral_constant<int, 2>;
     issue(S0{});
     issue(S1{});
     issue(S2{});
     issue(S3{});
-    write(S0{});                                   // item 0 goes straight into the (empty) chunk buffer 0
+    write(S0{}, PALL{});                           // item 0 goes straight into the (empty) chunk buffer 0
     issue(S0{});
     __syncthreads();                               // (init)
-    // at the tick of item k: item k + 1 (slot (k + 1) % DEPTH) is written, item k + 1 + DEPTH issued into the same slot
+    // at the tick of item k: item k + 1 (slot (k + 1) % DEPTH) is written -- half before, half after the next barrier
+    // when that is not item k + 1's own tick -- and item k + 1 + DEPTH issued into the same slot
     if (ldbg) llast = __builtin_readcyclecounter();
     for (;;) {
       if (!next_item_tick()) break;
-      lmark(0); write(S1{}); lmark(1); issue(S1{}); lmark(2);
+      lmark(0); write(S1{}, PA{}); lmark(1); pass_nontick(); lmark(0); write(S1{}, PB{}); lmark(1); issue(S1{}); lmark(2);
       if (!next_item_tick()) break;
-      lmark(0); write(S2{}); lmark(1); issue(S2{}); lmark(2);
+      lmark(0); write(S2{}, PA{}); lmark(1); pass_nontick(); lmark(0); write(S2{}, PB{}); lmark(1); issue(S2{}); lmark(2);
       if (!next_item_tick()) break;
-      lmark(0); write(S3{}); lmark(1); issue(S3{}); lmark(2);
+      lmark(0); write(S3{}, PA{}); lmark(1); pass_nontick(); lmark(0); write(S3{}, PB{}); lmark(1); issue(S3{}); lmark(2);
       if (!next_item_tick()) break;
-      lmark(0); write(S0{}); lmark(1); issue(S0{}); lmark(2);
+      lmark(0); write(S0{}, PA{}); lmark(1); pass_nontick(); lmark(0); write(S0{}, PB{}); lmark(1); issue(S0{}); lmark(2);
     }
     if (ldbg && lane == 0) {
 #pragma unroll
