@@ -48,13 +48,13 @@ B = 64
 for c, L, TT in ((32, 220416, 256), (64, 110208, 128)):
     x = torch.randn(B, L, c, device=dev).to(torch.bfloat16)
     out = torch.empty_like(x)
-    for k in (3, 11):
+    for k in (3, 7, 11):
+        if not pair_bf16_supported(c, k, 1):
+            continue
         c1 = PackedConvBf16(torch.randn(c, c, k) * (c * k) ** -0.5, torch.zeros(c), dev, dil=1)
         c2 = PackedConvBf16(torch.randn(c, c, k) * (c * k) ** -0.5, torch.zeros(c), dev, dil=1)
         for _ in range(20):
             launch_pair_bf16(c1, c2, x, out)
-        if not pair_bf16_supported(c, k, 1):
-            continue
         dbg = torch.zeros(1024 * 12 * 9, dtype=torch.int64, device=dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
