@@ -276,22 +276,39 @@ class ToneColorConverter(OpenVoiceBaseClass):
     def convert_batch_sharded(self, waveforms, src_se, tgt_se, tau=0.3, noise=None, gather=True):
         """``convert_batch`` across the GPUs of one node: call it from every rank of an
         initialised ``torch.distributed`` process group (backend "nccl" = RCCL; one process per GPU, this converter on
-        the rank's own device) with the same ``waveforms`` ([N, samples], equal lengths).  Rank 0's speaker embeddings
-        are broadcast (2 KiB, the only collective on the path; other ranks may pass None), rank r converts utterances
-        ``parallel.shard_range(N, r, world)``, and with ``gather`` every rank receives the whole ``[N, 1, hop*T]``
-        batch (one all-gather), else ``(local_o_hat, (start, end))``.  ``noise`` [N, 192, T] is per utterance, so the
-        result does not depend on the number of ranks.  Without a process group this is ``convert_batch``."""
+        the rank's own device) with the same ``waveforms`` -- a ``[N, samples]`` tensor, or a list of N waveforms of
+        different lengths.  Rank 0's speaker embeddings are broadcast (2 KiB, the only collective on the path; other
+        ranks may pass None), rank r converts utterances ``parallel.shard_range(N, r, world)``, and with ``gather``
+        every rank receives the whole ``[N, 1, hop*T_max]`` batch (one all-gather), else ``(local_o_hat, (start,
+        end))``.  ``noise`` [N, 192, T] is per utterance, so the result does not depend on the number of ranks.  For a
+        list the return value is ``(o_hat, lengths_in_samples [N])`` as from ``convert_batch`` (every rank knows every
+        length, so the padded width is agreed on without a collective).  Without a process group this is
+        ``convert_batch``."""
         from . import parallel
         gin = self.model.model_cfg["gin_channels"]
+        d = self.hps.data
+        hop = d.hop_length
+        frames_of = lambda n: (int(n) + (d.filter_length - hop) // 2 * 2 - d.filter_length) // hop + 1
+        ragged = isinstance(waveforms, (list, tuple))
+        if ragged:
+            frames = [frames_of(len(w)) for w in waveforms]
+            items = list(waveforms)
+        else:
+            items = torch.as_tensor(waveforms, dtype=torch.float32)
+            frames = [frames_of(items.shape[1])] * len(items)
+        width = max(frames) * hop                        # samples of the padded batch, the same on every rank
 
         def convert(shard, s, t, nz):
-            if len(shard) == 0:         # more ranks than utterances: an empty shard of the right width
-                hop, d = self.hps.data.hop_length, self.hps.data
-                frames = (waveforms.shape[1] + (d.filter_length - hop) // 2 * 2 - d.filter_length) // hop + 1
-                return torch.zeros(0, 1, frames * hop, dtype=torch.float32, device=self.device)
-            return self.convert_batch(shard, s, t, tau=tau, noise=nz)[0]
-        waveforms = torch.as_tensor(waveforms, dtype=torch.float32)
-        return parallel.convert_sharded(convert, waveforms, src_se, tgt_se, gin, self.device, noise=noise, gather=gather)
+            if len(shard) == 0:         # more ranks than utterances: an empty shard of the agreed width
+                return torch.zeros(0, 1, width, dtype=torch.float32, device=self.device)
+            o = self.convert_batch(shard, s, t, tau=tau, noise=nz)[0]
+            if o.shape[2] < width:      # a shard whose longest utterance is shorter than the batch's
+                o = torch.nn.functional.pad(o, (0, width - o.shape[2]))
+            return o
+        out = parallel.convert_sharded(convert, items, src_se, tgt_se, gin, self.device, noise=noise, gather=gather)
+        if ragged and gather:
+            return out, torch.tensor(frames, dtype=torch.int64, device=self.device) * hop
+        return out
 
     def convert(self, audio_src_path, src_se, tgt_se, output_path=None, tau=0.3, message="default"):
         """reference: openvoice/api.py:141-160."""

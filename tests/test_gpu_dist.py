@@ -60,6 +60,11 @@ def test_rccl_broadcast_gather_and_sharded_api_at_world_size_1(synth_sd, tmp_pat
         full = tcc.convert_batch_sharded(waves, src, tgt, tau=0.3, noise=noise)
         plain = tcc.convert_batch(waves, src.to(DEV), tgt.to(DEV), tau=0.3, noise=noise)[0]
         assert full.shape == (3, 1, 256 * 20) and torch.equal(full, plain)
+        # ragged list: same call, padded to the longest utterance of the WHOLE batch, lengths returned
+        ragged = [waves[0], waves[1][: 256 * 11 + 40], waves[2][: 256 * 7]]
+        o_r, n_r = tcc.convert_batch_sharded(ragged, src, tgt, tau=0.0)
+        o_p, n_p = tcc.convert_batch(ragged, src.to(DEV), tgt.to(DEV), tau=0.0)
+        assert torch.equal(n_r, n_p) and n_r.tolist() == [256 * 20, 256 * 11, 256 * 7] and torch.equal(o_r, o_p)
     finally:
         dist.destroy_process_group()
 
