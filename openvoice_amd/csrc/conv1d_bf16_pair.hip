@@ -16,14 +16,10 @@
 // channel tiles) + 4 loader waves.  Everything the k-step loops touch is in LDS:
 //   wsm  both convs' packed weights, copied once per workgroup (it runs ~200 steps)             12 ... 48 KB
 //   xs   double-buffered 32-channel chunks of lrelu(x) with the (K-1) DIL halo                    -> c1's B operands
+//   xr   the same chunks RAW, output rows only, double-buffered per step                         -> residual
 //   hb   the t tile: [K-1 rows of left context | TT new rows]                                    -> c2's B operands
-// The loaders read every x vector once and write its activated copy; the next item's loads are in flight (in
-// registers) while the current one is written and across the barriers.  The RESIDUAL does not go through the loaders
-// (round 3; it used to: a raw copy of every chunk in a third LDS region, added with an identity MFMA): each matrix wave
-// reads the 32 x 32 raw fragment it owns straight from HBM / L2 -- four 8-byte loads per lane at the top of the step,
-// in flight through c1 and c2 -- and adds it in fp32 where the identity MFMA did (bf16 -> fp32 is exact, one rounding
-// either way: bit-identical).  That takes ~15 % of the instructions out of the loaders' pass, which is what a step
-// waits for, and 41 KB out of LDS.  The MFMAs are issued "transposed"
+// The loaders read every x vector ONCE and write both its activated and its raw copy; the next item's loads are in
+// flight (in registers) while the current one is written and across the barriers.  The MFMAs are issued "transposed"
 // (A = weights, B = activations) so that a lane ends up with 4 x 4 consecutive CHANNELS of one time row: t goes to LDS
 // and the output to HBM with 8-byte stores (the time-major form needs four times as many 2-byte ones).
 // Rounds of one step: C/32 x chunks -> c1;  t -> LDS;  c2 out of hb;  residual out of xr;  C/32 chunks of `add`
@@ -91,6 +87,7 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair_bf16cl_kernel(const 
   constexpr int P1 = (K - 1) * DIL / 2, P2 = (K - 1) / 2;
   constexpr int R1 = TT + 2 * P1;                 // rows of a staged x chunk
   constexpr int BUF = R1 * PITCH;
+  constexpr int RBUF = TT * PITCH;                // one raw chunk (output rows only)
   constexpr int PH = 2 * C + 16;                  // row pitch of the t tile (bytes)
   constexpr int RH = TT + 2 * P2;                 // its rows: [2 P2 rows of left context | TT new rows]
   constexpr int NITEM = R1 * 4;                   // 16-byte vectors of a chunk
@@ -98,6 +95,7 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair_bf16cl_kernel(const 
   constexpr int DEPTH = 4;                        // items whose loads are in flight in the loaders' registers
   constexpr int WREC = NCT * NCH * K * 2;         // 1 KiB records of one conv's packed weight
   __shared__ __attribute__((aligned(16))) unsigned char xs[2 * BUF];
+  __shared__ __attribute__((aligned(16))) unsigned char xr[2 * NCH * RBUF];
   __shared__ __attribute__((aligned(16))) unsigned char hb[RH * PH];
   __shared__ __attribute__((aligned(16))) unsigned char wsm[2 * WREC * 1024];
   __shared__ __attribute__((aligned(16))) float bsm[2 * C];
@@ -134,12 +132,12 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair_bf16cl_kernel(const 
     const int llane = (wave - NMW) * 64 + lane;
     const float slope = p.slope;
     Seq st(g0, g1, nsteps);          // the item whose loads are issued next
-    int st_round = 0;
+    int st_round = 0, st_pstep = 0;
     bool more = true;
     long written = 0;
     u32x4 stg[DEPTH][PER_LANE];
     int okm[DEPTH];                                // bit i: vector i of the slot is inside the tensor
-    int pd_kind[DEPTH], pd_c[DEPTH];
+    int pd_kind[DEPTH], pd_c[DEPTH], pd_par[DEPTH];
     // per-lane constants of the PER_LANE vectors a lane stages of every item
     int vrow[PER_LANE];
     uint32_t voff[PER_LANE], loff[PER_LANE];
@@ -162,6 +160,7 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair_bf16cl_kernel(const 
         pd_kind[SL] = 1; pd_c[SL] = st_round - NCH; nrows = TT; tbase = t0 - P2;
       }
       if (!more) { src = reinterpret_cast<const unsigned char*>(p.x); nrows = 0; pd_kind[SL] = 2; pd_c[SL] = 0; tbase = 0; }
+      pd_par[SL] = st_pstep & 1;
       src += pd_c[SL] * (CH * 2);                  // uniform: chunk column of the utterance
       int m = 0;
 #pragma unroll
@@ -172,7 +171,7 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair_bf16cl_kernel(const 
         stg[SL][i] = *reinterpret_cast<const u32x4*>(src + (tc * (uint32_t)(C * 2) + voff[i]));
       }
       okm[SL] = m;
-      if (more && ++st_round == nrounds) { st_round = 0; st.advance(); more = st.valid(); }
+      if (more && ++st_round == nrounds) { st_round = 0; st.advance(); ++st_pstep; more = st.valid(); }
     };
     // `part`: 0 / 1 = the even / odd vectors of the lane (the write of one item is split around a barrier, see the
     // main loop), 2 = all of them
@@ -180,6 +179,7 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair_bf16cl_kernel(const 
       constexpr int SL = decltype(slot)::value;
       constexpr int PART = decltype(part)::value;
       unsigned char* dst = xs + (written & 1) * BUF;
+      unsigned char* raw = xr + (pd_par[SL] * NCH + pd_c[SL]) * RBUF - (P1 - P2) * PITCH;   // output-window rows
       const int nrows = pd_kind[SL] == 0 ? R1 : (pd_kind[SL] == 1 ? TT : 0);
       const bool is_x = pd_kind[SL] == 0;
 #pragma unroll
@@ -189,6 +189,7 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair_bf16cl_kernel(const 
           u32x4 v = stg[SL][i];
           if (!((okm[SL] >> i) & 1)) v = u32x4{0u, 0u, 0u, 0u};
           if (is_x) {
+            if (vrow[i] >= P1 - P2 && vrow[i] < P1 - P2 + TT) *reinterpret_cast<u32x4*>(raw + loff[i]) = v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               // leaky ReLU on a packed bf16 pair, evaluated in fp32 and rounded to nearest even: for 0 < slope <= 1
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair_bf16cl_kernel(const 
   // Where both convs' fragments of this wave's channel tile fit in <= 112 VGPRs they live in registers for the whole
   // kernel: no weight traffic at all inside the step loop (C = 32: K = 3, 7; C = 64: K = 3), half the LDS reads.
   constexpr int WR = NCH * K * 2;                   // records of one conv of one channel tile
-  constexpr bool WREG = 2 * WR * 4 <= 104;     // K = 7 at C = 32 (112) would leave no room for the residual fragment
+  constexpr bool WREG = 2 * WR * 4 <= 112;
   u32x4 wr1[WREG ? WR : 1], wr2[WREG ? WR : 1];
   if constexpr (WREG) {
 #pragma unroll
@@ -376,17 +377,7 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair_bf16cl_kernel(const 
     const int b = tk.b;
     const bool warm = tk.warm;
     const int t0 = tk.tile() * TT;
-    // ---- residual: this wave's raw 32 x 32 fragment of x (output rows t0 - P2 ...), 4 consecutive channels per 8-byte
-    // load, requested now and added after c2 ----------------------------------------------------------------------
-    u32x2 rres[4] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
-    if (!warm) {
-      const int tr = t0 - P2 + trow0 + l31;
-      if (tr >= 0 && tr < L) {
-        const uint16_t* rrow = p.x + ((int64_t)b * L + tr) * C + 32 * nt + 4 * half;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) rres[g] = *reinterpret_cast<const u32x2*>(rrow + 8 * g);
-      }
-    }
+    const int par = pstep & 1;                        // raw-chunk buffer of this pseudo-step
 
     // ---- c1: t = b1 + W1 * lrelu(x) -----------------------------------------------------------------
     f32x16 acc;
@@ -441,13 +432,7 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair_bf16cl_kernel(const 
       if constexpr (NCH == 2) mma(I1{}, IPH{}, std::integral_constant<int, 1>{}, hb + hl_off + 64, wl2, wr2, acc);
       mark(5);
       // ---- residual: raw x of this wave's channel tile, out of xr ----------------------------------
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {      // acc[4 g + j] = channel 32 nt + 8 g + 4 half + j of this lane's time row
-        acc[4 * g + 0] += __uint_as_float(rres[g][0] << 16);
-        acc[4 * g + 1] += __uint_as_float(rres[g][0] & 0xffff0000u);
-        acc[4 * g + 2] += __uint_as_float(rres[g][1] << 16);
-        acc[4 * g + 3] += __uint_as_float(rres[g][1] & 0xffff0000u);
-      }
+      identity(xr + (par * NCH + nt) * RBUF + xl_off, acc);
       // ---- MRF running sum: staged rounds -----------------------------------------------------------
       for (int c = 0; c < n_add; ++c, ++it) {
         __syncthreads();
@@ -514,9 +499,8 @@ int launch(const ov_respair_bf16_params* p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
 }
 
-// LDS per workgroup = weights (2 C^2 K 2 B) + chunk buffers + t tile: C = 32 -> 74 / 93 / 113 KB at K = 3 / 7 / 11;
-// C = 64 -> 90 KB at K = 3, 156-165 KB at K = 7 (over the 160 KB of a CU at dilation 5), 180 KB + at K = 11 (those
-// shapes stay on two launches).
+// LDS per workgroup = weights (2 C^2 K 2 B) + chunk buffers + raw chunks + t tile: C = 32 -> 116 / 132 / 155 KB at
+// K = 3 / 7 / 11; C = 64 -> 130 KB at K = 3, over the 160 KB of a CU beyond that (those shapes stay on two launches).
 template <int K, int DIL>
 int launch_by_width(const ov_respair_bf16_params* p, hipStream_t stream) {
   if (p->C == 32) return launch<K, DIL, 32, 256>(p, stream);
