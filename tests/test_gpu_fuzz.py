@@ -1,0 +1,73 @@
+"""Seeded random shapes through the whole converter path against the CPU oracle: batch 1-6, 1-330 frames (every tile /
+halo / vector-tail residue class of the frame-rate and generator kernels), ragged lengths incl. length-1 utterances,
+broadcast and per-item speaker embeddings, zero_g on / off, tau 0 ... 1, with and without the length-aware work
+lists.  Tolerance: BASELINE.json north_star (waveform 1e-3; latents 2e-4)."""
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from openvoice_amd.hostinfo import usable_cpus  # noqa: E402
+from openvoice_amd.models import SynthesizerTrn  # noqa: E402
+from openvoice_amd.utils import CONVERTER_MODEL_CONFIG  # noqa: E402
+
+DEV = "cuda:0"
+_models = {}
+
+
+def _model(sd, zero_g):
+    if zero_g not in _models:
+        m = SynthesizerTrn(0, 513, n_speakers=0, zero_g=zero_g, **CONVERTER_MODEL_CONFIG)
+        m.load_state_dict(sd, strict=True)
+        _models[zero_g] = m.to(DEV).eval()
+    return _models[zero_g]
+
+
+def _cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        B = rng.randint(1, 6)
+        T = rng.choice([1, 2, 3, 5, 16, 17, 31, 33, 63, 64, 65, 111, 112, 113, 127, 128, 129, 200, 255, 256, 257, 330])
+        if i % 3 == 0:
+            T = rng.randint(1, 330)
+        lengths = [T] + [rng.randint(1, T) for _ in range(B - 1)]
+        rng.shuffle(lengths)
+        out.append(dict(B=B, T=T, lengths=lengths, zero_g=bool(rng.getrandbits(1)), per_item=bool(rng.getrandbits(1)),
+                        tau=rng.choice([0.0, 0.3, 1.0]), skip=bool(rng.getrandbits(1)), seed=seed * 1000 + i))
+    return out
+
+
+@pytest.mark.parametrize("case", _cases(24, 7), ids=lambda c: f"B{c['B']}_T{c['T']}_{'skip' if c['skip'] else 'full'}")
+def test_random_shape_matches_oracle(synth_sd, case):
+    from oracle import vc_oracle
+    B, T = case["B"], case["T"]
+    gen = torch.Generator().manual_seed(case["seed"])
+    spec = torch.rand(B, 513, T, generator=gen) * torch.linspace(3, 0.05, 513)[None, :, None]
+    lengths = torch.tensor(case["lengths"], dtype=torch.long)
+    gshape = (B if case["per_item"] else 1, 256, 1)
+    g_src, g_tgt = 0.3 * torch.randn(gshape, generator=gen), 0.3 * torch.randn(gshape, generator=gen)
+    noise = torch.randn(B, 192, T, generator=gen)
+    torch.set_num_threads(usable_cpus(32))
+    with torch.no_grad():
+        o_ref, mask_ref, (z_r, zp_r, zh_r) = vc_oracle.voice_conversion(
+            synth_sd, CONVERTER_MODEL_CONFIG, spec, lengths, g_src, g_tgt, case["tau"], noise, zero_g=case["zero_g"])
+    model = _model(synth_sd, case["zero_g"])
+    o, mask, (z, z_p, z_hat) = model.voice_conversion(spec.to(DEV), lengths.to(DEV), g_src.to(DEV), g_tgt.to(DEV),
+                                                      tau=case["tau"], noise=noise.to(DEV), skip_padding=case["skip"])
+    torch.cuda.synchronize()
+    assert torch.equal(mask.cpu(), mask_ref)
+    for got, ref, name in ((z, z_r, "z"), (z_p, zp_r, "z_p"), (z_hat, zh_r, "z_hat")):
+        err = (got.cpu() - ref).abs().max().item()
+        assert err <= 2e-4, (name, err, case)
+    o = o.cpu()
+    if case["skip"]:
+        for b, n in enumerate(case["lengths"]):       # valid samples against the oracle, silence beyond
+            err = (o[b, :, :256 * n] - o_ref[b, :, :256 * n]).abs().max().item()
+            assert err <= 1e-3, (b, err, case)
+            assert (o[b, :, 256 * n:] == 0).all(), (b, case)
+    else:
+        err = (o - o_ref).abs().max().item()
+        assert err <= 1e-3, (err, case)
