@@ -71,3 +71,57 @@ def test_random_shape_matches_oracle(synth_sd, case):
     else:
         err = (o - o_ref).abs().max().item()
         assert err <= 1e-3, (err, case)
+
+
+def _tts_cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        B = rng.randint(1, 4)
+        Tx = rng.choice([3, 7, 16, 17, 33, 48, 61])
+        lengths = [Tx] + [rng.randint(2, Tx) for _ in range(B - 1)]
+        rng.shuffle(lengths)
+        out.append(dict(B=B, Tx=Tx, lengths=lengths, sid=[rng.randrange(10) for _ in range(B)],
+                        noise_scale=rng.choice([0.0, 0.667, 1.0]), length_scale=rng.choice([0.8, 1.0, 1.25]),
+                        noise_scale_w=rng.choice([0.0, 0.6, 0.8]), sdp_ratio=rng.choice([0.0, 0.2, 0.5, 1.0]),
+                        skip=bool(i % 2), seed=seed * 100 + i))
+    return out
+
+
+@pytest.mark.parametrize("case", _tts_cases(8, 3), ids=lambda c: f"B{c['B']}_Tx{c['Tx']}_{'skip' if c['skip'] else 'full'}")
+def test_random_tts_batch_matches_oracle(synth_tts_sd, case):
+    """``SynthesizerTrn.infer`` on random ragged token batches, speeds, noise scales and duration mixes against the CPU
+    oracle: alignment bit-exact (the durations are integers), waveform within 1e-3 -- over each utterance's own length
+    when the length-aware work lists are on."""
+    from oracle import tts_oracle
+    B, Tx = case["B"], case["Tx"]
+    gen = torch.Generator().manual_seed(case["seed"])
+    tokens = torch.randint(0, 68, (B, Tx), generator=gen)
+    lengths = torch.tensor(case["lengths"])
+    sid = torch.tensor(case["sid"])
+    noise_w = torch.randn(B, 2, Tx, generator=gen)
+    noise_z = torch.randn(B, 192, 40 * Tx, generator=gen)
+    torch.set_num_threads(usable_cpus(32))
+    args = (case["noise_scale"], case["length_scale"], case["noise_scale_w"], case["sdp_ratio"])
+    with torch.no_grad():
+        o_r, attn_r, ym_r, (z_r, zp_r, _, _), _ = tts_oracle.infer(synth_tts_sd, CONVERTER_MODEL_CONFIG, tokens, lengths,
+                                                                   sid, noise_w, noise_z, *args)
+    key = "tts"
+    if key not in _models:
+        m = SynthesizerTrn(68, 513, n_speakers=10, **CONVERTER_MODEL_CONFIG)
+        m.load_state_dict(synth_tts_sd, strict=True)
+        _models[key] = m.to(DEV).eval()
+    o, attn, y_mask, (z, z_p, _, _) = _models[key].infer(
+        tokens.to(DEV), lengths.to(DEV), sid=sid.to(DEV), noise_scale=args[0], length_scale=args[1],
+        noise_scale_w=args[2], sdp_ratio=args[3], noise_w=noise_w.to(DEV), noise_z=noise_z.to(DEV),
+        skip_padding=case["skip"])
+    torch.cuda.synchronize()
+    assert torch.equal(attn.cpu(), attn_r) and torch.equal(y_mask.cpu(), ym_r), case
+    assert (z.cpu() - z_r).abs().max().item() <= 5e-4 and (z_p.cpu() - zp_r).abs().max().item() <= 5e-4
+    frames = ym_r[:, 0].sum(1).long().tolist()
+    o = o.cpu()
+    for b, n in enumerate(frames):
+        span = 256 * n if case["skip"] else o.shape[2]
+        assert (o[b, :, :span] - o_r[b, :, :span]).abs().max().item() <= 1e-3, (b, case)
+        if case["skip"]:
+            assert (o[b, :, span:] == 0).all()
