@@ -20,6 +20,7 @@
 // the DEFAULT binding of the Python package (openvoice_amd/_lib.py); OPENVOICE_AMD_BINDING=ctypes selects the
 // libtorch-free ctypes binding of the same C ABI.
 #include <ATen/ATen.h>
+#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -62,6 +63,13 @@ struct Ctx {
     TORCH_CHECK(have_dev, name, ": no device tensor among the arguments");
     return static_cast<ov_stream_t>(c10::hip::getCurrentHIPStream(dev.index()).stream());
   }
+};
+
+// The launch happens with the tensors' device current (the library sizes launches for, and launches on, the CURRENT
+// device): a caller holding tensors on cuda:1 while cuda:0 is current gets the same behaviour as any torch op.
+struct DeviceScope {
+  c10::hip::OptionalHIPGuard guard;
+  explicit DeviceScope(const Ctx& c) { if (c.have_dev) guard.set_device(c.dev); }
 };
 
 template <typename E> bool dtype_ok(at::ScalarType s);
@@ -141,6 +149,7 @@ template <typename R, typename... C> struct Wrap<0, R, List<C...>> {
       int i = 0;
       // braced init list: arguments are converted left to right
       std::tuple<C...> v{Arg<C>::get(a, c, i++)...};
+      DeviceScope scope(c);
       const int rc = std::apply([&](C... x) { return Fn(x..., c.stream()); }, v);
       TORCH_CHECK(rc == OV_OK, "ov_", name, " failed: ", ov_strerror(rc));
     }
@@ -226,6 +235,7 @@ void conv1d_f32(const OptTensor& x, const OptTensor& w, const OptTensor& bias, c
   p.x_bstride = ip[17]; p.out_bstride = ip[18]; p.res_bstride = ip[19]; p.add_bstride = ip[20];
   p.out2_bstride = ip[21]; p.bias_b_bstride = ip[22]; p.mask_bstride = ip[23];
   p.in_slope = (float)fp[0]; p.scale = (float)fp[1];
+  DeviceScope scope(c);
   finish(ov_conv1d_f32(&p, c.stream()), "ov_conv1d_f32");
 }
 
@@ -245,6 +255,7 @@ void resblock_pair_f32(const OptTensor& x, const OptTensor& w1, const OptTensor&
   p.dil = (int32_t)ip[5]; p.nwg = (int32_t)ip[6];
   p.x_bstride = ip[7]; p.out_bstride = ip[8]; p.add_bstride = ip[9]; p.col_limit_scale = (int32_t)ip[10];
   p.slope = (float)fp[0]; p.scale = (float)fp[1];
+  DeviceScope scope(c);
   finish(ov_resblock_pair_f32(&p, c.stream()), "ov_resblock_pair_f32");
 }
 
@@ -262,6 +273,7 @@ void wn_layer_f32(const OptTensor& x, const OptTensor& out, const OptTensor& ski
   p.B = (int32_t)ip[0]; p.H = (int32_t)ip[1]; p.T = (int32_t)ip[2]; p.ld = (int32_t)ip[3]; p.K = (int32_t)ip[4];
   p.first = (int32_t)ip[5]; p.last = (int32_t)ip[6]; p.width = (int32_t)ip[7];
   p.bstride = ip[8]; p.cond_bstride = ip[9]; p.mask_bstride = ip[10];
+  DeviceScope scope(c);
   finish(ov_wn_layer_f32(&p, c.stream()), "ov_wn_layer_f32");
 }
 
@@ -278,6 +290,7 @@ void conv1d_bf16cl(const OptTensor& x, const OptTensor& w, const OptTensor& bias
   p.B = (int32_t)ip[0]; p.L = (int32_t)ip[1]; p.Cin = (int32_t)ip[2]; p.Cout = (int32_t)ip[3]; p.K = (int32_t)ip[4];
   p.dil = (int32_t)ip[5]; p.phase_s = (int32_t)ip[6]; p.bias_bstride = (int32_t)ip[7]; p.layout = (int32_t)ip[8];
   p.in_slope = (float)fp[0]; p.scale = (float)fp[1]; p.out_slope = (float)fp[2];
+  DeviceScope scope(c);
   finish(ov_conv1d_bf16cl(&p, c.stream()), "ov_conv1d_bf16cl");
 }
 
@@ -295,6 +308,7 @@ void resblock_pair_bf16cl(const OptTensor& x, const OptTensor& w1, const OptTens
   p.B = (int32_t)ip[0]; p.L = (int32_t)ip[1]; p.C = (int32_t)ip[2]; p.K = (int32_t)ip[3]; p.dil = (int32_t)ip[4];
   p.nwg = (int32_t)ip[5];
   p.slope = (float)fp[0]; p.scale = (float)fp[1];
+  DeviceScope scope(c);
   finish(ov_resblock_pair_bf16cl(&p, c.stream()), "ov_resblock_pair_bf16cl");
 }
 
