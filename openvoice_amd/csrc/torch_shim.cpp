@@ -20,7 +20,7 @@
 // the DEFAULT binding of the Python package (openvoice_amd/_lib.py); OPENVOICE_AMD_BINDING=ctypes selects the
 // libtorch-free ctypes binding of the same C ABI.
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -68,7 +68,7 @@ struct Ctx {
 // The launch happens with the tensors' device current (the library sizes launches for, and launches on, the CURRENT
 // device): a caller holding tensors on cuda:1 while cuda:0 is current gets the same behaviour as any torch op.
 struct DeviceScope {
-  c10::hip::OptionalHIPGuard guard;
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard;   // ROCm torch tensors report DeviceType "cuda"
   explicit DeviceScope(const Ctx& c) { if (c.have_dev) guard.set_device(c.dev); }
 };
 
