@@ -81,6 +81,14 @@ class RespairBf16Params(ctypes.Structure):
                 ("dbg", _fp)]
 
 
+class Respair2Bf16Params(ctypes.Structure):
+    """Mirror of ``ov_respair2_bf16_params`` (include/openvoice_amd.h)."""
+    _fields_ = [("x", _fp), ("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("out", _fp), ("add", _fp),
+                ("B", ctypes.c_int32), ("L", ctypes.c_int32), ("C", ctypes.c_int32), ("K", ctypes.c_int32),
+                ("dil", ctypes.c_int32), ("nwg", ctypes.c_int32), ("slope", ctypes.c_float), ("scale", ctypes.c_float),
+                ("out_slope", ctypes.c_float), ("reserved0", ctypes.c_int32), ("dbg", _fp)]
+
+
 class WnLayerParams(ctypes.Structure):
     """Mirror of ``ov_wn_layer_params`` (include/openvoice_amd.h)."""
     _fields_ = [("x", _fp), ("out", _fp), ("skip", _fp), ("w_in", _fp), ("b_in", _fp), ("cond", _fp), ("w_rs", _fp),
@@ -123,6 +131,8 @@ SIGNATURES = {
     "ov_conv1d_bf16cl": (ctypes.c_int, [ctypes.POINTER(ConvBf16Params), _fp]),
     "ov_resblock_pair_bf16cl": (ctypes.c_int, [ctypes.POINTER(RespairBf16Params), _fp]),
     "ov_resblock_pair_bf16_supported": (ctypes.c_int, [_i, _i, _i]),
+    "ov_resblock_pair2_bf16cl": (ctypes.c_int, [ctypes.POINTER(Respair2Bf16Params), _fp]),
+    "ov_resblock_pair2_bf16_supported": (ctypes.c_int, [_i, _i, _i]),
     "ov_conv_post_tanh_bf16": (ctypes.c_int, [_fp, _fp, _fp, _i, _i, _i, _i, ctypes.c_float, _fp]),
     "ov_frame_hops_f32": (ctypes.c_int, [_fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
     "ov_embed_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, ctypes.c_float, _fp]),
@@ -188,7 +198,7 @@ _ops = None
 # entry points whose return value is a quantity, not an OV_* status
 VALUE_FUNCS = {"ov_version", "ov_build_experiment", "ov_conv1d_pack_size", "ov_conv1d_pack_rows", "ov_wn_pack_size",
                "ov_conv1d_bf16_pack_size", "ov_resblock_pair_supported", "ov_wn_layer_supported", "ov_wn_layer_tile",
-               "ov_resblock_pair_bf16_supported"}
+               "ov_resblock_pair_bf16_supported", "ov_resblock_pair2_bf16_supported"}
 
 
 def binding():

@@ -67,7 +67,38 @@ def launch_pair_bf16(c1, c2, x, out, add=None, scale=1.0, slope=0.1, nwg=0, dbg=
     _lib.check(_lib.load().ov_resblock_pair_bf16cl(ctypes.byref(p), stream), "ov_resblock_pair_bf16cl")
 
 
+def launch_pair2_bf16(c1, c2, x, out, add=None, scale=1.0, slope=0.1, out_slope=1.0, nwg=0, dbg=None):
+    """One fused ResBlock1 iteration of the matrix-bound stages (``ov_resblock_pair2_bf16cl``, C in {64, 128}) on
+    bf16 channels-last tensors stored ACTIVATED: ``x`` = bf16(lrelu(x_raw, slope));
+    out = bf16(lrelu((c2(bf16(lrelu(c1(x) + b1))) + b2 + x_raw [+ add]) * scale, out_slope)), ``add`` raw.
+    x / out / add (B, L, C) contiguous bfloat16; ``out`` must not alias ``x``."""
+    B, L, C = x.shape
+    assert c1.cin == c1.cout == c2.cin == c2.cout == C and c1.K == c2.K and c2.dil == 1 and out.shape == x.shape
+    for t in (x, out, add):
+        assert t is None or (t.dtype == torch.bfloat16 and t.is_contiguous())
+    if _lib.use_torch_binding():
+        _lib.torch_op("resblock_pair2_bf16cl", x, c1.w, c1.bias, c2.w, c2.bias, out, add, dbg,
+                      [B, L, C, c1.K, c1.dil, nwg], [slope, scale, out_slope])
+        return
+    p = _lib.Respair2Bf16Params()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    p.x, p.w1, p.b1, p.w2, p.b2, p.out, p.add = vp(x), vp(c1.w), vp(c1.bias), vp(c2.w), vp(c2.bias), vp(out), vp(add)
+    p.B, p.L, p.C, p.K, p.dil, p.nwg = B, L, C, c1.K, c1.dil, nwg
+    p.slope, p.scale, p.out_slope = slope, scale, out_slope
+    p.dbg = vp(dbg)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(_lib.load().ov_resblock_pair2_bf16cl(ctypes.byref(p), stream), "ov_resblock_pair2_bf16cl")
+
+
 _pair_supported = {}
+_pair2_supported = {}
+
+
+def pair2_bf16_supported(C, K, dil):
+    key = (C, K, dil)
+    if key not in _pair2_supported:
+        _pair2_supported[key] = bool(_lib.call("ov_resblock_pair2_bf16_supported", C, K, dil))
+    return _pair2_supported[key]
 
 
 def pair_bf16_supported(C, K, dil):
@@ -109,7 +140,7 @@ def generator_alg_bytes(cfg, B, T, esize=2, z_channels=192, fused=True):
         tensor = B * L * ch * esize
         passes = 1                                                  # the ups write
         for j, (k, rd) in enumerate(zip(kernels, dils)):
-            one = fused and all(pair_bf16_supported(ch, k, d) for d in rd)
+            one = fused and all(pair_bf16_supported(ch, k, d) or pair2_bf16_supported(ch, k, d) for d in rd)
             passes += len(rd) * (2 if one else 5) + (1 if j > 0 else 0)
         total += tensor * passes
     return total + B * L * ch * esize + B * L * 4
@@ -156,6 +187,11 @@ class GeneratorBf16:
         # t = bf16(lrelu(v))), which can differ from that by one bf16 ulp of t on negative values -- fuse_pairs on / off
         # therefore agree within bf16 rounding, not bit for bit (tests/test_gpu_bf16_pair.py)
         self.fuse_pairs = True
+        # Stages whose every ResBlock pair has a second-generation fused instance (csrc/conv1d_bf16_pair2.hip: C = 64 /
+        # 128, every kernel size) keep their tensors ACTIVATED in HBM: the ConvTranspose stores lrelu(u), each pair
+        # stores lrelu(x_n), the residual add inverts it in fp32, the chains' sums stay raw (round 4).  False = the
+        # round-3 launch sequence (first-generation pairs where they exist, two launches elsewhere).
+        self.act_hbm = True
         # independent ResBlock chains of a stage on this many HIP streams (1 = one stream, the serial order).  Measured
         # (round 3, batch 64): 3 streams 45.46 ms vs 45.86 ms on one -- a launch of 2 workgroups per CU owns the chip,
         # so kernels of different streams overlap only at their ramps and tails -- 0.9 %, not worth a default that makes
@@ -216,7 +252,9 @@ class GeneratorBf16:
             s = up["stride"]
             cin, ch = ch, ch // 2
             u = free.pop()[: B * L * s * ch].view(B, L * s, ch)
-            _launch(up["conv"], cur_x, u, L, in_slope=LRELU_SLOPE, phase_s=s)
+            act = (self.act_hbm and self.fuse_pairs and
+                   all(pair2_bf16_supported(ch, c1.K, c1.dil) for pairs in self.resblocks[i] for c1, _ in pairs))
+            _launch(up["conv"], cur_x, u, L, in_slope=LRELU_SLOPE, phase_s=s, out_slope=LRELU_SLOPE if act else 1.0)
             L *= s
             acc = free.pop()[: B * L * ch].view(B, L, ch)
             nchains = nk if concurrent else 1
@@ -232,7 +270,11 @@ class GeneratorBf16:
                 last = n == npairs - 1
                 add = acc if (last and j > 0) else None
                 scale = 1.0 / nk if (last and j == nk - 1) else 1.0
-                if fused[j]:       # one launch per pair, intermediate in LDS; out must not alias x: ra / t1 ping-pong
+                if act:            # activated tensors between the launches; the chain's last output (a sum) stays raw
+                    dst = acc if last else (t1 if cur[j] is ra else ra)
+                    launch_pair2_bf16(c1, c2, cur[j], dst, add=add, scale=scale, slope=LRELU_SLOPE,
+                                      out_slope=1.0 if last else LRELU_SLOPE)
+                elif fused[j]:       # one launch per pair, intermediate in LDS; out must not alias x: ra / t1 ping-pong
                     dst = acc if last else (t1 if cur[j] is ra else ra)
                     launch_pair_bf16(c1, c2, cur[j], dst, add=add, scale=scale, slope=LRELU_SLOPE)
                 else:

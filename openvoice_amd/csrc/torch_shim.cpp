@@ -312,6 +312,24 @@ void resblock_pair_bf16cl(const OptTensor& x, const OptTensor& w1, const OptTens
   finish(ov_resblock_pair_bf16cl(&p, c.stream()), "ov_resblock_pair_bf16cl");
 }
 
+// ip = [B, L, C, K, dil, nwg];  fp = [slope, scale, out_slope]
+void resblock_pair2_bf16cl(const OptTensor& x, const OptTensor& w1, const OptTensor& b1, const OptTensor& w2,
+                           const OptTensor& b2, const OptTensor& out, const OptTensor& add, const OptTensor& dbg,
+                           at::IntArrayRef ip, at::ArrayRef<double> fp) {
+  TORCH_CHECK(ip.size() == 6 && fp.size() == 3, "openvoice_amd::resblock_pair2_bf16cl: 6 integer and 3 float parameters");
+  Ctx c{"resblock_pair2_bf16cl", false};
+  ov_respair2_bf16_params p{};
+  p.x = sptr<uint16_t>(x, c, 0); p.w1 = sptr<uint16_t>(w1, c, 1); p.b1 = sptr<float>(b1, c, 2);
+  p.w2 = sptr<uint16_t>(w2, c, 3); p.b2 = sptr<float>(b2, c, 4); p.out = sptr<uint16_t>(out, c, 5);
+  p.add = sptr<uint16_t>(add, c, 6);
+  p.dbg = sptr<unsigned long long>(dbg, c, 7);
+  p.B = (int32_t)ip[0]; p.L = (int32_t)ip[1]; p.C = (int32_t)ip[2]; p.K = (int32_t)ip[3]; p.dil = (int32_t)ip[4];
+  p.nwg = (int32_t)ip[5];
+  p.slope = (float)fp[0]; p.scale = (float)fp[1]; p.out_slope = (float)fp[2];
+  DeviceScope scope(c);
+  finish(ov_resblock_pair2_bf16cl(&p, c.stream()), "ov_resblock_pair2_bf16cl");
+}
+
 }  // namespace
 
 TORCH_LIBRARY(openvoice_amd, m) {
@@ -326,6 +344,8 @@ TORCH_LIBRARY(openvoice_amd, m) {
         "int[] ip, float[] fp) -> ()", &conv1d_bf16cl);
   m.def("resblock_pair_bf16cl(Tensor? x, Tensor? w1, Tensor? b1, Tensor? w2, Tensor? b2, Tensor(a!)? out, Tensor? add, "
         "Tensor(b!)? dbg, int[] ip, float[] fp) -> ()", &resblock_pair_bf16cl);
+  m.def("resblock_pair2_bf16cl(Tensor? x, Tensor? w1, Tensor? b1, Tensor? w2, Tensor? b2, Tensor(a!)? out, Tensor? add, "
+        "Tensor(b!)? dbg, int[] ip, float[] fp) -> ()", &resblock_pair2_bf16cl);
   // ---- device entry points with flat argument lists (schema derived from the C prototype)
   bind_device<&ov_frame_hops_f32>(m, "frame_hops_f32");
   bind_device<&ov_conv_post_tanh_f32>(m, "conv_post_tanh_f32");
@@ -358,6 +378,7 @@ TORCH_LIBRARY(openvoice_amd, m) {
   bind_value<&ov_wn_layer_supported>(m, "wn_layer_supported");
   bind_value<&ov_wn_layer_tile>(m, "wn_layer_tile");
   bind_value<&ov_resblock_pair_bf16_supported>(m, "resblock_pair_bf16_supported");
+  bind_value<&ov_resblock_pair2_bf16_supported>(m, "resblock_pair2_bf16_supported");
   bind_value<&ov_version>(m, "version");
   bind_value<&ov_build_experiment>(m, "build_experiment");
 }

@@ -167,6 +167,27 @@ def test_respair_bf16_params_struct_matches_header_field_order():
     assert lib.ov_resblock_pair_bf16_supported(32, 11, 5) == 1 and lib.ov_resblock_pair_bf16_supported(64, 7, 1) == 0
 
 
+def test_respair2_bf16_params_struct_matches_header_field_order():
+    header = open(os.path.join(REPO, "include", "openvoice_amd.h")).read()
+    body = header[header.index("typedef struct ov_respair2_bf16_params {"):header.index("} ov_respair2_bf16_params;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        first, *rest = decl.split(",")
+        names.append(re.findall(r"(\w+)$", first.strip())[0])
+        names += [r.strip() for r in rest]
+    assert names == [f[0] for f in _lib.Respair2Bf16Params._fields_]
+    import ctypes
+    assert ctypes.sizeof(_lib.Respair2Bf16Params) == 104      # 7 pointers, 6 int32, 3 float, 1 int32, 1 pointer
+    lib = _lib.load()
+    assert lib.ov_resblock_pair2_bf16cl(None, None) == -1
+    assert lib.ov_resblock_pair2_bf16_supported(128, 11, 5) == 1 and lib.ov_resblock_pair2_bf16_supported(64, 3, 1) == 1
+    assert lib.ov_resblock_pair2_bf16_supported(32, 3, 1) == 0 and lib.ov_resblock_pair2_bf16_supported(256, 7, 1) == 0
+
+
 def test_every_header_function_is_bound_and_exported():
     """Every `int|size_t ov_*(...)` declared in include/openvoice_amd.h is in _lib.SIGNATURES and exported by the .so."""
     header = open(os.path.join(REPO, "include", "openvoice_amd.h")).read()
