@@ -417,13 +417,15 @@ typedef struct ov_respair_bf16_params {
 int ov_resblock_pair_bf16cl(const ov_respair_bf16_params* p, ov_stream_t stream);
 int ov_resblock_pair_bf16_supported(int C, int K, int dil);
 
-/* One ResBlock1 iteration in ONE launch for the matrix-bound stages (C in {64, 128}), second generation
+/* One ResBlock1 iteration in ONE launch (C in {32, 64, 128}), second generation
  * (csrc/conv1d_bf16_pair2.hip).  Tensors between these launches are stored ACTIVATED:
  *   x   = bf16(lrelu(x_raw, slope))  [B][L][C]            (the producer applied the leaky ReLU before rounding)
  *   t   = bf16(lrelu(c1(x) + b1, slope))                   (never leaves the CU)
- *   out = bf16(act((c2(t) + b2 + x~ [+ add]) * scale)),    x~ = x >= 0 ? x : x / slope  (exact inverse in fp32),
+ *   out = bf16(act((c2(t) + b2 + x~) * scale)),            x~ = x >= 0 ? x : x / slope  (exact inverse in fp32),
  *         act = leaky ReLU with out_slope (1.0f: the raw sum, for a tensor that is consumed as `add` or by a kernel
- *         that activates on load), `add` is a RAW tensor.
+ *         that activates on load);
+ *   with `add` (a RAW tensor, the MRF running sum; out_slope must be 0 / 1):
+ *   out = bf16((bf16(c2(t) + b2 + x~) + add) * scale).
  * reference openvoice/modules.py:296-306, models.py:280-286.  w1 / w2 from ov_conv1d_bf16_pack(C, C, K), b1 / b2 fp32
  * [C].  out must not alias x; add may alias out. */
 typedef struct ov_respair2_bf16_params {
@@ -439,8 +441,9 @@ typedef struct ov_respair2_bf16_params {
   float slope;          /* leaky-ReLU slope of x and t, 0 < slope <= 1 */
   float scale;
   float out_slope;      /* 0 or 1.0f = store the raw sum */
-  int32_t reserved0;
-  unsigned long long* dbg; /* measurement only, NULL in production: [workgroups][4 matrix waves][8] ticks per phase */
+  int32_t exp_flags;    /* 0 in production.  MEASUREMENT ONLY: bit 0 = the loader waves idle after the first tile (wrong
+                         * results), bit 1 = 16-deep weight ring where instantiated */
+  unsigned long long* dbg; /* measurement only, NULL in production: [workgroups][4 matrix + 4 loader waves][8] ticks per phase */
 } ov_respair2_bf16_params;
 int ov_resblock_pair2_bf16cl(const ov_respair2_bf16_params* p, ov_stream_t stream);
 int ov_resblock_pair2_bf16_supported(int C, int K, int dil);

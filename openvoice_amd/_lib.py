@@ -86,7 +86,7 @@ class Respair2Bf16Params(ctypes.Structure):
     _fields_ = [("x", _fp), ("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("out", _fp), ("add", _fp),
                 ("B", ctypes.c_int32), ("L", ctypes.c_int32), ("C", ctypes.c_int32), ("K", ctypes.c_int32),
                 ("dil", ctypes.c_int32), ("nwg", ctypes.c_int32), ("slope", ctypes.c_float), ("scale", ctypes.c_float),
-                ("out_slope", ctypes.c_float), ("reserved0", ctypes.c_int32), ("dbg", _fp)]
+                ("out_slope", ctypes.c_float), ("exp_flags", ctypes.c_int32), ("dbg", _fp)]
 
 
 class WnLayerParams(ctypes.Structure):

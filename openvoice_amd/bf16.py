@@ -67,7 +67,7 @@ def launch_pair_bf16(c1, c2, x, out, add=None, scale=1.0, slope=0.1, nwg=0, dbg=
     _lib.check(_lib.load().ov_resblock_pair_bf16cl(ctypes.byref(p), stream), "ov_resblock_pair_bf16cl")
 
 
-def launch_pair2_bf16(c1, c2, x, out, add=None, scale=1.0, slope=0.1, out_slope=1.0, nwg=0, dbg=None):
+def launch_pair2_bf16(c1, c2, x, out, add=None, scale=1.0, slope=0.1, out_slope=1.0, nwg=0, dbg=None, exp_flags=0):
     """One fused ResBlock1 iteration of the matrix-bound stages (``ov_resblock_pair2_bf16cl``, C in {64, 128}) on
     bf16 channels-last tensors stored ACTIVATED: ``x`` = bf16(lrelu(x_raw, slope));
     out = bf16(lrelu((c2(bf16(lrelu(c1(x) + b1))) + b2 + x_raw [+ add]) * scale, out_slope)), ``add`` raw.
@@ -78,13 +78,13 @@ def launch_pair2_bf16(c1, c2, x, out, add=None, scale=1.0, slope=0.1, out_slope=
         assert t is None or (t.dtype == torch.bfloat16 and t.is_contiguous())
     if _lib.use_torch_binding():
         _lib.torch_op("resblock_pair2_bf16cl", x, c1.w, c1.bias, c2.w, c2.bias, out, add, dbg,
-                      [B, L, C, c1.K, c1.dil, nwg], [slope, scale, out_slope])
+                      [B, L, C, c1.K, c1.dil, nwg, exp_flags], [slope, scale, out_slope])
         return
     p = _lib.Respair2Bf16Params()
     vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     p.x, p.w1, p.b1, p.w2, p.b2, p.out, p.add = vp(x), vp(c1.w), vp(c1.bias), vp(c2.w), vp(c2.bias), vp(out), vp(add)
     p.B, p.L, p.C, p.K, p.dil, p.nwg = B, L, C, c1.K, c1.dil, nwg
-    p.slope, p.scale, p.out_slope = slope, scale, out_slope
+    p.slope, p.scale, p.out_slope, p.exp_flags = slope, scale, out_slope, exp_flags
     p.dbg = vp(dbg)
     stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(_lib.load().ov_resblock_pair2_bf16cl(ctypes.byref(p), stream), "ov_resblock_pair2_bf16cl")

@@ -1,9 +1,10 @@
-// Fused ResBlock1 pair for the MATRIX-bound stages of the bf16 generator (C = 64 / 128; BASELINE.json configs[4],
+// Fused ResBlock1 pair of the bf16 generator's MRF stages (C = 32 / 64 / 128; BASELINE.json configs[4],
 // SURVEY.md section 8f item 3), second generation.  reference: openvoice/modules.py:296-306 (loop body of
 // ResBlock1.forward), models.py:280-286 (MRF sum / mean).
 //
 //   t   = bf16( lrelu( c1(xa) + b1 ) )                                   xa = lrelu(x): the input is stored ACTIVATED
-//   out = bf16( act_out( (c2(t) + b2 + x~ [+ add]) * scale ) )           x~ = xa >= 0 ? xa : xa / slope
+//   out = bf16( act_out( (c2(t) + b2 + x~) * scale ) )                   x~ = xa >= 0 ? xa : xa / slope
+//   with the MRF running sum:  out = bf16( (bf16(c2(t) + b2 + x~) + add) * scale )
 //
 // What bounded the first generation (conv1d_bf16.hip as two launches per pair; profiles/r02_s14, r03_s11): per 128-row
 // tile a matrix wave spent 20 % of its time at the 32/64-channel chunk hand-offs, 17 % moving the tile out, 15 % in the
@@ -29,6 +30,10 @@
 
 #include "openvoice_amd.h"
 
+#ifndef OV_EXP
+#define OV_EXP 0   // measurement builds only (scripts/exp_pair2.sh; results meaningless, the binding refuses them):
+#endif             // 10 = no weight requests in the k-loops, 11 = no LDS operand reads, 12 = neither, 13 = no MFMAs
+
 namespace ovk16q {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -40,14 +45,37 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int NMW = 4;       // matrix waves: one per SIMD
-constexpr int NLD = 2;       // loader waves: LDS-DMA in, whole-row stores out
-constexpr int WD = 8;        // weight-fragment ring: requests run WD - 1 k-steps (of 4 MFMAs) ahead
+constexpr int NLD = 4;       // loader waves (one per SIMD, so every matrix wave has the same company): LDS-DMA in, whole-row stores out
 
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {       // one v_cvt_pk_bf16_f32, round to nearest even
   const bf16x2 h = __builtin_convertvector(f32x2{lo, hi}, bf16x2);
   uint32_t u;
   __builtin_memcpy(&u, &h, 4);
   return u;
+}
+
+// max / min without fmaxf()'s canonicalisation of both operands (three instructions per value)
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmin(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// leaky ReLU for 0 < slope <= 1: max(v, slope v); its inverse for inv = 1 / slope >= 1: min(v, inv v)
+__device__ __forceinline__ f32x2 lrelu2(f32x2 v, float slope) {
+  const f32x2 sv = v * slope;              // v_pk_mul_f32
+  return f32x2{vmax(v[0], sv[0]), vmax(v[1], sv[1])};
+}
+__device__ __forceinline__ f32x2 unlrelu2(f32x2 v, float inv) {
+  const f32x2 sv = v * inv;
+  return f32x2{vmin(v[0], sv[0]), vmin(v[1], sv[1])};
+}
+__device__ __forceinline__ f32x2 unpack2(uint32_t w) {
+  return f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
 }
 
 // (utterance, step) sequence of one workgroup with the warm-up pseudo-step at a mid-utterance start (the tile before
@@ -74,10 +102,11 @@ struct Seq {
 // 16-byte positions of the 256-byte LDS bank row.
 template <int SPR>
 __device__ __forceinline__ int swz(int row) {
-  return SPR >= 16 ? (row & 15) : ((row >> 1) & 7);
+  return SPR >= 16 ? (row & 15) : (SPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3));
 }
 
-template <int K, int DIL, int C>
+// WD: depth of the weight-fragment ring -- requests run WD - 1 k-steps (of 4 MFMAs = 128 matrix cycles) ahead
+template <int K, int DIL, int C, int WD>
 struct Geo {
   static constexpr int NCT = C / 32;                 // 32-channel output tiles = matrix waves along channels
   static constexpr int NTG = NMW / NCT;              // matrix waves along time
@@ -93,14 +122,14 @@ struct Geo {
   static constexpr int RH = TT + 2 * P2;             // its rows: [2 P2 rows of left context | TT new rows]
   static constexpr int S = NCH * K * 2;              // k-steps (16 input channels x one tap) of one conv
   static constexpr int SMEM = 2 * XB + RH * PH + 2 * C * 4;
-  static_assert(NCT * NTG == NMW && (C == 64 || C == 128), "4 matrix waves of 128 x 32");
+  static_assert(NCT * NTG == NMW && (C == 32 || C == 64 || C == 128), "4 matrix waves of 128 x 32");
   static_assert((2 * S) % WD == 0, "the weight ring slot of every k-step must be static");
   static_assert(SMEM <= 160 * 1024, "LDS");
 };
 
-template <int K, int DIL, int C>
+template <int K, int DIL, int C, int WD>
 __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const ov_respair2_bf16_params p) {
-  using G = Geo<K, DIL, C>;
+  using G = Geo<K, DIL, C, WD>;
   constexpr int TT = G::TT, NCH = G::NCH, P1 = G::P1, P2 = G::P2, DELTA = G::DELTA, P = G::P, SPR = G::SPR;
   constexpr int R1 = G::R1, NBLK = G::NBLK, XB = G::XB, PH = G::PH, RH = G::RH, S = G::S, NCT = G::NCT;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[G::SMEM];
@@ -122,34 +151,124 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
     // start the DMA of the input tile of q + 1 into that same buffer.  Both passes deal the buffer's 1 KiB blocks to
     // the loader waves the same way, so a wave only ever overwrites blocks it has itself finished reading.
     const int lw = wave - NMW;
+    const bool idle = (p.exp_flags & 1) != 0;   // MEASUREMENT ONLY (wrong results): no staging after the first tile
     // the packer's trailing all-zero record: source of every vector outside [0, L)
     const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(p.w1) + (size_t)NCT * NCH * K * 2 * 1024;
+    // Block blk of a tile buffer = rows [blk RPB, (blk + 1) RPB); lane -> (row lrow of the block, physical slot sp).
+    // Byte offset of the lane's vector from the tile's first row IN THE TENSOR (source of the DMA, destination of the
+    // store): blk * 1024 + lrow * P + 16 * (sp ^ g(row)), and g(row) only depends on blk % NPH = lw % NPH: one per-lane constant.
+    // (The loaders share their SIMDs with the matrix waves: every VALU instruction here is taken from a matrix
+    // wave's issue slots -- profiles/r04_s3: ~1 000 per step cost its SIMD-mates 3 000 ticks of c1.)
+    constexpr int RPB = G::RPB, NPH = 16 / RPB;
+    const int lrow = lane / SPR, sp = lane % SPR;
+    static_assert(NLD % NPH == 0, "a loader wave's blocks (blk % NLD == lw) all share one swizzle phase");
+    const uint32_t dof = (uint32_t)(lrow * P + 16 * (sp ^ swz<SPR>((lw % NPH) * RPB + lrow)));
+    const uint32_t lds_lane = (uint32_t)(lane * 16);
+    // Tiles whose rows all lie inside [0, L) -- all but the first and last one or two of an utterance -- take a path
+    // WITHOUT vector ALU instructions: wave-uniform base (SALU) + the constant per-lane offset `dof`.  The matrix wave
+    // on this SIMD runs at a higher priority and always has an MFMA waiting for the pipe, i.e. a claim on the VALU
+    // issue slot: every VALU instruction of a loader waits for a gap (profiles/r04_s7: 80 loader instructions took
+    // 2 400-10 800 ticks and the matrix waves then waited for the loaders at barrier B).
+    typedef const __attribute__((address_space(1))) unsigned char* gc_ptr;
+    typedef __attribute__((address_space(1))) unsigned char* gm_ptr;
+    typedef __attribute__((address_space(3))) unsigned char* lds_ptr;
     auto dma = [&](int buf, int b, int tile) {
-      const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.x) + (size_t)b * L * P;
       const int tbase = tile * TT - P1;
+      const gc_ptr xb = (gc_ptr)(p.x) + ((int64_t)b * L + tbase) * P + lw * 1024;                          // (uniform)
+      const lds_ptr lb = (lds_ptr)(xs) + buf * XB + lw * 1024;                                            // (uniform)
+      if (tbase >= 0 && tbase + NBLK * RPB <= L) {
 #pragma unroll
-      for (int blk = lw; blk < NBLK; blk += NLD) {
-        const int U = blk * 64 + lane;
-        const int row = U / SPR, sp = U % SPR;
-        const int t = tbase + row;
-        const bool ok = row < R1 && t >= 0 && t < L;
-        const unsigned char* src = ok ? xb + ((size_t)t * P + (size_t)((sp ^ swz<SPR>(row)) * 16)) : zsrc;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(xs + buf * XB + U * 16), 16, 0, 0);
+        for (int j = 0; j < (NBLK + NLD - 1) / NLD; ++j)
+          if (j * NLD + lw < NBLK) {
+            gc_ptr bj = xb + j * (NLD * 1024);
+            asm volatile("" : "+s"(bj));     // opaque per block: scalar base + per-lane offset, no 64-bit vector adds
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bj + dof),
+                                             (__attribute__((address_space(3))) void*)(lb + j * (NLD * 1024)), 16, 0, 0);
+          }
+        return;
+      }
+#pragma unroll
+      for (int j = 0; j < (NBLK + NLD - 1) / NLD; ++j) {
+        const int blk = j * NLD + lw;
+        if (blk < NBLK) {
+          const int row = blk * RPB + lrow;
+          const int t = tbase + row;
+          const bool ok = row < R1 && t >= 0 && t < L;
+          const gc_ptr src = ok ? xb + j * (NLD * 1024) + dof : (gc_ptr)zsrc;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(lb + j * (NLD * 1024)), 16, 0, 0);
+        }
       }
     };
     constexpr int SB0 = DELTA * SPR / 64, SB1 = ((DELTA + TT) * SPR + 63) / 64;   // blocks that hold output rows
-    auto store = [&](int buf, int b, int tile) {
-      unsigned char* ob = reinterpret_cast<unsigned char*>(p.out) + (size_t)b * L * P;
+    constexpr int J0 = SB0 / NLD, J1 = (SB1 + NLD - 1) / NLD, NSB = J1 - J0;      // ... of one loader wave: j in [J0, J1)
+    // The MRF running sum (`add`) is applied HERE, on the way out: the matrix waves leave bf16(c2 + b2 + x~) in the
+    // tile, the loaders read the same rows of `add` as whole 16-byte vectors (requested a step earlier, right after
+    // the next tile's DMA) and store bf16((tile + add) * scale).  Read in the accumulator layout by the matrix waves
+    // it was 16 eight-byte loads per lane of 16 contiguous bytes per row, sitting in the same in-order vmcnt queue as
+    // the weight ring: launches with `add` ran 0.2-0.3 ms longer (profiles/r04_s4).
+    const bool has_add = p.add != nullptr;
+    const float scale = p.scale;
+    u32x4 addq[NSB];
+    // rows of the lane that belong to the output window [DELTA, DELTA + TT): all of them except in the first / last block
+    auto row_in_window = [&](int blk) { const int row = blk * RPB + lrow; return row >= DELTA && row < DELTA + TT; };
+    auto add_request = [&](int b, int tile) {
       const int tbase = tile * TT - P2 - DELTA;
+      const gc_ptr ab = (gc_ptr)(p.add) + ((int64_t)b * L + tbase) * P + lw * 1024;                       // (uniform)
+      const bool interior = tbase + DELTA >= 0 && tbase + DELTA + TT <= L;
 #pragma unroll
-      for (int blk = SB0 + ((lw - SB0) & (NLD - 1)); blk < SB1; blk += NLD) {   // blk % NLD == lw, as in dma()
-        const int U = blk * 64 + lane;
-        const int row = U / SPR, sp = U % SPR;
-        const int t = tbase + row;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(xs + buf * XB + U * 16);
-        if (row >= DELTA && row < DELTA + TT && t >= 0 && t < L)
-          *reinterpret_cast<u32x4*>(ob + ((size_t)t * P + (size_t)((sp ^ swz<SPR>(row)) * 16))) = v;
+      for (int j = J0; j < J1; ++j) {
+        const int blk = j * NLD + lw;
+        bool ok = blk >= SB0 && blk < SB1;
+        if (!interior || blk == SB0 || blk == SB1 - 1) {
+          const int t = tbase + blk * RPB + lrow;
+          ok = ok && row_in_window(blk) && t >= 0 && t < L;
+          addq[j - J0] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(ok ? ab + j * (NLD * 1024) + dof : (gc_ptr)zsrc);
+        } else if (ok) {
+          addq[j - J0] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(ab + j * (NLD * 1024) + dof);
+        }
+      }
+    };
+    // The output tile leaves in two halves: LDS -> registers right after barrier A (that frees the buffer for the
+    // next DMA at once), registers -> HBM after barrier B.  A 1 KiB store instruction holds the issuing wave for ~300
+    // cycles (the CU's memory pipe drains at ~10 B / cycle, MI355X guide): issued before the DMA and before barrier B,
+    // the eight stores of a loader wave delayed both (profiles/r04_s9: store pass 2 400 ticks per step at any priority).
+    u32x4 ov[NSB];
+    auto fetch_tile = [&](int buf) {
+      const unsigned char* lb = xs + buf * XB + lw * 1024 + lds_lane;
+#pragma unroll
+      for (int j = J0; j < J1; ++j) {                                            // blk % NLD == lw, as in dma()
+        const int blk = j * NLD + lw;
+        if (blk >= SB0 && blk < SB1) ov[j - J0] = *reinterpret_cast<const u32x4*>(lb + j * (NLD * 1024));
+      }
+    };
+    auto store = [&](int b, int tile) {
+      const int tbase = tile * TT - P2 - DELTA;
+      const gm_ptr ob = (gm_ptr)(p.out) + ((int64_t)b * L + tbase) * P + lw * 1024;                        // (uniform)
+      const bool interior = tbase + DELTA >= 0 && tbase + DELTA + TT <= L;
+      if (has_add) {
+#pragma unroll
+        for (int j = J0; j < J1; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x2 r = (unpack2(ov[j - J0][e]) + unpack2(addq[j - J0][e])) * scale;
+            ov[j - J0][e] = pack2(r[0], r[1]);
+          }
+      }
+#pragma unroll
+      for (int j = J0; j < J1; ++j) {
+        const int blk = j * NLD + lw;
+        if (blk >= SB0 && blk < SB1) {
+          gm_ptr bj = ob + j * (NLD * 1024);
+          asm volatile("" : "+s"(bj));
+          __attribute__((address_space(1))) u32x4* dst = reinterpret_cast<__attribute__((address_space(1))) u32x4*>(bj + dof);
+          if (interior && blk != SB0 && blk != SB1 - 1) {
+            *dst = ov[j - J0];
+          } else {
+            const int t = tbase + blk * RPB + lrow;
+            if (row_in_window(blk) && t >= 0 && t < L) *dst = ov[j - J0];
+          }
+        }
       }
     };
     Seq cur(g0, g1, nsteps);                 // the pseudo-step whose barrier A comes next
@@ -157,26 +276,53 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
     nxt.advance();
     dma(0, cur.b, cur.tile());
     __builtin_amdgcn_s_barrier();                            // (init: the matrix waves have zeroed the t tile)
+    // measurement only (p.dbg): ticks 0 waiting for the DMA / stores, 1 at barrier A, 2 tile -> registers, 3 DMA issue,
+    // 4 at barrier B, 6 stores (+ add requests), 5 at barrier C
+    const bool ldbg = p.dbg != nullptr;
+    unsigned long long lt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, llast = ldbg ? __builtin_readcyclecounter() : 0ull;
+    auto lmark = [&](int ph) {
+      if (ldbg) {
+        const unsigned long long now = __builtin_readcyclecounter();
+        lt[ph] += now - llast;
+        llast = now;
+      }
+    };
     int prev_b = 0, prev_tile = 0, q = 0;
     bool prev_real = false;
     for (; cur.valid(); ++q) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of tile q has landed (and its stores left)
+      lmark(0);
       __builtin_amdgcn_s_barrier();                          // A(q)
-      if (prev_real) store((q + 1) & 1, prev_b, prev_tile);  // output tile of q - 1, built in place in ITS input buffer
+      lmark(1);
+      const bool out_now = prev_real && !idle;
+      if (out_now) fetch_tile((q + 1) & 1);                  // output tile of q - 1, built in place in ITS input buffer
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every LDS read of that buffer has returned
-      if (nxt.valid()) dma((q + 1) & 1, nxt.b, nxt.tile());
+      lmark(2);
+      if (nxt.valid() && !idle) dma((q + 1) & 1, nxt.b, nxt.tile());
+      lmark(3);
       __builtin_amdgcn_s_barrier();                          // B(q)
+      lmark(4);
+      if (out_now) store(prev_b, prev_tile);
+      if (has_add && !cur.warm) add_request(cur.b, cur.tile());   // consumed after B(q + 1)
+      lmark(6);
       __builtin_amdgcn_s_barrier();                          // C(q)
+      lmark(5);
       prev_real = !cur.warm; prev_b = cur.b; prev_tile = cur.tile();
       cur = nxt;
       nxt.advance();
     }
     __builtin_amdgcn_s_barrier();                            // A(end): the last output tile is complete
-    if (prev_real) store((q + 1) & 1, prev_b, prev_tile);
+    if (prev_real) { fetch_tile((q + 1) & 1); store(prev_b, prev_tile); }
+    if (ldbg && lane == 0) {
+      lt[7] = (unsigned long long)q;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) p.dbg[((size_t)blockIdx.x * (NMW + NLD) + wave) * 8 + k] = lt[k];
+    }
     return;
   }
 
   // ================================== matrix waves ================================================
+  __builtin_amdgcn_s_setprio(2);                     // ahead of the loader wave on the same SIMD at every issue
   const int half = lane >> 5, l31 = lane & 31;
   const int nt = wave % NCT, tg = wave / NCT;        // this wave's output-channel tile / time group
   const int trow0 = 128 * tg;
@@ -205,6 +351,7 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
   };
 #pragma unroll
   for (int q = 0; q < WD - 1; ++q) wq[q] = wnext(q);
+  wq[WD - 1] = wq[0];
 
   // per-lane LDS offsets of c1's B operand (input tile): row trow0 + l31 + tap DIL (+ 32 i), logical slot
   // 4 c + 2 kb + half  ->  byte (row * P + 16 * (half ^ g(row)))  ^  (64 c + 32 kb)
@@ -234,9 +381,10 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
       tlast = now;
     }
   };
-  const float slope = p.slope, inv_slope = 1.0f / p.slope, scale = p.scale;
+  const bool has_add = p.add != nullptr;              // then the loader waves add it and scale (see above)
+  const float slope = p.slope, inv_slope = 1.0f / p.slope, scale = has_add ? 1.0f : p.scale;
   const float oslope = p.out_slope > 0.f ? p.out_slope : 1.f;
-  const bool has_add = p.add != nullptr;
+  const bool scaled = scale != 1.0f, act_out = oslope != 1.0f;    // (uniform; the epilogue skips what is an identity)
 
   __syncthreads();                                    // (init: t tile zeroed, biases in LDS)
   if (dbg) tlast = __builtin_readcyclecounter();
@@ -277,86 +425,80 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
     {
       u32x4 aq[2][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) aq[0][i] = *reinterpret_cast<const u32x4*>(xs + xlb[0] + i * 32 * P);
+      for (int i = 0; i < 4; ++i) aq[0][i] = aq[1][i] = *reinterpret_cast<const u32x4*>(xs + xlb[0] + i * 32 * P);
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        wq[(s + WD - 1) % WD] = wnext(s + WD - 1);
-        if (s + 1 < S) {
+        if (OV_EXP != 10 && OV_EXP != 12) wq[(s + WD - 1) % WD] = wnext(s + WD - 1);
+        if (s + 1 < S && OV_EXP != 11 && OV_EXP != 12) {
           const int c = (s + 1) / (2 * K), tap = ((s + 1) / 2) % K, kb = (s + 1) & 1;
           const uint32_t a = xlb[tap] ^ (uint32_t)(64 * c + 32 * kb);
 #pragma unroll
           for (int i = 0; i < 4; ++i) aq[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(xs + a + i * 32 * P);
         }
         __builtin_amdgcn_sched_barrier(0);
+        // ONE wait for the step's four operands (issued a step ago; the four just issued stay in flight): hipcc's own
+        // staggered lgkmcnt(7 .. 4) puts an instruction between every two MFMAs, ~6 cycles each (MI355X guide)
+        if (s + 1 < S) __builtin_amdgcn_s_waitcnt(0xC47F); else __builtin_amdgcn_s_waitcnt(0xC07F);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           bf16x8 av, bv;
           __builtin_memcpy(&av, &wq[s % WD], 16);
           __builtin_memcpy(&bv, &aq[s & 1][i], 16);
+          if (OV_EXP == 13) { asm volatile("" :: "v"(av), "v"(bv)); continue; }
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i], 0, 0, 0);   // D[channel][time]
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     mark(1);
-    // t: activated in fp32, rounded once, zero outside [0, L) (c2 pads t, not x); 4 consecutive channels per store
+    // t: activated in fp32, rounded once, zero outside [0, L) (c2 pads t, not x); 4 consecutive channels per store.
+    // (Two copies under a uniform branch: written as one, hipcc turns the row test into a select per value.)
+    {
+      auto t_write = [&](auto edge) {
+        constexpr bool EDGE = decltype(edge)::value;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool inside = t0 + trow0 + 32 * i + l31 < L;
-      unsigned char* hrow = hb + (2 * P2 + trow0 + 32 * i + l31) * PH + (32 * nt + 4 * half) * 2;
+        for (int i = 0; i < 4; ++i) {
+          unsigned char* hrow = hb + (2 * P2 + trow0 + 32 * i + l31) * PH + (32 * nt + 4 * half) * 2;
+          const bool inside = !EDGE || t0 + trow0 + 32 * i + l31 < L;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = acc[i][4 * q + e];
-          v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+          for (int q = 0; q < 4; ++q) {
+            const f32x2 a = lrelu2(f32x2{acc[i][4 * q], acc[i][4 * q + 1]}, slope);
+            const f32x2 c = lrelu2(f32x2{acc[i][4 * q + 2], acc[i][4 * q + 3]}, slope);
+            u32x2 o = {pack2(a[0], a[1]), pack2(c[0], c[1])};
+            if (EDGE && !inside) o = u32x2{0u, 0u};
+            *reinterpret_cast<u32x2*>(hrow + 16 * q) = o;
+          }
         }
-        u32x2 o = {pack2(v[0], v[1]), pack2(v[2], v[3])};
-        if (!inside) o = u32x2{0u, 0u};
-        *reinterpret_cast<u32x2*>(hrow + 16 * q) = o;
-      }
+      };
+      if (__builtin_expect(t0 + TT <= L, 1)) t_write(std::false_type{});   // every tile but an utterance's last one or two
+      else t_write(std::true_type{});
     }
     mark(2);
     __syncthreads();                                  // B: t in LDS
     mark(3);
-    // the MRF running sum of this wave's cells: requested now, consumed in the epilogue
-    u32x2 addv[4][4];
-    if (has_add && !warm) {
-      const uint16_t* ab = p.add + (size_t)b * L * C + 32 * nt + 4 * half;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int t = t0 - P2 + trow0 + 32 * i + l31;
-        const bool ok = t >= 0 && t < L;
-        const uint16_t* arow = ab + (size_t)(ok ? t : 0) * C;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          addv[i][q] = *reinterpret_cast<const u32x2*>(arow + 8 * q);
-          if (!ok) addv[i][q] = u32x2{0u, 0u};
-        }
-      }
-    }
     // ---- c2 out of the t tile: output row o (global t0 - P2 + o) needs t rows [o, o + K - 1] of the tile ----
     bias_init(bsm + C);
     {
       u32x4 aq[2][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) aq[0][i] = *reinterpret_cast<const u32x4*>(hb + hl_off + i * 32 * PH);
+      for (int i = 0; i < 4; ++i) aq[0][i] = aq[1][i] = *reinterpret_cast<const u32x4*>(hb + hl_off + i * 32 * PH);
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        wq[(S + s + WD - 1) % WD] = wnext(S + s + WD - 1);
-        if (s + 1 < S) {
+        if (OV_EXP != 10 && OV_EXP != 12) wq[(S + s + WD - 1) % WD] = wnext(S + s + WD - 1);
+        if (s + 1 < S && OV_EXP != 11 && OV_EXP != 12) {
           const int c = (s + 1) / (2 * K), tap = ((s + 1) / 2) % K, kb = (s + 1) & 1;
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             aq[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(hb + hl_off + (tap + 32 * i) * PH + 64 * c + 32 * kb);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < S) __builtin_amdgcn_s_waitcnt(0xC47F); else __builtin_amdgcn_s_waitcnt(0xC07F);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           bf16x8 av, bv;
           __builtin_memcpy(&av, &wq[(S + s) % WD], 16);
           __builtin_memcpy(&bv, &aq[s & 1][i], 16);
+          if (OV_EXP == 13) { asm volatile("" :: "v"(av), "v"(bv)); continue; }
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -373,31 +515,33 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
       }
     }
     // ---- epilogue, in place over the input tile: cell = (acc + x~ [+ add]) * scale, activated for its consumer ----
+    // All 16 cells of the lane are read first: as read-modify-write per cell the accesses may alias as far as hipcc
+    // can tell, and the 16 LDS round trips run one after the other (5 000 ticks per step, profiles/r04_s2).
     if (!warm) {
-      unsigned char* xw = xs + (pstep & 1) * XB;
+      unsigned char* xw = xs + bufoff;
+      u32x2 xv[4][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          unsigned char* cell = xw + ecell[q] + i * 32 * P;
-          const u32x2 xv = *reinterpret_cast<const u32x2*>(cell);
-          float r[4] = {__uint_as_float(xv[0] << 16), __uint_as_float(xv[0] & 0xffff0000u),
-                        __uint_as_float(xv[1] << 16), __uint_as_float(xv[1] & 0xffff0000u)};
-          float a[4] = {0.f, 0.f, 0.f, 0.f};
-          if (has_add) {
-            a[0] = __uint_as_float(addv[i][q][0] << 16); a[1] = __uint_as_float(addv[i][q][0] & 0xffff0000u);
-            a[2] = __uint_as_float(addv[i][q][1] << 16); a[3] = __uint_as_float(addv[i][q][1] & 0xffff0000u);
+        for (int q = 0; q < 4; ++q) xv[i][q] = *reinterpret_cast<const u32x2*>(xw + ecell[q] + i * 32 * P);
+      // (one copy per case under uniform branches: as run-time flags hipcc evaluates both sides with selects)
+      auto finish = [&](auto act, auto scl) {
+        constexpr bool ACT = decltype(act)::value, SCL = decltype(scl)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x2 v0 = f32x2{acc[i][4 * q], acc[i][4 * q + 1]} + unlrelu2(unpack2(xv[i][q][0]), inv_slope);
+            f32x2 v1 = f32x2{acc[i][4 * q + 2], acc[i][4 * q + 3]} + unlrelu2(unpack2(xv[i][q][1]), inv_slope);
+            if (SCL) { v0 *= scale; v1 *= scale; }
+            if (ACT) { v0 = lrelu2(v0, oslope); v1 = lrelu2(v1, oslope); }
+            *reinterpret_cast<u32x2*>(xw + ecell[q] + i * 32 * P) = u32x2{pack2(v0[0], v0[1]), pack2(v1[0], v1[1])};
           }
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float xr = r[e] >= 0.f ? r[e] : r[e] * inv_slope;
-            v[e] = (acc[i][4 * q + e] + xr + a[e]) * scale;
-            v[e] = v[e] > 0.f ? v[e] : v[e] * oslope;
-          }
-          *reinterpret_cast<u32x2*>(cell) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
         }
-      }
+      };
+      if (act_out) finish(std::true_type{}, std::false_type{});          // an intermediate pair (its scale is 1)
+      else if (scaled) finish(std::false_type{}, std::true_type{});      // the MRF mean without a running sum
+      else finish(std::false_type{}, std::false_type{});
     }
     mark(6);
     tk = nx;
@@ -406,7 +550,7 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
   if (dbg && lane == 0) {
     tph[7] = (unsigned long long)pstep;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) p.dbg[((size_t)blockIdx.x * NMW + wave) * 8 + q] = tph[q];
+    for (int q = 0; q < 8; ++q) p.dbg[((size_t)blockIdx.x * (NMW + NLD) + wave) * 8 + q] = tph[q];
   }
 }
 
@@ -424,22 +568,24 @@ inline int cu_count(std::atomic<int>* cache) {
   return cus;
 }
 
-template <int K, int DIL, int C>
+template <int K, int DIL, int C, int WD>
 int launch(const ov_respair2_bf16_params* p, hipStream_t stream) {
-  using G = Geo<K, DIL, C>;
+  using G = Geo<K, DIL, C, WD>;
   static std::atomic<int> cache[16];
   const int slots = cu_count(cache);                  // one workgroup per CU (its LDS tile fills the CU)
   const long SS = (long)p->B * ((p->L + G::P2 + G::TT - 1) / G::TT);
   long nwg = p->nwg > 0 ? p->nwg : slots;
   if (nwg > SS) nwg = SS;
-  hipLaunchKernelGGL((respair2_bf16_kernel<K, DIL, C>), dim3((unsigned)nwg), dim3(64 * (NMW + NLD)), 0, stream, *p);
+  hipLaunchKernelGGL((respair2_bf16_kernel<K, DIL, C, WD>), dim3((unsigned)nwg), dim3(64 * (NMW + NLD)), 0, stream, *p);
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
 }
 
 template <int K, int DIL>
 int launch_by_width(const ov_respair2_bf16_params* p, hipStream_t stream) {
-  if (p->C == 64) return launch<K, DIL, 64>(p, stream);
-  if (p->C == 128) return launch<K, DIL, 128>(p, stream);
+  if (p->C == 32) return launch<K, DIL, 32, 4>(p, stream);   // (2 S = 4 K k-steps per step: a 4-deep ring; the 45 KB of
+                                                               // both convs' weights are L1 / L2 hits for all four waves)
+  if (p->C == 64) return launch<K, DIL, 64, 8>(p, stream);
+  if (p->C == 128) return (p->exp_flags & 2) ? launch<K, DIL, 128, 16>(p, stream) : launch<K, DIL, 128, 8>(p, stream);
   return OV_E_UNSUPPORTED;
 }
 
@@ -451,7 +597,7 @@ extern "C" {
 
 int ov_resblock_pair2_bf16_supported(int C, int K, int dil) {
   const bool kd = (K == 3 || K == 7 || K == 11) && (dil == 1 || dil == 3 || dil == 5);
-  return kd && (C == 64 || C == 128) ? 1 : 0;
+  return kd && (C == 32 || C == 64 || C == 128) ? 1 : 0;
 }
 
 int ov_resblock_pair2_bf16cl(const ov_respair2_bf16_params* p, ov_stream_t stream) {
@@ -460,9 +606,11 @@ int ov_resblock_pair2_bf16cl(const ov_respair2_bf16_params* p, ov_stream_t strea
   if (p->out == p->x) return OV_E_BADARG;
   if (!(p->slope > 0.f && p->slope <= 1.f) || p->out_slope < 0.f || p->out_slope > 1.f) return OV_E_UNSUPPORTED;
   if (!ov_resblock_pair2_bf16_supported(p->C, p->K, p->dil)) return OV_E_UNSUPPORTED;
+  if (p->add && p->out_slope != 0.f && p->out_slope != 1.f) return OV_E_UNSUPPORTED;   // a sum is stored raw
+  if (p->out_slope != 0.f && p->out_slope != 1.f && p->scale != 1.f) return OV_E_UNSUPPORTED;   // (no such launch exists)
   if ((reinterpret_cast<uintptr_t>(p->x) & 15) || (reinterpret_cast<uintptr_t>(p->w1) & 15) ||
       (reinterpret_cast<uintptr_t>(p->w2) & 15) || (reinterpret_cast<uintptr_t>(p->out) & 15) ||
-      (p->add && (reinterpret_cast<uintptr_t>(p->add) & 7)))
+      (p->add && (reinterpret_cast<uintptr_t>(p->add) & 15)))
     return OV_E_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define OV16Q_CASE(KK, DD) if (p->K == KK && p->dil == DD) return launch_by_width<KK, DD>(p, st);

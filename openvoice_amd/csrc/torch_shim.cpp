@@ -312,11 +312,11 @@ void resblock_pair_bf16cl(const OptTensor& x, const OptTensor& w1, const OptTens
   finish(ov_resblock_pair_bf16cl(&p, c.stream()), "ov_resblock_pair_bf16cl");
 }
 
-// ip = [B, L, C, K, dil, nwg];  fp = [slope, scale, out_slope]
+// ip = [B, L, C, K, dil, nwg, exp_flags];  fp = [slope, scale, out_slope]
 void resblock_pair2_bf16cl(const OptTensor& x, const OptTensor& w1, const OptTensor& b1, const OptTensor& w2,
                            const OptTensor& b2, const OptTensor& out, const OptTensor& add, const OptTensor& dbg,
                            at::IntArrayRef ip, at::ArrayRef<double> fp) {
-  TORCH_CHECK(ip.size() == 6 && fp.size() == 3, "openvoice_amd::resblock_pair2_bf16cl: 6 integer and 3 float parameters");
+  TORCH_CHECK(ip.size() == 7 && fp.size() == 3, "openvoice_amd::resblock_pair2_bf16cl: 7 integer and 3 float parameters");
   Ctx c{"resblock_pair2_bf16cl", false};
   ov_respair2_bf16_params p{};
   p.x = sptr<uint16_t>(x, c, 0); p.w1 = sptr<uint16_t>(w1, c, 1); p.b1 = sptr<float>(b1, c, 2);
@@ -324,7 +324,7 @@ void resblock_pair2_bf16cl(const OptTensor& x, const OptTensor& w1, const OptTen
   p.add = sptr<uint16_t>(add, c, 6);
   p.dbg = sptr<unsigned long long>(dbg, c, 7);
   p.B = (int32_t)ip[0]; p.L = (int32_t)ip[1]; p.C = (int32_t)ip[2]; p.K = (int32_t)ip[3]; p.dil = (int32_t)ip[4];
-  p.nwg = (int32_t)ip[5];
+  p.nwg = (int32_t)ip[5]; p.exp_flags = (int32_t)ip[6];
   p.slope = (float)fp[0]; p.scale = (float)fp[1]; p.out_slope = (float)fp[2];
   DeviceScope scope(c);
   finish(ov_resblock_pair2_bf16cl(&p, c.stream()), "ov_resblock_pair2_bf16cl");

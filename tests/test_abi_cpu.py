@@ -185,7 +185,7 @@ def test_respair2_bf16_params_struct_matches_header_field_order():
     lib = _lib.load()
     assert lib.ov_resblock_pair2_bf16cl(None, None) == -1
     assert lib.ov_resblock_pair2_bf16_supported(128, 11, 5) == 1 and lib.ov_resblock_pair2_bf16_supported(64, 3, 1) == 1
-    assert lib.ov_resblock_pair2_bf16_supported(32, 3, 1) == 0 and lib.ov_resblock_pair2_bf16_supported(256, 7, 1) == 0
+    assert lib.ov_resblock_pair2_bf16_supported(32, 3, 1) == 1 and lib.ov_resblock_pair2_bf16_supported(256, 7, 1) == 0
 
 
 def test_every_header_function_is_bound_and_exported():

@@ -45,7 +45,7 @@ def pair2_table(args):
     dev, B = "cuda:0", args.batch
     print(f"B={B}: pair2 (ov_resblock_pair2_bf16cl) vs c1 + c2 launches [vs first-generation pair]; TF/s = both convs")
     print(f"{'C':>4} {'L':>7} {'k':>2} {'d':>1} {'pair2 ms':>9} {'TF/s':>7} {'GB/s':>7} {'+add ms':>8} {'c1+c2 ms':>9} {'pair1 ms':>9}")
-    for c, L in [(128, 55104), (64, 110208)]:
+    for c, L in [(128, 55104), (64, 110208), (32, 220416)]:
         x = torch.randn(B, L, c, device=dev).to(torch.bfloat16)
         xa = F.leaky_relu(x.float(), 0.1).to(torch.bfloat16)
         t, out, add = torch.empty_like(x), torch.empty_like(x), torch.randn_like(x)
