@@ -701,6 +701,22 @@ inline int resident_workgroups(const void* kernel, int block_threads, std::atomi
   return slots;
 }
 
+// Compute units of the current device (cached per ordinal).
+inline int compute_units() {
+  static std::atomic<int> cache[OV_MAX_DEVICES];
+  int dev = 0;
+  const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < OV_MAX_DEVICES;
+  if (known) {
+    const int v = cache[dev].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+  }
+  int cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  if (known) cache[dev].store(cus, std::memory_order_relaxed);
+  return cus;
+}
+
 typedef int (*conv_launch_fn)(const ov_conv1d_params*, hipStream_t);
 
 template <int K, int DIL, int WM, int WN, int WVM, int WVN, int CHUNK, int VEC, int EPI, int NLD>

@@ -260,6 +260,16 @@ int ov_conv1d_f32(const ov_conv1d_params* pin, ov_stream_t stream) {
   if (p->tile > 0) tile = p->tile - 1;
   else if (p->M <= 32 && !paired) tile = TILE_32x512;
   else if (p->M <= 64 && !paired) tile = TILE_64x256;
+  else if (!paired && epi == OV_EPI_LINEAR) {
+    // Small launches (batch 1: what the reference API issues, openvoice/api.py:141-160): when the 128 x 128 tiling
+    // leaves compute units idle (batch 1, generator stage 0: 108 workgroups on 256 CUs), the 32 x 256 tile -- four
+    // times the workgroups per launch -- is 1.4-1.8x faster (profiles/r04_s16_convs_small_batch_tiles.txt: C = 256,
+    // batch 1, k = 11 0.164 -> 0.092 ms); with one workgroup per CU or more, 128 x 128 wins.  (Also measured: the
+    // 32 x 256 tile on a mostly empty second round -- batch 2, stage 1: 862 tiles for 512 slots -- is ~10 % faster per
+    // launch at k >= 7, invisible end to end; not a rule.)  Falls back to 128 x 128 where no 32 x 256 instance exists.
+    const long t128 = (long)p->B * ((p->M + 127) / 128) * ((p->L + 127) / 128);
+    if (t128 < ovk::compute_units()) tile = TILE_32x256;
+  }
   const bool can_vec = (p->x_ld % 4 == 0) && !(reinterpret_cast<uintptr_t>(p->x) & 15) && (p->x_bstride % 4 == 0);
   int pref[3];
   conv_launch_fn fn = nullptr;

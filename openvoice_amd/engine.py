@@ -393,6 +393,14 @@ class ConverterEngine:
                 proj_b=sd["ref_enc.proj.bias"].contiguous().to(dev))
         self._ws = {}
         self.profile = None   # set to [] to collect per-launch HIP-event timings
+        # independent ResBlock chains of a generator stage on this many HIP streams when the batch is at most
+        # chain_streams_max_batch utterances (decode()); 1 = always the serial one-stream order
+        # Measured (round 4, profiles/r04_s14_sweep_chain_ab.txt): batch 1 8.75 vs 8.81 ms, batch 4 20.4 vs 20.2 ms -- the
+        # chains do overlap, but every kernel then runs proportionally longer (the chip is occupied by one-tile
+        # workgroups either way) -- so the default is the serial order; results are bit-identical both ways.
+        self.chain_streams = 1
+        self.chain_streams_max_batch = 8
+        self._streams = []
         self.fuse_wn = True      # WaveNet layers as one launch each (ov_wn_layer_f32) where the shape has an instance
         self.fuse_pairs = True   # ResBlock pairs of the HBM-bound stages as one launch each (PAIR_POLICY)
         # opt-in fast generator: bf16 activations, fp32 accumulation (waveform within
@@ -466,6 +474,18 @@ class ConverterEngine:
             ws["dec"] = [f(B * biggest) for _ in range(5)]
             self._ws[key] = ws
         return ws
+
+    def _side_streams(self, n):
+        while len(self._streams) < n:
+            self._streams.append(torch.cuda.Stream(self.device))
+        return self._streams[:n]
+
+    def _chain_scratch(self, ws, n):
+        """``n`` more decoder scratch buffers (the concurrent chains' own t1 / ra), allocated on first use."""
+        extra = ws.setdefault("dec_extra", [])
+        while len(extra) < n:
+            extra.append(torch.empty_like(ws["dec"][0]))
+        return extra
 
     def _wavenet(self, wn, ws, B, T, cond, mask):
         """h (in place) -> skip accumulator; reference: openvoice/modules.py:192-210.  The final
@@ -668,25 +688,56 @@ class ConverterEngine:
             x_ld = L
             t1, ra, acc = free.pop(), free.pop(), free.pop()
             bs = ch * L
-            # MRF: mean of the 3 ResBlock1 outputs (models.py:280-286, modules.py:296-306)
-            for j, pairs in enumerate(self.resblocks[i]):
+            # MRF: mean of the 3 ResBlock1 outputs (models.py:280-286, modules.py:296-306).  The three ResBlocks of a
+            # stage are independent chains until the sum.  At small batches one launch does not fill the chip (batch 1,
+            # stage 0: 108 workgroups for 512 slots; stages 1-3: one partial round of 431), so there the chains run on
+            # separate HIP streams and fill each other's ramps and tails; chain j's last launch waits for chain j - 1's
+            # (the running sum keeps its order: bit-identical to the serial sequence).
+            concurrent = (self.chain_streams > 1 and nk > 1 and B <= self.chain_streams_max_batch and self.profile is None)
+            scratch = [(t1, ra)]
+            if concurrent:
+                extra = self._chain_scratch(ws, 2 * (nk - 1))
+                scratch += [(extra[2 * j], extra[2 * j + 1]) for j in range(nk - 1)]
+
+            def chain(j, pairs):
+                t1_, ra_ = scratch[j if concurrent else 0]
                 cur = u
                 fused = self.fuse_pairs and L % 4 == 0 and all(
                     (ch, c1.K) in PAIR_POLICY and pair_supported(ch, c1.K, c1.dil) for c1, _ in pairs)
                 for n, (c1, c2) in enumerate(pairs):
                     last = n == len(pairs) - 1
+                    if last and concurrent and j > 0:
+                        torch.cuda.current_stream(self.device).wait_event(done[j - 1])
                     add = acc if (last and j > 0) else None
                     scale = 1.0 / nk if (last and j == nk - 1) else 1.0
                     if fused:
                         # one launch per pair, intermediate in LDS; out must not alias x: ra / t1 ping-pong
-                        dst = acc if last else (t1 if cur is ra else ra)
+                        dst = acc if last else (t1_ if cur is ra_ else ra_)
                         self._pair(c1, c2, cur, dst, bs, B, L, add, scale, **lim(rate))
                     else:
-                        self._conv(c1, cur, 0, bs, t1, 0, bs, B, L, in_slope=LRELU_SLOPE, tag="mrf", **lim(rate))
-                        dst = acc if last else ra
-                        self._conv(c2, t1, 0, bs, dst, 0, bs, B, L, in_slope=LRELU_SLOPE, res=cur, res_bs=bs,
+                        self._conv(c1, cur, 0, bs, t1_, 0, bs, B, L, in_slope=LRELU_SLOPE, tag="mrf", **lim(rate))
+                        dst = acc if last else ra_
+                        self._conv(c2, t1_, 0, bs, dst, 0, bs, B, L, in_slope=LRELU_SLOPE, res=cur, res_bs=bs,
                                    add=add, add_bs=bs, scale=scale, tag="mrf", **lim(rate))
                     cur = dst
+
+            if not concurrent:
+                for j, pairs in enumerate(self.resblocks[i]):
+                    chain(j, pairs)
+            else:
+                main = torch.cuda.current_stream(self.device)
+                side = self._side_streams(nk)
+                fork = torch.cuda.Event()
+                fork.record(main)
+                done = [None] * nk
+                for j, pairs in enumerate(self.resblocks[i]):
+                    with torch.cuda.stream(side[j]):
+                        side[j].wait_event(fork)
+                        chain(j, pairs)
+                        done[j] = torch.cuda.Event()
+                        done[j].record(side[j])
+                for j in range(nk):                     # every chain's scratch is free again before the next stage
+                    main.wait_event(done[j])
             free += [u, t1, ra]
             x = acc
         o_hat = torch.empty(B, 1, L, dtype=torch.float32, device=self.device)

@@ -366,3 +366,42 @@ def test_graph_replay_is_bit_identical_to_eager_launches(synth_sd):
     assert len(eng._graphs) == 1
     with pytest.raises(RuntimeError):
         eng.graphed(B, T, 0.3, B, 1)(a[0][:, :, :T - 1], a[1], a[2], a[3])
+
+
+def test_concurrent_resblock_chains_of_the_fp32_generator_are_bit_identical_to_the_serial_order(synth_sd):
+    """``ConverterEngine.chain_streams``: at small batches (what ``ToneColorConverter.convert`` issues: batch 1,
+    openvoice/api.py:141-160) the three ResBlock chains of a generator stage run on three HIP streams; the MRF sum
+    (openvoice/models.py:280-286) keeps its order through events, so ``o_hat`` equals the one-stream order bit for bit
+    -- fused and unfused pairs, twice in a row (scratch buffers are reused), under a non-default current stream, and
+    from a captured graph."""
+    from openvoice_amd.engine import ConverterEngine
+    from openvoice_amd.utils import CONVERTER_MODEL_CONFIG as CFG
+    gen = torch.Generator().manual_seed(11)
+    for B, T in ((1, 120), (3, 65)):
+        spec = (torch.randn(B, 513, T, generator=gen).abs() * torch.linspace(3, 0.05, 513)[None, :, None]).to(DEV)
+        lengths = torch.full((B,), T, dtype=torch.int64, device=DEV)
+        g1, g2 = (0.3 * torch.randn(1, 256, 1, generator=gen)).to(DEV), (0.3 * torch.randn(1, 256, 1, generator=gen)).to(DEV)
+        noise = torch.randn(B, 192, T, generator=gen).to(DEV)
+        eng = ConverterEngine(synth_sd, CFG, 513, DEV, zero_g=True)
+        run = lambda: eng.voice_conversion(spec, lengths, g1, g2, tau=0.3, noise=noise)[0].clone()
+        for fuse in (True, False):
+            eng.fuse_pairs = fuse
+            eng.chain_streams = 1
+            serial = run()
+            eng.chain_streams = 3
+            assert B <= eng.chain_streams_max_batch
+            a, b = run(), run()
+            side = torch.cuda.Stream(DEV)
+            side.wait_stream(torch.cuda.current_stream(DEV))
+            with torch.cuda.stream(side):
+                c = run()
+            side.synchronize()
+            torch.cuda.synchronize()
+            assert torch.isfinite(serial).all()
+            assert torch.equal(a, serial) and torch.equal(b, serial) and torch.equal(c, serial), (B, fuse)
+            if fuse:
+                serial_fused = serial
+        eng.fuse_pairs = True
+        graphed = eng.graphed(B, T, 0.3)(spec, lengths, g1, g2, noise=noise)[0].clone()
+        assert torch.equal(graphed, serial_fused)
+        assert "dec_extra" in eng._workspace(B, T)             # the concurrent chains really had their own scratch

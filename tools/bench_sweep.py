@@ -17,6 +17,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batches", type=int, nargs="+", default=[1, 2, 4, 8, 16, 32, 64])
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--chain-ab", action="store_true",
+                    help="small batches only: the concurrent ResBlock chains (engine.chain_streams = 3) against the "
+                         "serial one-stream order, same process, outputs compared bit for bit; also the captured-graph "
+                         "replay of the concurrent order")
+    ap.add_argument("--no-ragged", action="store_true")
     args = ap.parse_args()
     from bench import SAMPLE_RATE, synth_wave
     from openvoice_amd.mel_processing import spectrogram_torch
@@ -59,7 +64,24 @@ def main():
         dt = timeit(step)
         rows.append({"batch": B, "ms_per_batch": round(dt * 1e3, 3), "real_time_factor": round(B * 10.0 / dt, 1),
                      "utterances_per_s": round(B / dt, 2), "tflops": round(566.24e9 * B / dt / 1e12, 1)})
+        eng = model.engine()
+        if args.chain_ab and B <= eng.chain_streams_max_batch:
+            spec = spectrogram_torch(wave, d.filter_length, d.sampling_rate, d.hop_length, d.win_length, center=False)
+            lengths = torch.full((B,), spec.shape[2], dtype=torch.int64, device=dev)
+            noise = torch.randn(B, 192, spec.shape[2], generator=torch.Generator().manual_seed(B)).to(dev)
+            fixed = lambda **kw: model.voice_conversion(spec, lengths, se[0], se[1], tau=0.3, noise=noise, **kw)[0]
+            o3 = fixed().clone()
+            keep, eng.chain_streams = eng.chain_streams, 1
+            dt1 = timeit(step)
+            o1 = fixed().clone()
+            eng.chain_streams = keep
+            og = fixed(graph=True).clone()
+            dtg = timeit(lambda: fixed(graph=True))
+            rows[-1].update(ms_serial_order=round(dt1 * 1e3, 3), ms_graph_replay=round(dtg * 1e3, 3),
+                            bit_identical_to_serial=bool(torch.equal(o3, o1)), graph_bit_identical=bool(torch.equal(og, o1)))
         print(json.dumps(rows[-1]), flush=True)
+    if args.no_ragged:
+        return
     # ragged batch: 32 utterances of 3 ... 10 s, padded to the longest as the reference would
     B = 32
     gen = torch.Generator().manual_seed(5)
