@@ -47,19 +47,26 @@ def mrf_alg_bytes_per_launch(cfg, B, frames, fused=()):
     return total / launches
 
 
-def pmc_traffic():
+def pmc_traffic(batch, frames, fuse_pairs, pair_policy, launches_per_step, chain_streams=1):
     """HBM bytes per MRF launch measured with rocprofv3 PMC counters in a separate run of this same command
-    (scripts/gpu_session.sh, tools/pmc_traffic.py).  Reported only when the record was taken from the SAME kernel
-    sources and launch sequence as the running tree (``kernel_source_digest``); otherwise None plus the reason --
-    a stale figure is not a measurement of this code."""
-    from openvoice_amd.hostinfo import kernel_source_digest
+    (scripts/gpu_r4_profile.sh, tools/pmc_traffic.py).  Reported only when the record was taken on the SAME kernel
+    sources, workload shape and fusion policy as this run (``launch_config_digest``) AND counted the same number of
+    MRF launches per step as this run just issued; otherwise None plus the reason -- a figure measured on another
+    launch sequence is not a measurement of this one."""
+    from openvoice_amd.hostinfo import launch_config_digest
     try:
         with open(PMC_TRAFFIC_FILE) as fh:
             rec = json.load(fh)
-        have, want = rec.get("kernel_source_digest"), kernel_source_digest()
+        have = rec.get("launch_config_digest")
+        want = launch_config_digest(batch, frames, fuse_pairs, pair_policy, chain_streams)
         if have != want:
-            return None, f"profiles/pmc_traffic_latest.json was measured on kernel sources {have}, this tree is {want}"
-        return rec.get("calibrated", rec["nominal"])["bytes_per_launch"], f"PMC passes of kernel sources {have}"
+            return None, (f"profiles/pmc_traffic_latest.json was measured on launch configuration {have} "
+                          f"(kernel sources {rec.get('kernel_source_digest')}), this run is {want}")
+        if rec.get("launches_per_step") != launches_per_step:
+            return None, (f"profiles/pmc_traffic_latest.json counted {rec.get('launches_per_step')} MRF launches per "
+                          f"step, this run issued {launches_per_step}")
+        return (rec.get("calibrated", rec["nominal"])["bytes_per_launch"],
+                f"PMC passes of launch configuration {have}, {launches_per_step} MRF launches per step")
     except (OSError, KeyError, ValueError):
         return None, "no PMC record committed"
 
@@ -288,17 +295,39 @@ def dry_run(args):
         flag = torch.tensor([1.0 if ok else 0.0])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item() == 1.0)
+    names = [f"cpu (rank {rank})"]
+    dist_on = dist.is_initialized()
+    if dist_on:
+        names = [None] * world
+        dist.all_gather_object(names, f"cpu (rank {rank})")
+    line = None
     if rank == 0:
-        print(json.dumps({"metric": "real_time_factor", "value": None, "unit": "x real-time (audio s / wall s)",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-                          "per_rank_ms_per_step": rank_stats(per_rank, args.steps), "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "dry_run": True, "broadcast_consistent": ok,
-                          "config": {"workload": "control-flow rehearsal on CPU + gloo, no conversion",
-                                     "batch_per_gpu": B, "global_batch": B * world}}), flush=True)
-    if dist.is_initialized():
+        line = {"metric": "real_time_factor", "value": None, "unit": "x real-time (audio s / wall s)",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                "per_rank_ms_per_step": rank_stats(per_rank, args.steps), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "dry_run": True, "broadcast_consistent": ok,
+                "distributed": {"process_group": dist_on, "backend": dist.get_backend() if dist_on else None,
+                                "rccl_ranks": 0, "devices": names},
+                # the shape of the measured line's roofline object; no kernel ran, so no figures
+                "roofline": {"bound": "mfma", "achieved": None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": None, "traffic": None},
+                "config": {"workload": "control-flow rehearsal on CPU + gloo, no conversion",
+                           "batch_per_gpu": B, "global_batch": B * world}}
+    if dist_on:
         dist.destroy_process_group()
+    if rank == 0:
+        # rank 0's CPU-baseline leg exactly where the measured run has it -- after the group is gone -- on a
+        # 0.25 s utterance so that the rehearsal stays a rehearsal
+        if not args.no_cpu_baseline:
+            from openvoice_amd.params import synthetic_state_dict
+            from openvoice_amd.utils import default_converter_hparams
+            hps = default_converter_hparams("v2")
+            cfg = dict(hps.model.items())
+            sd = synthetic_state_dict(cfg, hps.data.filter_length // 2 + 1, seed=1234)
+            line["cpu_baseline"] = dict(cpu_baseline(sd, cfg, 0.25, budget_s=0.5, want_reference=False), dry_run=True)
+        print(json.dumps(line), flush=True)
     return 0 if ok else 1
 
 
@@ -361,18 +390,24 @@ def main():
     gen = torch.Generator().manual_seed(1)
     se = (0.1 * torch.randn(1, 256, 1, generator=gen), 0.1 * torch.randn(1, 256, 1, generator=gen))
     d = hps.data
+    n_frames = (samples + 2 * ((d.filter_length - d.hop_length) // 2) - d.filter_length) // d.hop_length + 1
+    lengths = torch.full((B,), n_frames, dtype=torch.int64, device=dev)      # resident, like the waveforms
 
     def step():
         # a real RCCL broadcast whenever a process group exists (N > 1, or N = 1 under --force-dist); else a copy
         src_se, tgt_se = broadcast_speaker_embeddings(se[0] if rank == 0 else None, se[1] if rank == 0 else None,
                                                       256, dev)
         spec = spectrogram_torch(wave, d.filter_length, d.sampling_rate, d.hop_length, d.win_length, center=False)
-        lengths = torch.full((B,), spec.shape[2], dtype=torch.int64, device=dev)
+        assert spec.shape[2] == n_frames
         o_hat, _, _ = model.voice_conversion(spec, lengths, src_se, tgt_se, tau=0.3)
         return o_hat, spec.shape[2]
 
     elapsed, per_rank, (o_hat, frames) = timed_steps(step, args, world, dev)
     dist_on = dist.is_available() and dist.is_initialized()
+    devices = [torch.cuda.get_device_name(dev)]
+    if dist_on:                      # every rank's device, gathered over the process group (a collective: all ranks)
+        devices = [None] * world
+        dist.all_gather_object(devices, torch.cuda.get_device_name(dev))
     assert o_hat.shape == (B, 1, frames * engine.total_upsample) and bool(torch.isfinite(o_hat).all())
 
     # PCIe-inclusive rate, reported beside `value` (never as it): the same step with the waveforms coming from
@@ -422,9 +457,9 @@ def main():
     else:
         n_mrf, f_mrf, t_mrf = by_tag["mrf"]
     achieved = f_mrf / t_mrf / 1e12
-    traffic, traffic_note = pmc_traffic()
     from openvoice_amd.engine import PAIR_POLICY
     fused_set = PAIR_POLICY if engine.fuse_pairs else ()
+    traffic, traffic_note = pmc_traffic(B, frames, engine.fuse_pairs, PAIR_POLICY, n_mrf, engine.chain_streams)
     alg_bytes = mrf_alg_bytes_per_launch(cfg, B, frames, fused_set)
     all_flops = sum(r[1] for r in by_tag.values())
     all_conv_s = sum(r[2] for r in by_tag.values())
@@ -448,6 +483,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "per_rank_ms_per_step": rank_stats(per_rank, args.steps),
             "distributed": {"process_group": dist_on, "backend": dist.get_backend() if dist_on else None,
+                            "rccl_ranks": world if dist_on else 0, "devices": devices,
                             "collectives_per_step": "1 broadcast of [2,256] fp32 (src/tgt se)" if dist_on else "none",
                             "binding": __import__("openvoice_amd._lib", fromlist=["binding"]).binding()},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -488,13 +524,16 @@ def main():
             except Exception as exc:   # noqa: BLE001 -- an unverifiable line must not look verified
                 out["parity"] = {"error": repr(exc)[:300], "ok": False, "tolerance": PARITY_TOLERANCE}
                 rc = 3
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, cfg, args.seconds, args.cpu_budget, batch32=args.cpu_batch32)
-        print(json.dumps(out), flush=True)
     else:
-        rc = 0
+        rc, out = 0, None
+    # The process group is torn down BEFORE the CPU baseline: the other ranks are done and exit, nobody waits in a
+    # collective while rank 0 spends ~20 s on the host cores.  The line is printed last, complete, once.
     if dist_on:
         dist.destroy_process_group()
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, cfg, args.seconds, args.cpu_budget, batch32=args.cpu_batch32)
+        print(json.dumps(out), flush=True)
     return rc
 
 

@@ -252,7 +252,8 @@ int ov_conv_post_tanh_f32(const float* x, const float* w, float* out, int B, int
                           float in_slope, ov_stream_t stream);
 /* The same with a length-aware tail: samples t >= col_limit[b] * col_limit_scale of utterance b are written as 0
  * without reading x there (the generator launches before it left those columns unwritten, see
- * ov_conv1d_params.col_limit).  col_limit NULL = ov_conv_post_tanh_f32. */
+ * ov_conv1d_params.col_limit).  col_limit NULL = ov_conv_post_tanh_f32.  (A col_limit_scale that is not a multiple
+ * of 4 takes the per-sample kernel: the 16-byte path decides per 4 consecutive samples.) */
 int ov_conv_post_tanh_limited_f32(const float* x, const float* w, float* out, int B, int C, int L, int K,
                                   float in_slope, const int32_t* col_limit, int col_limit_scale, ov_stream_t stream);
 /* limits[b] = min(T, max(0, lengths[b]) + margin): the frames of utterance b the generator has to produce so that
@@ -270,6 +271,9 @@ int ov_linear_f32(const float* x, const float* w, const float* bias, float* y, i
 /* mask[b][t] = t < lengths[b] ? 1 : 0 for t < T, reference openvoice/commons.py:121-125.
  * Rows of mask are ld floats apart (0 = T); columns >= T are not written. */
 int ov_sequence_mask_f32(const int64_t* lengths, float* mask, int B, int T, int ld, ov_stream_t stream);
+/* dst[r][t] = src[r * ld + t], t < T: the engine's 16-byte aligned rows -> the dense [.., T] tensors the model seam
+ * returns (z, z_p, z_hat, y_mask of openvoice/models.py:499). */
+int ov_unpad_rows_f32(const float* src, float* dst, int rows, int T, int ld, ov_stream_t stream);
 
 /* ---- ReferenceEncoder (extract_se), reference openvoice/models.py:339-359 -----------------------
  * Layout: time is the contiguous axis everywhere, [N][C][F][T]; the spectrogram [N][F][T] is the

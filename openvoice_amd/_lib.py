@@ -121,6 +121,7 @@ SIGNATURES = {
     "ov_frame_limits_i32": (ctypes.c_int, [_fp, _fp, _i, _i, _i, _fp]),
     "ov_linear_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
     "ov_sequence_mask_f32": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
+    "ov_unpad_rows_f32": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
     "ov_layernorm_freq_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_float, _fp]),
     "ov_conv2d_s2_relu_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -301,11 +301,13 @@ class ToneColorConverter(OpenVoiceBaseClass):
         def convert(shard, s, t, nz):
             if len(shard) == 0:         # more ranks than utterances: an empty shard of the agreed width
                 return torch.zeros(0, 1, width, dtype=torch.float32, device=self.device)
+            # (nz arrives cut to the shard's own longest length: parallel.convert_sharded(frames=...))
             o = self.convert_batch(shard, s, t, tau=tau, noise=nz)[0]
             if o.shape[2] < width:      # a shard whose longest utterance is shorter than the batch's
                 o = torch.nn.functional.pad(o, (0, width - o.shape[2]))
             return o
-        out = parallel.convert_sharded(convert, items, src_se, tgt_se, gin, self.device, noise=noise, gather=gather)
+        out = parallel.convert_sharded(convert, items, src_se, tgt_se, gin, self.device, noise=noise, gather=gather,
+                                       frames=frames)
         if ragged and gather:
             return out, torch.tensor(frames, dtype=torch.int64, device=self.device) * hop
         return out

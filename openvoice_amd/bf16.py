@@ -205,7 +205,7 @@ class GeneratorBf16:
         return self._streams[:n]
 
     def _workspace(self, B, T):
-        key = (B, T)
+        key = (B, T, self.chain_streams > 1)
         if key not in self._ws:
             self._ws.clear()
             ch, L, biggest = self.cfg["upsample_initial_channel"], T, 0
@@ -214,8 +214,9 @@ class GeneratorBf16:
                 L *= u
                 biggest = max(biggest, ch * L)
             f = lambda n: torch.empty(n, dtype=torch.bfloat16, device=self.device)
-            # stage input, ups output, running sum + (t1, ra) per concurrent chain
-            nbuf = 3 + 2 * max(1, len(self.cfg["resblock_kernel_sizes"]))
+            # stage input, ups output, running sum + (t1, ra) per concurrent chain: ONE pair for the default serial order
+            # (chain_streams == 1: 5 buffers, 4.5 GB at batch 64), one per chain only when concurrency is on (9, 8.1 GB)
+            nbuf = 3 + 2 * (max(1, len(self.cfg["resblock_kernel_sizes"])) if self.chain_streams > 1 else 1)
             self._ws[key] = dict(pre=f(B * T * self.cfg["upsample_initial_channel"]), dec=[f(B * biggest) for _ in range(nbuf)])
         return self._ws[key]
 

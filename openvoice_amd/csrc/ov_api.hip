@@ -118,6 +118,14 @@ __global__ void sequence_mask_kernel(const int64_t* __restrict__ lengths, float*
   if (t < T) mask[(int64_t)b * ld + t] = t < lengths[b] ? 1.f : 0.f;
 }
 
+// rows of `ld` floats -> dense rows of `T` floats: the engine keeps frame-rate tensors in 16-byte aligned rows
+// (T = 861 -> 864), the model seam returns the reference's dense [B, C, T] (openvoice/models.py:499)
+__global__ void unpad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int T, int ld) {
+  const int64_t row = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < T) dst[row * T + t] = src[row * ld + t];
+}
+
 // Framing for the spectrogram (reference: openvoice/mel_processing.py:54-58 reflect pad, :61-72 framing inside
 // torch.stft): hops[b][c][u] = ypad[hop*u + c], ypad = y reflect-padded by `pad` samples on both sides.  With
 // n_fft = 4*hop, frame t is hops[:, t .. t+3], so the windowed DFT becomes a 4-tap conv over u with `hop` input
@@ -325,8 +333,10 @@ int ov_conv_post_tanh_limited_f32(const float* x, const float* w, float* out, in
   if (col_limit && col_limit_scale <= 0) return OV_E_BADARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t smem = (size_t)C * K * sizeof(float);
+  // the vector path decides "kept or zero" per 4 consecutive samples: a limit that is not a multiple of 4 samples
+  // takes the per-sample path instead (never up to 3 samples computed from columns the generator left unwritten)
   const bool vec = (K == 7) && (L % 4 == 0) && !(reinterpret_cast<uintptr_t>(x) & 15) &&
-                   !(reinterpret_cast<uintptr_t>(out) & 15);
+                   !(reinterpret_cast<uintptr_t>(out) & 15) && (!col_limit || col_limit_scale % 4 == 0);
   if (vec) {
     dim3 grid((L / 4 + 255) / 256, B);
     hipLaunchKernelGGL(conv_post_tanh_vec_kernel<7>, grid, dim3(256), smem, st, x, w, out, C, L, in_slope, col_limit,
@@ -352,6 +362,17 @@ int ov_sequence_mask_f32(const int64_t* lengths, float* mask, int B, int T, int 
   dim3 grid((T + 255) / 256, B);
   hipLaunchKernelGGL(sequence_mask_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), lengths, mask, T,
                      ld ? ld : T);
+  return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
+}
+
+int ov_unpad_rows_f32(const float* src, float* dst, int rows, int T, int ld, ov_stream_t stream) {
+  if (!src || !dst || rows <= 0 || T <= 0 || ld < T || rows > 65535 * 1024) return OV_E_BADARG;
+  for (int r0 = 0; r0 < rows; r0 += 65535) {          // (grid.y limit)
+    const int n = rows - r0 < 65535 ? rows - r0 : 65535;
+    dim3 grid((T + 255) / 256, n);
+    hipLaunchKernelGGL(unpad_rows_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), src + (int64_t)r0 * ld,
+                       dst + (int64_t)r0 * T, T, ld);
+  }
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
 }
 

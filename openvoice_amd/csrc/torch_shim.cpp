@@ -353,6 +353,7 @@ TORCH_LIBRARY(openvoice_amd, m) {
   bind_device<&ov_frame_limits_i32>(m, "frame_limits_i32");
   bind_device<&ov_linear_f32>(m, "linear_f32");
   bind_device<&ov_sequence_mask_f32>(m, "sequence_mask_f32");
+  bind_device<&ov_unpad_rows_f32>(m, "unpad_rows_f32");
   bind_device<&ov_layernorm_freq_f32>(m, "layernorm_freq_f32");
   bind_device<&ov_conv2d_s2_relu_f32>(m, "conv2d_s2_relu_f32");
   bind_device<&ov_gru_f32>(m, "gru_f32");

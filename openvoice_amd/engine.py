@@ -25,10 +25,29 @@ from .params import ENC_Q_LAYERS, FLOW_LAYERS, N_FLOWS, REF_ENC_FILTERS, REF_ENC
 # dilation-1 convs = 5 * (1 + 3 + 5 + 3)) at 8 / 64 / 128 / 256 samples per frame, conv_post 3 samples (reference:
 # openvoice/models.py:225-291, modules.py:221-309) -- so computing length + 16 frames leaves the first ``length``
 # frames bit-identical to the full computation.
-GENERATOR_MARGIN = 16
+GENERATOR_MARGIN = 16   # the released configuration's; every engine computes its own (generator_margin_frames)
 LIMIT_MAX_BATCH = 256   # ovk::LIMIT_MAX_BATCH: utterances per launch the kernels' prefix table holds
 LRELU_SLOPE = 0.1       # reference: openvoice/modules.py:14
 FINAL_LRELU_SLOPE = 0.01  # F.leaky_relu default at openvoice/models.py:287
+
+
+def generator_margin_frames(cfg, conv_pre_kernel=7, conv_post_kernel=7):
+    """Frames beyond an utterance's end that can still influence its last sample: the generator's one-sided receptive
+    field, derived from the configuration (reference: openvoice/models.py:225-291 -- conv_pre, per stage a
+    ConvTranspose1d of kernel k_u and stride u followed by the MRF whose widest ResBlock1 reaches
+    (k - 1) / 2 * (sum(dilations) + len(dilations)) samples (modules.py:221-309: one dilated and one plain conv per
+    dilation), conv_post), rounded up plus one frame of slack.  16 for every released configuration."""
+    import math
+    reach = (conv_pre_kernel - 1) / 2.0                      # frames
+    spf = 1                                                  # samples per frame after the stage
+    for u, ku in zip(cfg["upsample_rates"], cfg["upsample_kernel_sizes"]):
+        spf *= u
+        reach += (ku - u + 1) / 2.0 / spf * 2                # a transposed conv reaches ceil((k_u - u) / 2) + 1 inputs back
+        widest = max((k - 1) // 2 * (sum(d) + len(d)) for k, d in
+                     zip(cfg["resblock_kernel_sizes"], cfg["resblock_dilation_sizes"]))
+        reach += widest / spf
+    reach += (conv_post_kernel - 1) / 2.0 / spf
+    return int(math.ceil(reach)) + 1
 
 
 def on_own_device(method):
@@ -401,6 +420,11 @@ class ConverterEngine:
         self.chain_streams = 1
         self.chain_streams_max_batch = 8
         self._streams = []
+        self._zeros = {}
+        # frames the generator computes beyond an utterance's length under skip_padding: this checkpoint's own
+        # receptive field (larger ResBlock kernels / dilations or other upsampling than the released models' would
+        # silently corrupt the last samples with a hard-wired 16)
+        self.generator_margin = max(GENERATOR_MARGIN, generator_margin_frames(self.cfg))
         self.fuse_wn = True      # WaveNet layers as one launch each (ov_wn_layer_f32) where the shape has an instance
         self.fuse_pairs = True   # ResBlock pairs of the HBM-bound stages as one launch each (PAIR_POLICY)
         # opt-in fast generator: bf16 activations, fp32 accumulation (waveform within
@@ -461,8 +485,9 @@ class ConverterEngine:
             Tp = padded_frames(T)
             # zero-filled once: the pad columns [T, Tp) are never written by a kernel and never read as data
             f = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+            lat = f(3, B, C, Tp)         # the three latents in ONE allocation: one ov_unpad_rows_f32 returns them dense
             ws = dict(Tp=Tp, mask=f(B, Tp), h=f(B, H, Tp), h2=f(B, H, Tp), acts=f(B, H, Tp), skip=f(B, H, Tp), noise=f(B, C, Tp),
-                      z=f(B, C, Tp), z_p=f(B, C, Tp), z_hat=f(B, C, Tp))
+                      lat=lat, z=lat[0], z_p=lat[1], z_hat=lat[2])
             ch = self.cfg["upsample_initial_channel"]
             ws["pre"] = f(B, ch, Tp)
             f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
@@ -474,6 +499,15 @@ class ConverterEngine:
             ws["dec"] = [f(B * biggest) for _ in range(5)]
             self._ws[key] = ws
         return ws
+
+    def _zeros_like_cached(self, t):
+        """An all-zero tensor of ``t``'s shape (the ``zero_g`` conditioning, models.py:495,498) without a fill launch
+        per conversion."""
+        key = tuple(t.shape)
+        z = self._zeros.get(key)
+        if z is None:
+            z = self._zeros[key] = torch.zeros_like(t)
+        return z
 
     def _side_streams(self, n):
         while len(self._streams) < n:
@@ -560,15 +594,16 @@ class ConverterEngine:
         lengths = spec_lengths.to(dev, torch.int64).contiguous()
         g_src = sid_src.to(dev, torch.float32).reshape(sid_src.shape[0], -1).contiguous()
         g_tgt = sid_tgt.to(dev, torch.float32).reshape(sid_tgt.shape[0], -1).contiguous()
-        if noise is None:
-            noise = torch.randn(B, C, T, dtype=torch.float32, device=dev)
         ws = self._workspace(B, T)
         Tp, mask = ws["Tp"], ws["mask"]
-        ws["noise"][:, :, :T].copy_(noise.to(dev, torch.float32))     # into the padded-row layout
+        if noise is None:
+            ws["noise"].normal_()        # drawn straight into the padded rows (the pad columns are never read): one launch
+        else:
+            ws["noise"][:, :, :T].copy_(noise.to(dev, torch.float32))     # into the padded-row layout
         _lib.call("ov_sequence_mask_f32", lengths, mask, B, T, Tp)
         # conditioning GEMVs (T = 1): modules.py:189-190 for every WN, models.py:275 for the decoder
-        g_q = torch.zeros_like(g_src) if self.zero_g else g_src
-        g_d = torch.zeros_like(g_tgt) if self.zero_g else g_tgt
+        g_q = self._zeros_like_cached(g_src) if self.zero_g else g_src
+        g_d = self._zeros_like_cached(g_tgt) if self.zero_g else g_tgt
         conds = dict(q=self._wn_cond(self.q_wn, g_q),
                      src=[self._wn_cond(cp["wn"], g_src) for cp in self.couplings],
                      tgt=[self._wn_cond(cp["wn"], g_tgt) for cp in self.couplings])
@@ -588,12 +623,20 @@ class ConverterEngine:
             if self.profile is not None:
                 e1.record()
                 self.profile.append(("gen_bf16", 0.0, e0, e1))
+            if skip_padding:
+                # the bf16 generator has no length-aware work lists (it computes the padded batch); the contract of
+                # skip_padding -- every sample beyond an utterance's own length is zero -- is kept by masking
+                keep_samples = (lengths.clamp(max=T) * self.total_upsample).view(B, 1, 1)
+                o_hat.masked_fill_(torch.arange(o_hat.shape[2], device=dev).view(1, 1, -1) >= keep_samples, 0.0)
         else:
             limits = self.frame_limits(lengths, T) if skip_padding else None
             o_hat = self.decode(z_hat, cond_d, ws, T=T, limits=limits)
-        # fresh dense tensors for the caller (the workspace is reused by the next call)
-        outs = tuple(t[:, :, :T].contiguous() for t in (z, z_p, z_hat))
-        return o_hat, mask[:, :T].unsqueeze(1).contiguous(), outs
+        # fresh dense tensors for the caller (the workspace is reused by the next call): padded rows -> [.., T]
+        dense = torch.empty(3, B, C, T, dtype=torch.float32, device=dev)
+        _lib.call("ov_unpad_rows_f32", ws["lat"], dense, 3 * B * C, T, Tp)
+        y_mask = torch.empty(B, 1, T, dtype=torch.float32, device=dev)
+        _lib.call("ov_unpad_rows_f32", mask, y_mask, B, T, Tp)
+        return o_hat, y_mask, (dense[0], dense[1], dense[2])
 
     def _frames(self, ws, b0, b1, spec, conds, tau):
         """Posterior encoder and the two flow passes for the utterances [b0, b1) (views of the whole-batch workspace)."""
@@ -645,7 +688,7 @@ class ConverterEngine:
         and must not leak into the result."""
         B = lengths.shape[0]
         lim = torch.empty(2, B, dtype=torch.int32, device=self.device)
-        _lib.call("ov_frame_limits_i32", lengths, lim[0], B, int(T), GENERATOR_MARGIN)
+        _lib.call("ov_frame_limits_i32", lengths, lim[0], B, int(T), self.generator_margin)
         _lib.call("ov_frame_limits_i32", lengths, lim[1], B, int(T), 0)
         return lim
 
@@ -660,11 +703,14 @@ class ConverterEngine:
         Tp = ws["Tp"]
         cfg = self.cfg
         ch = cfg["upsample_initial_channel"]
-        if limits is not None and B > LIMIT_MAX_BATCH:
-            limits = None                       # the kernels' prefix table holds 256 utterances: whole tensors beyond
         keep = None
         if limits is not None:
             limits, keep = limits[0], limits[1]
+            if B > LIMIT_MAX_BATCH:
+                # the conv kernels' prefix table holds 256 utterances: beyond that every launch computes the whole
+                # tensors, but conv_post (a per-utterance limit, no table) still keeps `length` frames and writes zeros
+                # beyond them -- the skip_padding contract ("the padded tail of o_hat is zero") holds at any batch size
+                limits = None
         lim = lambda scale: dict(col_limit=limits, col_limit_scale=scale) if limits is not None else {}
         self._conv(self.conv_pre, z_hat, 0, C * ld, ws["pre"], 0, ch * Tp, B, T, bias_b=cond_d,
                    bias_b_bs=0 if cond_d.shape[0] == 1 else cond_d.shape[1], x_ld=ld, out_ld=Tp, tag="conv_pre",
@@ -741,7 +787,7 @@ class ConverterEngine:
             free += [u, t1, ra]
             x = acc
         o_hat = torch.empty(B, 1, L, dtype=torch.float32, device=self.device)
-        if limits is not None:
+        if keep is not None:
             _lib.call("ov_conv_post_tanh_limited_f32", x, self.post_w, o_hat, B, ch, L, self.post_w.shape[1],
                       FINAL_LRELU_SLOPE, keep, rate)
         else:

@@ -56,3 +56,14 @@ def kernel_source_digest():
         with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def launch_config_digest(batch, frames, fuse_pairs, pair_policy, chain_streams=1):
+    """``kernel_source_digest()`` extended by what else decides the bytes a launch moves and how many launches a step
+    has: the workload shape (utterances per GPU, frames) and the engine's fusion policy.  A PMC traffic record
+    (tools/pmc_traffic.py) carries it; bench.py reports the record's figure only when it equals the running
+    configuration's -- a change of ``PAIR_POLICY`` / ``fuse_pairs`` keeps the source digest and changes the traffic."""
+    import hashlib
+    policy = sorted(f"{c}x{k}" for c, k in pair_policy) if fuse_pairs else []
+    text = f"{kernel_source_digest()}|B={int(batch)}|T={int(frames)}|fuse={int(bool(fuse_pairs))}|{','.join(policy)}|cs={int(chain_streams)}"
+    return hashlib.sha256(text.encode()).hexdigest()[:16]

@@ -63,7 +63,8 @@ def gather_waveforms(local_wave, group=None, counts=None):
     return torch.cat([o[:n] for o, n in zip(out, counts)], 0)
 
 
-def convert_sharded(convert_fn, waveforms, src_se, tgt_se, gin, device, noise=None, gather=True, root=0, group=None):
+def convert_sharded(convert_fn, waveforms, src_se, tgt_se, gin, device, noise=None, gather=True, root=0, group=None,
+                    frames=None):
     """Convert a batch of independent utterances across the ranks of the process group.
 
     Every rank passes the same ``waveforms`` ([N, samples] tensor, or a list of N waveforms) and, optionally, the same
@@ -71,14 +72,21 @@ def convert_sharded(convert_fn, waveforms, src_se, tgt_se, gin, device, noise=No
     converts utterances ``shard_range(N, r, world)`` with ``convert_fn(waveforms_shard, src_se, tgt_se, noise_shard)
     -> [n_r, 1, L]`` -- ``ToneColorConverter.convert_batch`` on the GPU path, the CPU oracle in the gloo test -- after
     ONE broadcast of the packed embeddings.  Returns the full [N, 1, L] batch on every rank when ``gather`` (one
-    all-gather, outside the hot path), else the local shard and its [start, end)."""
+    all-gather, outside the hot path), else the local shard and its [start, end).
+
+    ``frames`` (ragged batches): every utterance's frame count.  ``noise`` is [N, C, max(frames)] -- the width of the
+    WHOLE batch -- while a shard is converted at its OWN longest length, so the noise handed to ``convert_fn`` is cut
+    to ``max(frames[start:end])`` frames: per-utterance noise, the same result however the batch is cut."""
     world = dist.get_world_size(group) if _initialised() else 1
     rank = dist.get_rank(group) if _initialised() else 0
     n = len(waveforms)
     start, end = shard_range(n, rank, world)
     src_se, tgt_se = broadcast_speaker_embeddings(src_se, tgt_se, gin, device, root=root, group=group)
     shard = waveforms[start:end]
-    local = convert_fn(shard, src_se, tgt_se, None if noise is None else noise[start:end])
+    nz = None if noise is None else noise[start:end]
+    if nz is not None and frames is not None and end > start:
+        nz = nz[:, :, :max(int(f) for f in frames[start:end])]
+    local = convert_fn(shard, src_se, tgt_se, nz)
     if not gather:
         return local, (start, end)
     counts = [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]

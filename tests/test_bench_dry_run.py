@@ -42,6 +42,12 @@ def test_bench_multi_rank_control_flow_on_gloo(n):
     assert rec["ms_per_step"] >= 0
     pr = rec["per_rank_ms_per_step"]         # every rank's own time: a straggler shows up as max >> min
     assert len(pr["ranks"]) == n and pr["min"] <= pr["max"] <= rec["ms_per_step"] + 1e-3
+    # the N > 1 line is COMPLETE: roofline-shaped object, the CPU baseline (timed on rank 0 after the process group is
+    # gone), every rank's device gathered over the group
+    assert set(rec["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    cb = rec["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb and "unit" in cb
+    assert rec["distributed"]["process_group"] is True and len(rec["distributed"]["devices"]) == n
 
 
 def test_bench_single_rank_dry_run_needs_no_process_group():

@@ -111,3 +111,32 @@ def test_spectrogram_dft_weights_reproduce_torch_stft():
     ref = torch.stft(yp, n_fft, hop_length=hop, win_length=n_fft, window=torch.hann_window(n_fft), center=False,
                      return_complex=True).abs().pow(2).add(1e-6).sqrt()
     assert mag.shape == ref.shape and torch.allclose(mag.float(), ref, atol=2e-4)
+
+
+def test_generator_margin_covers_the_receptive_field_of_the_configuration():
+    """``engine.generator_margin_frames``: frames beyond an utterance's end that the generator must still compute under
+    ``skip_padding`` -- derived from the checkpoint's configuration instead of the released models' 16.  Checked on the
+    CPU oracle's generator (reference: openvoice/models.py:272-291): changing z from frame L + margin on leaves the
+    first L frames of audio untouched, for the released configuration and for one with larger ResBlock kernels and
+    dilations (where a hard-wired 16 would be too small); three frames less than the released margin is not enough."""
+    from openvoice_amd.engine import GENERATOR_MARGIN, generator_margin_frames
+    from openvoice_amd.params import synthetic_state_dict
+    from openvoice_amd.utils import CONVERTER_MODEL_CONFIG
+    from oracle import vc_oracle
+    big = dict(CONVERTER_MODEL_CONFIG, resblock_kernel_sizes=[3, 7, 13], resblock_dilation_sizes=[[1, 3, 7]] * 3)
+    assert generator_margin_frames(CONVERTER_MODEL_CONFIG) <= GENERATOR_MARGIN < generator_margin_frames(big)
+    L = 6
+    for cfg, margins in ((CONVERTER_MODEL_CONFIG, (generator_margin_frames(CONVERTER_MODEL_CONFIG), 11)),
+                         (big, (generator_margin_frames(big), GENERATOR_MARGIN))):
+        sd = synthetic_state_dict(cfg, 513, seed=5)
+        T = L + max(margins) + 4
+        z = _rand(1, cfg["inter_channels"], T, seed=7)
+        g = 0.3 * _rand(1, cfg["gin_channels"], 1, seed=8)
+        with torch.no_grad():
+            full = vc_oracle.generator(sd, z, g, cfg)
+            hop = full.shape[2] // T
+            for m, enough in zip(margins, (True, False)):
+                z2 = z.clone()
+                z2[:, :, L + m:] = 0.0                                       # what lies beyond the computed frames
+                diff = (vc_oracle.generator(sd, z2, g, cfg)[:, :, :L * hop] - full[:, :, :L * hop]).abs().max().item()
+                assert (diff == 0.0) == enough, (cfg["resblock_kernel_sizes"], m, diff)

@@ -51,7 +51,33 @@ def test_pmc_traffic_applies_guide_factors_and_separates_conv_pre(tmp_path):
              [3, 512, PRE, "WRITE_SIZE", 50000.0, 0, 1]] + [[10 + i, 1, COPY, "WRITE_SIZE", gib_kib, 0, 1] for i in range(3)]
     _write(str(tmp_path / "f" / "r1_counter_collection.csv"), fetch)
     _write(str(tmp_path / "w" / "r1_counter_collection.csv"), write)
-    rec = json.loads(_run("pmc_traffic.py", str(tmp_path / "f"), str(tmp_path / "w")))
+    rec = json.loads(_run("pmc_traffic.py", str(tmp_path / "f"), str(tmp_path / "w"), "2"))
     assert rec["mrf_launches_fetch_pass"] == 2 and rec["mrf_launches_write_pass"] == 2
+    assert rec["steps_in_pass"] == 2 and rec["launches_per_step"] == 1      # what bench.py compares with its own count
+    assert len(rec["launch_config_digest"]) == 16 and rec["launch_config"]["batch_per_gpu"] == 32
     assert rec["nominal"]["bytes_per_launch"] == (2 * 500000 + 900000) * 1024
     assert abs(rec["calibrated"]["read_factor"] - 2.0) < 1e-6 and abs(rec["calibrated"]["write_factor"] - 1.0) < 1e-6
+
+
+def test_bench_reports_pmc_traffic_only_for_the_same_launch_configuration(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic comes from a committed PMC record: it is reported only when the record was taken on
+    the same kernel sources + workload shape + fusion policy (launch_config_digest) AND counted the number of MRF
+    launches per step this run issued; a change of PAIR_POLICY / fuse_pairs / batch / frames voids it."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    from openvoice_amd.engine import PAIR_POLICY
+    from openvoice_amd.hostinfo import launch_config_digest
+    rec = {"launch_config_digest": launch_config_digest(32, 861, True, PAIR_POLICY), "launches_per_step": 63,
+           "nominal": {"bytes_per_launch": 123}, "calibrated": {"bytes_per_launch": 456}}
+    f = tmp_path / "pmc.json"
+    f.write_text(json.dumps(rec))
+    monkeypatch.setattr(bench, "PMC_TRAFFIC_FILE", str(f))
+    assert bench.pmc_traffic(32, 861, True, PAIR_POLICY, 63)[0] == 456
+    for args in ((16, 861, True, PAIR_POLICY, 63), (32, 860, True, PAIR_POLICY, 63), (32, 861, False, PAIR_POLICY, 63),
+                 (32, 861, True, set(list(PAIR_POLICY)[1:]), 63), (32, 861, True, PAIR_POLICY, 72),
+                 (32, 861, True, PAIR_POLICY, 63, 3)):
+        value, why = bench.pmc_traffic(*args)
+        assert value is None and "this run" in why, args
+    monkeypatch.setattr(bench, "PMC_TRAFFIC_FILE", str(tmp_path / "missing.json"))
+    assert bench.pmc_traffic(32, 861, True, PAIR_POLICY, 63) == (None, "no PMC record committed")

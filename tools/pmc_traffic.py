@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """HBM traffic of the MRF conv launches from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
 
-    python tools/pmc_traffic.py FETCH_DIR WRITE_DIR > profiles/rNN_pmc_traffic.json
+    python tools/pmc_traffic.py FETCH_DIR WRITE_DIR [STEPS_IN_PASS [BATCH [FRAMES]]] > profiles/rNN_pmc_traffic.json
+
+STEPS_IN_PASS = conversions the profiled command ran (bench.py --steps 1 --warmup 0: the timed step, the two
+PCIe-inclusive steps + their warm-up, the roofline step = 5); with it the record carries the MRF launches per step,
+which bench.py compares with what it launches itself.
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): the counters are in
 KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced streaming read, other access
@@ -47,9 +51,18 @@ def main():
     f_mrf, f_cal = summarise(read(fetch_dir, "FETCH_SIZE"), 80000.0)     # raw FETCH_SIZE is half the bytes
     w_mrf, w_cal = summarise(read(write_dir, "WRITE_SIZE"), 100000.0)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from openvoice_amd.hostinfo import kernel_source_digest
+    from openvoice_amd.engine import PAIR_POLICY
+    from openvoice_amd.hostinfo import kernel_source_digest, launch_config_digest
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    batch = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+    frames = int(sys.argv[5]) if len(sys.argv) > 5 else 861
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), counters in KiB",
            "kernel_source_digest": kernel_source_digest(),
+           "launch_config_digest": launch_config_digest(batch, frames, True, PAIR_POLICY),
+           "launch_config": {"batch_per_gpu": batch, "frames": frames, "fuse_pairs": True,
+                             "pair_policy": sorted(f"C={c} k={k}" for c, k in PAIR_POLICY)},
+           "steps_in_pass": steps,
+           "launches_per_step": (len(f_mrf) / steps if len(f_mrf) % steps == 0 else None),
            "mrf_launches_fetch_pass": len(f_mrf), "mrf_launches_write_pass": len(w_mrf)}
     if f_mrf and w_mrf:
         fetch_kib = sum(f_mrf) / len(f_mrf)
