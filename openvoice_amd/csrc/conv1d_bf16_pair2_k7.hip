@@ -1,0 +1,5 @@
+// Second-generation fused bf16 ResBlock pair, kernel size 7: explicit instantiations (see conv1d_bf16_pair2.h).
+#include "conv1d_bf16_pair2.h"
+namespace ovk16q {
+int pair2_launch_k7(const ov_respair2_bf16_params* p, hipStream_t stream) { return pair2_launch_by_dilation<7>(p, stream); }
+}  // namespace ovk16q

@@ -136,6 +136,23 @@ def test_pair2_chain_of_three_pairs_matches_raw_residual_chain():
     assert err <= 3e-2 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("c,k,d", [(128, 11, 5), (128, 3, 1), (64, 7, 3), (32, 3, 5)])
+def test_pair2_deferred_epilogue_equals_the_epilogue_phase(c, k, d):
+    """The production kernels finish a step's output cells inside the next step's c1 loop (deferred epilogue); the same
+    arithmetic as its own phase (exp_flags bit 1, kept for A/B measurements) must give the same bits -- also with the
+    running sum, runs cut mid-utterance and a third input buffer where it fits."""
+    B, L = 3, 1900
+    (w1, b1, w2, b2), c1, c2 = _layers(c, k, d, seed=5)
+    xa = _act_input(B, L, c, 61)
+    add = _r(_rand(B, L, c, seed=62)).to(DEV, torch.bfloat16)
+    xd = xa.to(DEV, torch.bfloat16)
+    for kw in (dict(out_slope=SLOPE), dict(add=add, scale=1.0 / 3.0), dict(nwg=5), dict(scale=1.0 / 3.0)):
+        a, b = torch.full_like(xd, float("nan")), torch.full_like(xd, float("nan"))
+        launch_pair2_bf16(c1, c2, xd, a, **kw)
+        launch_pair2_bf16(c1, c2, xd, b, exp_flags=2, **kw)
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b), kw
+
+
 def test_pair2_rejects_bad_arguments():
     from openvoice_amd import _lib
     (w1, b1, w2, b2), c1, c2 = _layers(64, 3, 1)

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openvoice_amd.bf16 import PackedConvBf16, launch_pair2_bf16  # noqa: E402
 
-PH = ["barrier A", "c1 k-steps", "t -> LDS", "barrier B", "c2 k-steps", "barrier C", "epilogue"]
+PH = ["barrier A", "c1 (+cells)", "t -> LDS", "barrier B", "c2 k-steps", "barrier C", "epilogue"]
 dev, B = "cuda:0", 64
 shapes = {128: (55104, 128), 64: (110208, 256), 32: (220416, 512)}
 for c in ([int(a) for a in sys.argv[1:]] or [128, 64]):
