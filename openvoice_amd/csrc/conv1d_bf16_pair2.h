@@ -48,6 +48,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int NMW = 4;       // matrix waves: one per SIMD
+#ifndef OV_P2_LD
+#define OV_P2_LD 2           // LDS operand buffers of the k-loops: the reads of k-step s + LD - 1 are issued at k-step s
+#endif
+constexpr int LD = OV_P2_LD;     // (3 measured: no faster without the deferred epilogue, spills with it -- profiles/r04_s22)
 constexpr int NLD = 4;       // loader waves (one per SIMD, so every matrix wave has the same company): LDS-DMA in, whole-row stores out
 
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {       // one v_cvt_pk_bf16_f32, round to nearest even
@@ -541,9 +545,21 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
     mark(0);
     // ---- c1: t = b1 + W1 * xa  (+ the cells of the previous step's output, DEFER) ----------------------------------
     {
-      u32x4 aq[2][4];
+      u32x4 aq[LD][4];
+      auto xread = [&](auto sc) {                      // B operands of k-step s' -> buffer s' % LD
+        constexpr int sp = decltype(sc)::value;
+        if constexpr (sp < S && OV_EXP != 11 && OV_EXP != 12) {
+          constexpr int c = sp / (2 * K), tap = (sp / 2) % K, kb = sp & 1;
+          const uint32_t a = xlb[tap] ^ (uint32_t)(64 * c + 32 * kb);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) aq[0][i] = aq[1][i] = *reinterpret_cast<const u32x4*>(xs + xlb[0] + i * 32 * P);
+          for (int i = 0; i < 4; ++i) aq[sp % LD][i] = *reinterpret_cast<const u32x4*>(xs + a + i * 32 * P);
+        }
+      };
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < LD; ++b) aq[b][i] = u32x4{0u, 0u, 0u, 0u};
+      static_for<0, LD - 1>([&](auto sc) { xread(sc); });
       // cells [CB(s), CB(s + 1)) are finished in k-step s; their 8-byte reads are issued a k-step earlier
       constexpr int MAXC = (16 + S - 1) / S + 1;
       u32x2 cx[2][MAXC];
@@ -558,12 +574,7 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
         constexpr int s = decltype(sc)::value;
         constexpr int C0 = cells_before<S>(s), C1 = cells_before<S>(s + 1), C2 = cells_before<S>(s + 2);
         if constexpr (OV_EXP != 10 && OV_EXP != 12) wq[(s + WD - 1) % WD] = wnext(s + WD - 1);
-        if constexpr (s + 1 < S && OV_EXP != 11 && OV_EXP != 12) {
-          constexpr int c = (s + 1) / (2 * K), tap = ((s + 1) / 2) % K, kb = (s + 1) & 1;
-          const uint32_t a = xlb[tap] ^ (uint32_t)(64 * c + 32 * kb);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) aq[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(xs + a + i * 32 * P);
-        }
+        xread(std::integral_constant<int, s + LD - 1>{});
         constexpr int nread = DEFER ? C2 - C1 : 0;               // cell reads issued behind the operand reads
         if constexpr (DEFER) {
           static_for<C1, C2>([&](auto cc) {
@@ -575,15 +586,19 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
         // ONE wait for the step's four operands (issued a step ago; what was issued in this step stays in flight):
         // hipcc's own staggered lgkmcnt(7 .. 4) puts an instruction between every two MFMAs, ~6 cycles each
         {
-          constexpr int left = (s + 1 < S ? 4 : 0) + nread;
-          static_assert(left <= 7, "lgkmcnt immediate");
+          // in flight behind the operands of this step: those of the next LD - 2 steps (issued earlier), of step
+          // s + LD - 1 and the cell reads (issued just now); with DEFER the older cell reads / writes sit in between,
+          // so the count is only exact without them -- a smaller count waits for more, never for less
+          constexpr int ahead = (S - 1 - s < LD - 1 ? S - 1 - s : LD - 1);
+          constexpr int left = DEFER ? ((s + LD - 1 < S ? 4 : 0) + nread) : 4 * ahead;
+          static_assert(left <= 15, "lgkmcnt immediate");
           __builtin_amdgcn_s_waitcnt(0xC07F | (left << 8));
         }
         static_for<0, 4>([&](auto ic) {
           constexpr int i = decltype(ic)::value;
           bf16x8 av, bv;
           __builtin_memcpy(&av, &wq[s % WD], 16);
-          __builtin_memcpy(&bv, &aq[s & 1][i], 16);
+          __builtin_memcpy(&bv, &aq[s % LD][i], 16);
           if constexpr (OV_EXP == 13) { asm volatile("" :: "v"(av), "v"(bv)); }
           else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i], 0, 0, 0);   // D[channel][time]
           if constexpr (DEFER && C1 > C0) {
@@ -636,25 +651,35 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
 #pragma unroll
           for (int e = 0; e < 4; ++e) a2[i][4 * q + e] = v[e];
       }
-      u32x4 aq[2][4];
+      u32x4 aq[LD][4];
+      auto hread = [&](auto sc) {
+        constexpr int sp = decltype(sc)::value;
+        if constexpr (sp < S && OV_EXP != 11 && OV_EXP != 12) {
+          constexpr int c = sp / (2 * K), tap = (sp / 2) % K, kb = sp & 1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) aq[0][i] = aq[1][i] = *reinterpret_cast<const u32x4*>(hb + hl_off + i * 32 * PH);
+          for (int i = 0; i < 4; ++i)
+            aq[sp % LD][i] = *reinterpret_cast<const u32x4*>(hb + hl_off + (tap + 32 * i) * PH + 64 * c + 32 * kb);
+        }
+      };
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < LD; ++b) aq[b][i] = u32x4{0u, 0u, 0u, 0u};
+      static_for<0, LD - 1>([&](auto sc) { hread(sc); });
       static_for<0, S>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         if constexpr (OV_EXP != 10 && OV_EXP != 12) wq[(S + s + WD - 1) % WD] = wnext(S + s + WD - 1);
-        if constexpr (s + 1 < S && OV_EXP != 11 && OV_EXP != 12) {
-          constexpr int c = (s + 1) / (2 * K), tap = ((s + 1) / 2) % K, kb = (s + 1) & 1;
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            aq[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(hb + hl_off + (tap + 32 * i) * PH + 64 * c + 32 * kb);
-        }
+        hread(std::integral_constant<int, s + LD - 1>{});
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(s + 1 < S ? 0xC47F : 0xC07F);
+        {
+          constexpr int ahead = (S - 1 - s < LD - 1 ? S - 1 - s : LD - 1);
+          __builtin_amdgcn_s_waitcnt(0xC07F | ((4 * ahead) << 8));
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           bf16x8 av, bv;
           __builtin_memcpy(&av, &wq[(S + s) % WD], 16);
-          __builtin_memcpy(&bv, &aq[s & 1][i], 16);
+          __builtin_memcpy(&bv, &aq[s % LD][i], 16);
           if (OV_EXP == 13) { asm volatile("" :: "v"(av), "v"(bv)); continue; }
           a2[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, a2[i], 0, 0, 0);
         }
