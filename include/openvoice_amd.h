@@ -428,8 +428,8 @@ int ov_resblock_pair_bf16_supported(int C, int K, int dil);
  *   out = bf16(act((c2(t) + b2 + x~) * scale)),            x~ = x >= 0 ? x : x / slope  (exact inverse in fp32),
  *         act = leaky ReLU with out_slope (1.0f: the raw sum, for a tensor that is consumed as `add` or by a kernel
  *         that activates on load);
- *   with `add` (a RAW tensor, the MRF running sum; out_slope must be 0 / 1):
- *   out = bf16((bf16(c2(t) + b2 + x~) + add) * scale).
+ *   with `add` (a RAW tensor, the MRF running sum):
+ *   out = bf16(act((bf16(c2(t) + b2 + x~) + add) * scale)).
  * reference openvoice/modules.py:296-306, models.py:280-286.  w1 / w2 from ov_conv1d_bf16_pack(C, C, K), b1 / b2 fp32
  * [C].  out must not alias x; add may alias out. */
 typedef struct ov_respair2_bf16_params {

@@ -237,8 +237,10 @@ class GeneratorBf16:
         cond = cond.expand(B, -1).contiguous()                                               # [B, 512] fp32
         ch = self.cfg["upsample_initial_channel"]
         pre = ws["pre"][: B * T * ch].view(B, T, ch)
-        _launch(self.conv_pre, x, pre, T, bias=cond, bias_bstride=ch)
-        cur_x, L = pre, T
+        # every tensor a ConvTranspose reads is stored ACTIVATED by its producer (conv_pre here, the MRF mean below):
+        # its loaders then copy instead of unpacking / activating / re-packing every vector
+        _launch(self.conv_pre, x, pre, T, bias=cond, bias_bstride=ch, out_slope=LRELU_SLOPE)
+        cur_x, L, cur_act = pre, T, True                  # cur_act: cur_x holds lrelu(x) already
         free = list(ws["dec"])
         nk = len(self.cfg["resblock_kernel_sizes"])
         # The three ResBlocks of a stage (k = 3, 7, 11) are independent chains until the MRF sum.  In bf16 they bound
@@ -255,7 +257,8 @@ class GeneratorBf16:
             u = free.pop()[: B * L * s * ch].view(B, L * s, ch)
             act = (self.act_hbm and self.fuse_pairs and
                    all(pair2_bf16_supported(ch, c1.K, c1.dil) for pairs in self.resblocks[i] for c1, _ in pairs))
-            _launch(up["conv"], cur_x, u, L, in_slope=LRELU_SLOPE, phase_s=s, out_slope=LRELU_SLOPE if act else 1.0)
+            _launch(up["conv"], cur_x, u, L, in_slope=1.0 if cur_act else LRELU_SLOPE, phase_s=s,
+                    out_slope=LRELU_SLOPE if act else 1.0)
             L *= s
             acc = free.pop()[: B * L * ch].view(B, L, ch)
             nchains = nk if concurrent else 1
@@ -263,6 +266,8 @@ class GeneratorBf16:
             cur = [u] * nk
             fused = [self.fuse_pairs and all(pair_bf16_supported(ch, c1.K, c1.dil) for c1, _ in pairs)
                      for pairs in self.resblocks[i]]
+            # can the launch that writes the MRF mean apply an activation?  (the first-generation fused pair cannot)
+            mean_act = i + 1 < len(self.ups) and (act or not fused[nk - 1])
             npairs = len(self.resblocks[i][0])
 
             def pair(j, n):
@@ -271,10 +276,13 @@ class GeneratorBf16:
                 last = n == npairs - 1
                 add = acc if (last and j > 0) else None
                 scale = 1.0 / nk if (last and j == nk - 1) else 1.0
-                if act:            # activated tensors between the launches; the chain's last output (a sum) stays raw
+                # the MRF mean feeds the next stage's ConvTranspose, which wants it activated; the last stage's feeds
+                # conv_post (its own slope, applied there); the chains' partial sums stay raw
+                mean_slope = LRELU_SLOPE if (last and j == nk - 1 and mean_act) else 1.0
+                if act:            # activated tensors between the launches
                     dst = acc if last else (t1 if cur[j] is ra else ra)
                     launch_pair2_bf16(c1, c2, cur[j], dst, add=add, scale=scale, slope=LRELU_SLOPE,
-                                      out_slope=1.0 if last else LRELU_SLOPE)
+                                      out_slope=mean_slope if last else LRELU_SLOPE)
                 elif fused[j]:       # one launch per pair, intermediate in LDS; out must not alias x: ra / t1 ping-pong
                     dst = acc if last else (t1 if cur[j] is ra else ra)
                     launch_pair_bf16(c1, c2, cur[j], dst, add=add, scale=scale, slope=LRELU_SLOPE)
@@ -283,7 +291,7 @@ class GeneratorBf16:
                     # two) and let c2's loaders copy it as is
                     _launch(c1, cur[j], t1, L, in_slope=LRELU_SLOPE, out_slope=LRELU_SLOPE)
                     dst = acc if last else ra
-                    _launch(c2, t1, dst, L, in_slope=1.0, res=cur[j], add=add, scale=scale)
+                    _launch(c2, t1, dst, L, in_slope=1.0, res=cur[j], add=add, scale=scale, out_slope=mean_slope)
                 cur[j] = dst
 
             if not concurrent:
@@ -308,7 +316,7 @@ class GeneratorBf16:
                 main.wait_event(done[nk - 1])
             # every scratch buffer except the one holding this stage's output is free again
             free = [buf for buf in ws["dec"] if buf.data_ptr() != acc.data_ptr()]
-            cur_x = acc
+            cur_x, cur_act = acc, mean_act
         o = torch.empty(B, 1, L, dtype=torch.float32, device=dev)
         _lib.call("ov_conv_post_tanh_bf16", cur_x, self.post_w, o, B, ch, L, self.post_w.shape[1], FINAL_LRELU_SLOPE)
         return o

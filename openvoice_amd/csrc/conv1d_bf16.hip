@@ -494,39 +494,57 @@ int launch_by_width(const ov_conv1d_bf16_params* p, hipStream_t stream) {
 }
 
 // conv_post + tanh on the bf16 channels-last tensor (reference: openvoice/models.py:287-289):
-// out[b][t] = tanh(sum_{c, j} w[c][j] * lrelu(x[b][t + j - (K-1)/2][c], slope)), fp32 out.  One thread per sample,
-// the C * 2 bytes of a row are read as 16-byte vectors; HBM-bound (the last and largest tensor of the generator).
+// out[b][t] = tanh(sum_{c, j} w[c][j] * lrelu(x[b][t + j - (K-1)/2][c], slope)), fp32 out; HBM-bound (the last and
+// largest tensor of the generator: 64 bytes in, 4 bytes out per sample).  A thread reads ITS row once (four 16-byte
+// loads), forms the K per-tap dot products of that row against weights held in scalar registers (the weight index is
+// a compile-time constant: s_load), leaves them in LDS, and a sample is the sum of K partials of K neighbouring rows.
+// (Round 3's version read all K rows per thread -- 28 loads -- and its 224 weights one by one from LDS: 0.46 ms per
+// batch-64 for a 0.16 ms tensor read.)
 template <int C, int K>
 __global__ __launch_bounds__(256) void conv_post_tanh_bf16_kernel(const uint16_t* __restrict__ x,
                                                                   const float* __restrict__ w,
                                                                   float* __restrict__ out, int L, float slope) {
-  __shared__ float wsm[C * K];
-  for (int i = threadIdx.x; i < C * K; i += 256) wsm[i] = w[i];
-  __syncthreads();
-  const int b = blockIdx.y;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= L) return;
+  constexpr int H = (K - 1) / 2, NR = 256 + K - 1;
+  __shared__ float ps[K][NR + 1];
+  const int b = blockIdx.y, t0 = blockIdx.x * 256, tid = threadIdx.x;
   const uint16_t* xb = x + (int64_t)b * L * C;
-  float acc = 0.f;
+  auto row_partials = [&](int i) {
+    const int t = t0 - H + i;
+    float p[K];
 #pragma unroll
-  for (int j = 0; j < K; ++j) {
-    const int tt = t + j - (K - 1) / 2;
-    if (tt < 0 || tt >= L) continue;
-    const u32x4* row = reinterpret_cast<const u32x4*>(xb + (int64_t)tt * C);
+    for (int j = 0; j < K; ++j) p[j] = 0.f;
+    if (t >= 0 && t < L) {
+      const u32x4* row = reinterpret_cast<const u32x4*>(xb + (int64_t)t * C);
+      u32x4 v[C / 8];
 #pragma unroll
-    for (int q = 0; q < C / 8; ++q) {
-      const u32x4 v = row[q];
+      for (int q = 0; q < C / 8; ++q) v[q] = row[q];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
-        lo = lo > 0.f ? lo : lo * slope;
-        hi = hi > 0.f ? hi : hi * slope;
-        acc = fmaf(wsm[(8 * q + 2 * e) * K + j], lo, acc);
-        acc = fmaf(wsm[(8 * q + 2 * e + 1) * K + j], hi, acc);
-      }
+      for (int q = 0; q < C / 8; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float lo = __uint_as_float(v[q][e] << 16), hi = __uint_as_float(v[q][e] & 0xffff0000u);
+          lo = lo > 0.f ? lo : lo * slope;
+          hi = hi > 0.f ? hi : hi * slope;
+#pragma unroll
+          for (int j = 0; j < K; ++j) {
+            p[j] = fmaf(w[(8 * q + 2 * e) * K + j], lo, p[j]);
+            p[j] = fmaf(w[(8 * q + 2 * e + 1) * K + j], hi, p[j]);
+          }
+        }
     }
+#pragma unroll
+    for (int j = 0; j < K; ++j) ps[j][i] = p[j];
+  };
+  row_partials(tid);
+  if (tid < K - 1) row_partials(256 + tid);
+  __syncthreads();
+  const int t = t0 + tid;
+  if (t < L) {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc += ps[j][tid + j];      // tap j of sample t reads row t + j - H = tile row tid + j
+    out[(int64_t)b * L + t] = tanhf(acc);
   }
-  out[(int64_t)b * L + t] = tanhf(acc);
 }
 
 }  // namespace ovk16

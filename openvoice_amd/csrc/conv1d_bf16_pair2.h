@@ -235,6 +235,7 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
     // the weight ring: launches with `add` ran 0.2-0.3 ms longer (profiles/r04_s4).
     const bool has_add = p.add != nullptr;
     const float scale = p.scale;
+    const float add_oslope = p.out_slope > 0.f ? p.out_slope : 1.f;   // (the sum's consumer may want it activated)
     u32x4 addq[NSB];
     // rows of the lane that belong to the output window [DELTA, DELTA + TT): all of them except in the first / last block
     auto row_in_window = [&](int blk) { const int row = blk * RPB + lrow; return row >= DELTA && row < DELTA + TT; };
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
         for (int j = J0; j < J1; ++j)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const f32x2 r = (unpack2(ov[j - J0][e]) + unpack2(addq[j - J0][e])) * scale;
+            const f32x2 r = lrelu2((unpack2(ov[j - J0][e]) + unpack2(addq[j - J0][e])) * scale, add_oslope);
             ov[j - J0][e] = pack2(r[0], r[1]);
           }
       }
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
   };
   const bool has_add = p.add != nullptr;              // then the loader waves add it and scale (see above)
   const float slope = p.slope, inv_slope = 1.0f / p.slope, scale = has_add ? 1.0f : p.scale;
-  const float oslope = p.out_slope > 0.f ? p.out_slope : 1.f;
+  const float oslope = (p.out_slope > 0.f && !has_add) ? p.out_slope : 1.f;
   const bool scaled = scale != 1.0f, act_out = oslope != 1.0f;    // (uniform; the epilogue skips what is an identity)
 
   // Deferred epilogue (DEFER): c2 accumulates into accE, which then waits through the next step's c1 loop, where its

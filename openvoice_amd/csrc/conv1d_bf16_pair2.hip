@@ -16,8 +16,8 @@ int ov_resblock_pair2_bf16cl(const ov_respair2_bf16_params* p, ov_stream_t strea
   if (p->out == p->x) return OV_E_BADARG;
   if (!(p->slope > 0.f && p->slope <= 1.f) || p->out_slope < 0.f || p->out_slope > 1.f) return OV_E_UNSUPPORTED;
   if (!ov_resblock_pair2_bf16_supported(p->C, p->K, p->dil)) return OV_E_UNSUPPORTED;
-  if (p->add && p->out_slope != 0.f && p->out_slope != 1.f) return OV_E_UNSUPPORTED;   // a sum is stored raw
-  if (p->out_slope != 0.f && p->out_slope != 1.f && p->scale != 1.f) return OV_E_UNSUPPORTED;   // (no such launch exists)
+  // without `add` the epilogue has one copy per case: activated (scale 1), scaled (raw), plain
+  if (!p->add && p->out_slope != 0.f && p->out_slope != 1.f && p->scale != 1.f) return OV_E_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(p->x) & 15) || (reinterpret_cast<uintptr_t>(p->w1) & 15) ||
       (reinterpret_cast<uintptr_t>(p->w2) & 15) || (reinterpret_cast<uintptr_t>(p->out) & 15) ||
       (p->add && (reinterpret_cast<uintptr_t>(p->add) & 15)))

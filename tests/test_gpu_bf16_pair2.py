@@ -37,7 +37,7 @@ def _reference(xa, w1, b1, w2, b2, k, d, add=None, scale=1.0, out_slope=1.0):
     x_raw = torch.where(xat >= 0, xat, xat * inv)
     y = F.conv1d(t, w2, b2, padding=(k - 1) // 2) + x_raw
     if add is not None:                      # the running sum is added to the ROUNDED pair output, on the way out
-        y = (_r(y) + add.transpose(1, 2)) * scale
+        y = F.leaky_relu((_r(y) + add.transpose(1, 2)) * scale, out_slope)
     else:
         y = F.leaky_relu(y * scale, out_slope)
     return y.transpose(1, 2)
@@ -114,6 +114,10 @@ def test_pair2_mrf_operands_and_output_activation(c, k, d):
     out2 = torch.full_like(xd, float("nan"))
     launch_pair2_bf16(c1, c2, xd, out2, out_slope=SLOPE)
     _check(out2, _reference(xa, w1, b1, w2, b2, k, d, out_slope=SLOPE))
+    # the MRF mean is stored activated for the next stage's ConvTranspose (openvoice/models.py:278-279)
+    out3 = torch.full_like(xd, float("nan"))
+    launch_pair2_bf16(c1, c2, xd, out3, add=addd, scale=1.0 / 3.0, out_slope=SLOPE)
+    _check(out3, _reference(xa, w1, b1, w2, b2, k, d, add=add, scale=1.0 / 3.0, out_slope=SLOPE))
 
 
 def test_pair2_chain_of_three_pairs_matches_raw_residual_chain():
@@ -161,6 +165,4 @@ def test_pair2_rejects_bad_arguments():
         launch_pair2_bf16(c1, c2, x, x)                               # out aliases x
     with pytest.raises(_lib.OvError):
         launch_pair2_bf16(c1, c2, x, torch.empty_like(x), slope=0.0)  # the residual inverse needs slope > 0
-    with pytest.raises(_lib.OvError):                                 # a running sum is stored raw
-        launch_pair2_bf16(c1, c2, x, torch.empty_like(x), add=torch.zeros_like(x), out_slope=0.1)
     assert not pair2_bf16_supported(16, 3, 1) and not pair2_bf16_supported(256, 3, 1)
