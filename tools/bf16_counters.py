@@ -21,7 +21,7 @@ import sys
 from collections import defaultdict
 
 GIB = float(1 << 30)
-FAM = re.compile(r"(conv1d_bf16cl_kernel|respair_bf16cl_kernel|conv_post_tanh_bf16\w*)<?([^>(]*)")
+FAM = re.compile(r"(conv1d_bf16cl_kernel|respair_bf16cl_kernel|respair2_bf16_kernel|conv_post_tanh_bf16\w*)<?([^>(]*)")
 
 
 def rows(d):
@@ -100,6 +100,11 @@ def main():
     allk = busy.get("ALL ovk16 kernels", {})
     out["mfma_busy"] = allk.get("mfma_busy")
     out["shader_clock_ghz"] = allk.get("shader_clock_ghz")
+    out["wait_any_frac"] = allk.get("wait_any_frac")
+    out["note"] = ("wait_any_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES over ALL resident waves; respair2_bf16_kernel keeps four "
+                   "loader waves per workgroup parked at barriers by design (they issue the LDS-DMA and the stores), so "
+                   "half of its wave-cycles are waits even when its four matrix waves never stall; mfma_busy is per SIMD "
+                   "and is not affected")
     out["by_kernel"] = busy
     json.dump(out, sys.stdout, indent=1)
     print()
