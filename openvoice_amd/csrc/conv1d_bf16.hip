@@ -370,14 +370,17 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
   }
 
   // ---- epilogue: scale, round to bf16, store channels-last ------------------------------------------------
-  // Plain convs (phase_s <= 1): the workgroup's TT x NB output tile goes through LDS and leaves as 16-byte stores of
+  // The workgroup's TT x NB output tile goes through LDS and leaves as 16-byte stores of
   // whole rows -- NB * 2 bytes contiguous per time row, 4 KiB per instruction round of the four matrix waves.  Storing
   // from the accumulator layout is 64 two-byte store instructions per lane and tile, each 2 x 64 bytes, and the CU's
   // store path is issue-bound (the regime profiles/r02_s13 measured on the fp32 kernel): staging took the k = 3 convs
   // 10-20 % down (profiles/r02_s14).  (MFMAs issued transposed + 8-byte stores from registers, tried earlier in round
   // 2, touch 32 rows x 16 B per instruction and were no faster.)
   mark(3);
-  if (p.phase_s <= 1) {
+  // ConvTranspose (phase_s > 1) takes the same path: its rows are packed phase-major (row = ph * C + co), so output
+  // element (t * s + ph, co) of the [L * s][C] tensor sits at t * Cout + row -- exactly the channels-last address of a
+  // plain conv with Cout = s * C rows.  (Until round 4 it left as 8-byte stores from the accumulator layout.)
+  {
     const float scale = p.scale;
     const float oslope = p.out_slope > 0.f ? p.out_slope : 1.f;   // 0 (old callers) = none
     unsigned char* stg_out = xs;
@@ -420,36 +423,6 @@ __global__ __launch_bounds__(64 * (4 + NLD)) void conv1d_bf16cl_kernel(const ov_
     }
     mark(6);
     dump();
-    return;
-  }
-  // ConvTranspose (phase_s > 1): 8-byte stores from the accumulator layout (4 channels of one output row).
-  const int s_ph = p.phase_s > 1 ? p.phase_s : 1;
-  const int Creal = Cout / s_ph;
-  uint16_t* outb = p.out + (int64_t)b * L * Cout;           // L * s_ph rows of Creal channels
-  const float scale = p.scale;
-  const float oslope = p.out_slope > 0.f ? p.out_slope : 1.f;   // 0 (old callers) = none
-#pragma unroll
-  for (int n = 0; n < WN; ++n) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int col = 32 * (ntile0 + n) + 8 * q + 4 * half;   // 4 consecutive columns = 4 channels of one phase
-      if (col >= Cout) continue;
-      const int ph = col / Creal, co = col - ph * Creal;
-#pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        const int t = t0 + trow0 + 32 * i + l31;
-        if (t < L) {
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = acc[i][n][4 * q + e] * scale;
-            v[e] = v[e] > 0.f ? v[e] : v[e] * oslope;
-          }
-          *reinterpret_cast<u32x2*>(outb + ((int64_t)t * s_ph + ph) * Creal + co) =
-              u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-        }
-      }
-    }
   }
 }
 
