@@ -430,8 +430,8 @@ int ov_resblock_pair_bf16_supported(int C, int K, int dil);
  *         that activates on load);
  *   with `add` (a RAW tensor, the MRF running sum):
  *   out = bf16(act((bf16(c2(t) + b2 + x~) + add) * scale)).
- * reference openvoice/modules.py:296-306, models.py:280-286.  w1 / w2 from ov_conv1d_bf16_pack(C, C, K), b1 / b2 fp32
- * [C].  out must not alias x; add may alias out. */
+ * reference openvoice/modules.py:296-306, models.py:280-286.  w1 / w2 from ov_conv1d_bf16_pack16(C, C, K), b1 / b2
+ * fp32 [C].  out must not alias x; add may alias out. */
 typedef struct ov_respair2_bf16_params {
   const uint16_t* x;    /* [B][L][C] bf16, activated */
   const uint16_t* w1;
@@ -451,6 +451,9 @@ typedef struct ov_respair2_bf16_params {
   unsigned long long* dbg; /* measurement only, NULL in production: [workgroups][4 matrix + 4 loader waves][8] ticks per phase */
 } ov_respair2_bf16_params;
 int ov_resblock_pair2_bf16cl(const ov_respair2_bf16_params* p, ov_stream_t stream);
+/* Weights for ov_resblock_pair2_bf16cl (v_mfma_f32_16x16x32_bf16 fragment order; HOST w and dst; dst holds
+ * ov_conv1d_bf16_pack_size(Cout, Cin, K) elements, the last 512 an all-zero record). */
+int ov_conv1d_bf16_pack16(const float* w, int Cout, int Cin, int K, uint16_t* dst);
 int ov_resblock_pair2_bf16_supported(int C, int K, int dil);
 
 /* Library/ABI version (major*100 + minor).  2.01: ov_conv1d_params.col_limit, ov_conv_post_tanh_limited_f32,

@@ -129,6 +129,7 @@ SIGNATURES = {
     "ov_gru_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
     "ov_conv1d_bf16_pack_size": (ctypes.c_size_t, [_i, _i, _i]),
     "ov_conv1d_bf16_pack": (ctypes.c_int, [_fp, _i, _i, _i, _fp]),
+    "ov_conv1d_bf16_pack16": (ctypes.c_int, [_fp, _i, _i, _i, _fp]),
     "ov_conv1d_bf16cl": (ctypes.c_int, [ctypes.POINTER(ConvBf16Params), _fp]),
     "ov_resblock_pair_bf16cl": (ctypes.c_int, [ctypes.POINTER(RespairBf16Params), _fp]),
     "ov_resblock_pair_bf16_supported": (ctypes.c_int, [_i, _i, _i]),

@@ -21,6 +21,12 @@ class PackedConvBf16:
         packed = torch.empty(n, dtype=torch.int16)
         _lib.call("ov_conv1d_bf16_pack", w, self.cout, self.cin, self.K, packed)
         self.w = packed.to(device)
+        # the second-generation fused pair runs on 16x16x32 fragments: its own record order (ov_conv1d_bf16_pack16)
+        self.w16 = None
+        if self.cout == self.cin and _lib.call("ov_resblock_pair2_bf16_supported", self.cin, self.K, dil):
+            packed16 = torch.empty(n, dtype=torch.int16)
+            _lib.call("ov_conv1d_bf16_pack16", w, self.cout, self.cin, self.K, packed16)
+            self.w16 = packed16.to(device)
         self.bias = None if bias is None else bias.detach().float().contiguous().to(device)
 
 
@@ -76,13 +82,15 @@ def launch_pair2_bf16(c1, c2, x, out, add=None, scale=1.0, slope=0.1, out_slope=
     assert c1.cin == c1.cout == c2.cin == c2.cout == C and c1.K == c2.K and c2.dil == 1 and out.shape == x.shape
     for t in (x, out, add):
         assert t is None or (t.dtype == torch.bfloat16 and t.is_contiguous())
+    if c1.w16 is None or c2.w16 is None:
+        raise _lib.OvError(f"ov_resblock_pair2_bf16cl: no 16x16x32 weight stream for C={C} K={c1.K} dil={c1.dil}")
     if _lib.use_torch_binding():
-        _lib.torch_op("resblock_pair2_bf16cl", x, c1.w, c1.bias, c2.w, c2.bias, out, add, dbg,
+        _lib.torch_op("resblock_pair2_bf16cl", x, c1.w16, c1.bias, c2.w16, c2.bias, out, add, dbg,
                       [B, L, C, c1.K, c1.dil, nwg, exp_flags], [slope, scale, out_slope])
         return
     p = _lib.Respair2Bf16Params()
     vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-    p.x, p.w1, p.b1, p.w2, p.b2, p.out, p.add = vp(x), vp(c1.w), vp(c1.bias), vp(c2.w), vp(c2.bias), vp(out), vp(add)
+    p.x, p.w1, p.b1, p.w2, p.b2, p.out, p.add = vp(x), vp(c1.w16), vp(c1.bias), vp(c2.w16), vp(c2.bias), vp(out), vp(add)
     p.B, p.L, p.C, p.K, p.dil, p.nwg = B, L, C, c1.K, c1.dil, nwg
     p.slope, p.scale, p.out_slope, p.exp_flags = slope, scale, out_slope, exp_flags
     p.dbg = vp(dbg)

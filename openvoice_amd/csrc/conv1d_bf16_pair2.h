@@ -48,10 +48,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int NMW = 4;       // matrix waves: one per SIMD
-#ifndef OV_P2_LD
-#define OV_P2_LD 2           // LDS operand buffers of the k-loops: the reads of k-step s + LD - 1 are issued at k-step s
-#endif
-constexpr int LD = OV_P2_LD;     // (3 measured: no faster without the deferred epilogue, spills with it -- profiles/r04_s22)
 constexpr int NLD = 4;       // loader waves (one per SIMD, so every matrix wave has the same company): LDS-DMA in, whole-row stores out
 
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {       // one v_cvt_pk_bf16_f32, round to nearest even
@@ -96,10 +92,6 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-// cells (of the 16 a lane owns) finished before k-step st of an S-step k-loop
-template <int S>
-constexpr int cells_before(int st) { return st >= S ? 16 : (16 * st) / S; }
-
 // (utterance, step) sequence of one workgroup with the warm-up pseudo-step at a mid-utterance start (the tile before
 // the first real one: it only produces the t context rows; nothing of it is stored)
 struct Seq {
@@ -127,10 +119,8 @@ __device__ __forceinline__ int swz(int row) {
   return SPR >= 16 ? (row & 15) : (SPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3));
 }
 
-// WD: depth of the weight-fragment ring -- requests run WD - 1 k-steps (of 4 MFMAs = 128 matrix cycles) ahead
-// DEFER: the epilogue of step i runs INSIDE the c1 k-loop of step i + 1 (its VALU work between the MFMAs), see the
-// kernel; NXB input-tile buffers (3 where they fit: the DMA then runs a whole step ahead)
-template <int K, int DIL, int C, int WD, bool DEFER>
+// WD: depth of the weight-fragment ring -- requests run WD - 1 positions (of 8 MFMAs = 128 matrix cycles) ahead
+template <int K, int DIL, int C, int WD>
 struct Geo {
   static constexpr int NCT = C / 32;                 // 32-channel output tiles = matrix waves along channels
   static constexpr int NTG = NMW / NCT;              // matrix waves along time
@@ -144,17 +134,17 @@ struct Geo {
   static constexpr int XB = NBLK * 1024;             // bytes per input-tile buffer
   static constexpr int PH = 2 * C + 16;              // row pitch of the t tile (conflict-free b128 reads)
   static constexpr int RH = TT + 2 * P2;             // its rows: [2 P2 rows of left context | TT new rows]
-  static constexpr int S = NCH * K * 2;              // k-steps (16 input channels x one tap) of one conv
-  static constexpr int NXB = (DEFER && 3 * XB + RH * PH + 2 * C * 4 <= 160 * 1024) ? 3 : 2;
+  static constexpr int S = NCH * K * 2;              // positions of one conv's k-loop: (32 input channels, tap, 16-channel output fragment)
+  static constexpr int NXB = 2;                      // input-tile buffers
   static constexpr int SMEM = NXB * XB + RH * PH + 2 * C * 4;
   static_assert(NCT * NTG == NMW && (C == 32 || C == 64 || C == 128), "4 matrix waves of 128 x 32");
   static_assert((2 * S) % WD == 0, "the weight ring slot of every k-step must be static");
   static_assert(SMEM <= 160 * 1024, "LDS");
 };
 
-template <int K, int DIL, int C, int WD, bool DEFER>
+template <int K, int DIL, int C, int WD>
 __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const ov_respair2_bf16_params p) {
-  using G = Geo<K, DIL, C, WD, DEFER>;
+  using G = Geo<K, DIL, C, WD>;
   constexpr int NXB = G::NXB;
   constexpr int TT = G::TT, NCH = G::NCH, P1 = G::P1, P2 = G::P2, DELTA = G::DELTA, P = G::P, SPR = G::SPR;
   constexpr int R1 = G::R1, NBLK = G::NBLK, XB = G::XB, PH = G::PH, RH = G::RH, S = G::S, NCT = G::NCT;
@@ -312,104 +302,43 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
     Seq cur(g0, g1, nsteps);                 // the pseudo-step whose barrier A comes next
     int prev_b = 0, prev_tile = 0, q = 0;
     bool prev_real = false;
-    if constexpr (!DEFER) {
-      Seq nxt = cur;                           // the one after it
+    Seq nxt = cur;                           // the one after it
+    nxt.advance();
+    dma(0, cur.b, cur.tile());
+    __builtin_amdgcn_s_barrier();                            // (init: the matrix waves have zeroed the t tile)
+    if (ldbg) llast = __builtin_readcyclecounter();
+    for (; cur.valid(); ++q) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of tile q has landed (and its stores left)
+      lmark(0);
+      __builtin_amdgcn_s_barrier();                          // A(q)
+      lmark(1);
+      const bool out_now = prev_real && !idle;
+      if (out_now) fetch_tile((q + 1) & 1);                  // output tile of q - 1, built in place in ITS input buffer
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every LDS read of that buffer has returned
+      if (p.exp_flags & 8) {                                 // MEASUREMENT ONLY: ~500 VALU instructions of busy work
+        f32x2 d0 = {1.0f + lane, 2.0f}, d1 = {3.0f, 4.0f + lane};
+        for (int it = 0; it < 64; ++it) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { d0 = d0 * d1 + d0; d1 = d1 * d0 + d1; }
+        }
+        if (d0[0] + d1[1] == 12345.678f) ov[0][0] = 1u;      // (keeps the loop alive)
+      }
+      lmark(2);
+      if (nxt.valid() && !idle) dma((q + 1) & 1, nxt.b, nxt.tile());
+      lmark(3);
+      __builtin_amdgcn_s_barrier();                          // B(q)
+      lmark(4);
+      if (out_now) store(prev_b, prev_tile);
+      if (has_add && !cur.warm) add_request(cur.b, cur.tile());   // consumed after B(q + 1)
+      lmark(6);
+      __builtin_amdgcn_s_barrier();                          // C(q)
+      lmark(5);
+      prev_real = !cur.warm; prev_b = cur.b; prev_tile = cur.tile();
+      cur = nxt;
       nxt.advance();
-      dma(0, cur.b, cur.tile());
-      __builtin_amdgcn_s_barrier();                            // (init: the matrix waves have zeroed the t tile)
-      if (ldbg) llast = __builtin_readcyclecounter();
-      for (; cur.valid(); ++q) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of tile q has landed (and its stores left)
-        lmark(0);
-        __builtin_amdgcn_s_barrier();                          // A(q)
-        lmark(1);
-        const bool out_now = prev_real && !idle;
-        if (out_now) fetch_tile((q + 1) & 1);                  // output tile of q - 1, built in place in ITS input buffer
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every LDS read of that buffer has returned
-        if (p.exp_flags & 8) {                                 // MEASUREMENT ONLY: ~500 VALU instructions of busy work
-          f32x2 d0 = {1.0f + lane, 2.0f}, d1 = {3.0f, 4.0f + lane};
-          for (int it = 0; it < 64; ++it) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { d0 = d0 * d1 + d0; d1 = d1 * d0 + d1; }
-          }
-          if (d0[0] + d1[1] == 12345.678f) ov[0][0] = 1u;      // (keeps the loop alive)
-        }
-        lmark(2);
-        if (nxt.valid() && !idle) dma((q + 1) & 1, nxt.b, nxt.tile());
-        lmark(3);
-        __builtin_amdgcn_s_barrier();                          // B(q)
-        lmark(4);
-        if (out_now) store(prev_b, prev_tile);
-        if (has_add && !cur.warm) add_request(cur.b, cur.tile());   // consumed after B(q + 1)
-        lmark(6);
-        __builtin_amdgcn_s_barrier();                          // C(q)
-        lmark(5);
-        prev_real = !cur.warm; prev_b = cur.b; prev_tile = cur.tile();
-        cur = nxt;
-        nxt.advance();
-      }
-      __builtin_amdgcn_s_barrier();                            // A(end): the last output tile is complete
-      if (prev_real) { fetch_tile((q + 1) & 1); store(prev_b, prev_tile); }
-    } else {
-      // Deferred epilogue: the output tile of step q - 1 is complete at barrier B(q) (its cells were finished inside
-      // the c1 loop of step q).  After B(q): tile -> registers (frees the buffer), the running-sum rows of that tile are
-      // requested, the DMA of step q + NXB - 1 goes into the freed buffer -- the LAST memory operations this wave issues
-      // before barrier A(q + 1), so that a counted vmcnt can leave exactly them in flight when there are three buffers.
-      // The stores (300 cycles of issue each) wait for the next A -> B window, where the loaders have nothing else to do.
-      constexpr int NDMA0 = (NBLK + NLD - 1) / NLD;            // DMA instructions per tile of loader wave 0 (the others:
-      const int ndma = (NBLK - lw + NLD - 1) / NLD;            // NDMA0 or NDMA0 - 1)
-      Seq ahead = cur;                                         // the pseudo-step whose tile is requested next
-#pragma unroll
-      for (int k = 0; k < NXB - 1; ++k) {
-        if (ahead.valid()) dma(k, ahead.b, ahead.tile());
-        ahead.advance();
-      }
-      __builtin_amdgcn_s_barrier();                            // (init)
-      if (ldbg) llast = __builtin_readcyclecounter();
-      bool ovalid = false, dma_last = false;
-      int ob = 0, otile = 0;
-      for (; cur.valid(); ++q) {
-        // x(q) has landed; with three buffers the DMA issued after B(q - 1) (tile q + 1) may stay in flight
-        if (NXB == 3 && dma_last) {
-          if (ndma == NDMA0) __builtin_amdgcn_s_waitcnt(0x0F70 | (NDMA0 & 15) | ((NDMA0 >> 4) << 14));
-          else __builtin_amdgcn_s_waitcnt(0x0F70 | ((NDMA0 - 1) & 15) | (((NDMA0 - 1) >> 4) << 14));
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        asm volatile("" ::: "memory");
-        lmark(0);
-        __builtin_amdgcn_s_barrier();                          // A(q)
-        lmark(1);
-        if (ovalid && !idle) store(ob, otile);                 // output tile of q - 2 (in registers since B(q - 1))
-        ovalid = false;
-        lmark(6);
-        __builtin_amdgcn_s_barrier();                          // B(q)
-        lmark(4);
-        if (prev_real && !idle) {
-          fetch_tile((q + NXB - 1) % NXB);                     // output tile of q - 1
-          ovalid = true; ob = prev_b; otile = prev_tile;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every LDS read of that buffer has returned
-        lmark(2);
-        if (has_add && prev_real && !idle) add_request(prev_b, prev_tile);   // consumed after A(q + 1)
-        dma_last = ahead.valid() && !idle;
-        if (dma_last) dma((q + NXB - 1) % NXB, ahead.b, ahead.tile());
-        lmark(3);
-        __builtin_amdgcn_s_barrier();                          // C(q)
-        lmark(5);
-        prev_real = !cur.warm; prev_b = cur.b; prev_tile = cur.tile();
-        cur.advance();
-        ahead.advance();
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                            // A(end): the matrix waves have finished the last tile
-      if (ovalid) store(ob, otile);
-      if (prev_real) {
-        fetch_tile((q + NXB - 1) % NXB);
-        if (has_add) add_request(prev_b, prev_tile);
-        store(prev_b, prev_tile);
-      }
     }
+    __builtin_amdgcn_s_barrier();                            // A(end): the last output tile is complete
+    if (prev_real) { fetch_tile((q + 1) & 1); store(prev_b, prev_tile); }
     if (ldbg && lane == 0) {
       lt[7] = (unsigned long long)q;
 #pragma unroll
@@ -419,18 +348,25 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
   }
 
   // ================================== matrix waves ================================================
+  // v_mfma_f32_16x16x32_bf16, D[channel][time] = W (16 channels x 32 k) * x (32 k x 16 time rows): the chip's bf16 matrix
+  // pipe is POWER-limited on real operands, and this shape does 12 % more matrix work per watt than 32x32x16 (a 16 x 16
+  // tile moves a quarter of the accumulator per instruction; profiles/r03_s5_mfma_sustained_ceilings_fp32_bf16.txt, and
+  // in this kernel profiles/r04_s27: 1.57 -> 1.88 GHz at the same flops).  A wave's 128 x 32 tile is 8 (time) x 2
+  // (channel) fragments; per 32 input channels of one tap it reads 8 x operands (16 bytes per lane each) and 2 weight
+  // records -- the same operand bytes per flop as the 32x32x16 tiling had.  A lane holds time row 16 j + (lane & 15)
+  // and channels 16 f + 4 (lane >> 4) + {0..3} of fragment (f, j): one 8-byte cell, as before.
   __builtin_amdgcn_s_setprio(2);                     // ahead of the loader wave on the same SIMD at every issue
-  const int half = lane >> 5, l31 = lane & 31;
+  const int g4 = lane >> 4, l15 = lane & 15;
   const int nt = wave % NCT, tg = wave / NCT;        // this wave's output-channel tile / time group
   const int trow0 = 128 * tg;
   for (int e = tid; e < RH * PH / 4; e += 64 * NMW) reinterpret_cast<uint32_t*>(hb)[e] = 0u;
   if (tid < C) { bsm[tid] = p.b1[tid]; bsm[C + tid] = p.b2[tid]; }
 
-  // packed weights (ov_conv1d_bf16_pack): record ((nt * NCH + c) * K + tap) * 2 + kb, 64 lanes x 16 bytes.
+  // packed weights (ov_conv1d_bf16_pack16): record ((nt * NCH + c) * K + tap) * 2 + f, 64 lanes x 16 bytes.
   // Weight stream of a step: positions [0, S) = c1's records, [S, 2 S) = c2's, then the next step's c1 again; the
   // request for position pos + WD - 1 is issued at position pos into ring slot (pos + WD - 1) % WD -- a compile-time
   // constant everywhere because 2 S % WD == 0.  `wp` is the (wave-uniform) running pointer of the request stream: a
-  // loop-carried scalar, so the record addresses are two SALU adds per k-step (as `base + constant` they are loop
+  // loop-carried scalar, so the record addresses are two SALU adds per position (as `base + constant` they are loop
   // invariants and hipcc hoists all 2 S of them out of the step loop: hundreds of spilled registers).
   typedef const __attribute__((address_space(1))) u32x4* gw_ptr;    // explicitly GLOBAL: behind the asm below hipcc would
   const gw_ptr wg1 = (gw_ptr)(p.w1) + (size_t)nt * S * 64;          // otherwise fall back to flat loads, which also count
@@ -450,21 +386,24 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
   for (int q = 0; q < WD - 1; ++q) wq[q] = wnext(q);
   wq[WD - 1] = wq[0];
 
-  // per-lane LDS offsets of c1's B operand (input tile): row trow0 + l31 + tap DIL (+ 32 i), logical slot
-  // 4 c + 2 kb + half  ->  byte (row * P + 16 * (half ^ g(row)))  ^  (64 c + 32 kb)
+  // per-lane LDS offsets of c1's x operand (input tile): row trow0 + l15 + tap DIL (+ 16 j), logical slot 4 c + g4
+  //   ->  byte (row * P + 16 * (g4 ^ g(row)))  ^  64 c      (one register per tap: K; computing g(row) per (c, tap) in the
+  //   k-loop instead costs five VALU instructions in one MFMA gap, +8 % on c1 -- profiles/r04_s28)
   uint32_t xl_tap[K];
 #pragma unroll
   for (int tap = 0; tap < K; ++tap) {
-    const int row = trow0 + l31 + tap * DIL;
-    xl_tap[tap] = (uint32_t)(row * P + 16 * (half ^ swz<SPR>(row)));
+    const int row = trow0 + l15 + tap * DIL;
+    xl_tap[tap] = (uint32_t)(row * P + 16 * (g4 ^ swz<SPR>(row)));
   }
-  // c2's B operand (t tile): row trow0 + l31 + tap (+ 32 i), byte 64 c + 32 kb + 16 half
-  const uint32_t hl_off = (uint32_t)((trow0 + l31) * PH + half * 16);
-  // epilogue cells: input-tile row trow0 + l31 + DELTA (+ 32 i), logical slot 4 nt + q, byte 8 half inside it
-  const int erow = trow0 + l31 + DELTA;
-  uint32_t ecell[4];
+  // c2's x operand (t tile): row trow0 + l15 + tap (+ 16 j), byte 64 c + 16 g4
+  const uint32_t hl_off = (uint32_t)((trow0 + l15) * PH + g4 * 16);
+  // epilogue cells: cell c = 2 j + f of the lane = input-tile row trow0 + l15 + DELTA + 16 j, channels
+  // 32 nt + 16 f + 4 g4 + {0..3}: logical slot 4 nt + 2 f + (g4 >> 1), byte 8 (g4 & 1) inside it
+  const int erow = trow0 + l15 + DELTA;
+  uint32_t ecell[2];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) ecell[q] = (uint32_t)(erow * P + 16 * ((4 * nt + q) ^ swz<SPR>(erow)) + 8 * half);
+  for (int f = 0; f < 2; ++f)
+    ecell[f] = (uint32_t)(erow * P + 16 * ((4 * nt + 2 * f + (g4 >> 1)) ^ swz<SPR>(erow)) + 8 * (g4 & 1));
 
   // measurement only (p.dbg != NULL): shader-clock ticks per phase, summed over the steps of this wave
   // 0 barrier A, 1 c1 k-loop, 2 t -> LDS, 3 barrier B, 4 c2 k-loop, 5 barrier C, 6 epilogue, 7 steps
@@ -483,31 +422,8 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
   const float oslope = (p.out_slope > 0.f && !has_add) ? p.out_slope : 1.f;
   const bool scaled = scale != 1.0f, act_out = oslope != 1.0f;    // (uniform; the epilogue skips what is an identity)
 
-  // Deferred epilogue (DEFER): c2 accumulates into accE, which then waits through the next step's c1 loop, where its
-  // 16 cells per lane are finished one by one -- LDS read a k-step ahead, four ~8-instruction stages placed after
-  // the four MFMAs of a k-step (an MFMA occupies the matrix pipe for 32 cycles: ~5 more instructions issue for free),
-  // LDS write.  As its own phase the epilogue is 2 500 ticks per step of pure VALU with the matrix pipe idle: 8 % of
-  // a K = 11, C = 128 step, 20 % at K = 3 (profiles/r04_s12).
-  f32x16 accE[4];
-  bool pend = false;                                  // accE holds a step's c2 result whose cells are not finished yet
-  uint32_t pbufoff = 0;                               // ... in this input-tile buffer
-  // cell c = 4 i + q of the lane: rows trow0 + l31 + DELTA + 32 i, 4 channels 32 nt + 8 q + 4 half
-  auto cell_addr = [&](int c, uint32_t boff) -> unsigned char* { return xs + boff + ecell[c & 3] + (c >> 2) * 32 * P; };
-  auto cell_stage = [&](auto cc, auto sc, u32x2 xv, f32x2& v0, f32x2& v1, uint32_t boff) {
-    constexpr int c = decltype(cc)::value, stage = decltype(sc)::value;
-    constexpr int i = c >> 2, q = c & 3;
-    if constexpr (stage == 0) {
-      v0 = f32x2{accE[i][4 * q], accE[i][4 * q + 1]} + unlrelu2(unpack2(xv[0]), inv_slope);
-    } else if constexpr (stage == 1) {
-      v0 = lrelu2(v0 * scale, oslope);
-      v1 = unlrelu2(unpack2(xv[1]), inv_slope);
-    } else if constexpr (stage == 2) {
-      v1 = lrelu2((f32x2{accE[i][4 * q + 2], accE[i][4 * q + 3]} + v1) * scale, oslope);
-    } else {
-      const u32x2 o = {pack2(v0[0], v0[1]), pack2(v1[0], v1[1])};
-      if (pend) *reinterpret_cast<u32x2*>(cell_addr(c, boff)) = o;
-    }
-  };
+  // cell c = 2 j + f of the lane (its 16 output cells of 8 bytes)
+  auto cell_addr = [&](int c, uint32_t boff) -> unsigned char* { return xs + boff + ecell[c & 1] + (c >> 1) * 16 * P; };
 
   __syncthreads();                                    // (init: t tile zeroed, biases in LDS)
   if (dbg) tlast = __builtin_readcyclecounter();
@@ -530,90 +446,73 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
       xlb[tap] = xl_tap[tap] + bufoff;     // (XB is a multiple of 1024, the XOR constants are < 256: they commute)
       asm volatile("" : "+v"(xlb[tap]));
     }
-    f32x16 acc[4];
-    auto bias_init = [&](const float* bvec) {
+    f32x4 acc[2][8];
+    auto bias_init = [&](f32x4 (&a)[2][8], const float* bvec) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(bvec + 32 * nt + 8 * q + 4 * half);
+      for (int f = 0; f < 2; ++f) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(bvec + 32 * nt + 16 * f + 4 * g4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[i][4 * q + e] = v[e];
+        for (int j = 0; j < 8; ++j) a[f][j] = v;
       }
     };
-    bias_init(bsm);
+    bias_init(acc, bsm);
     __syncthreads();                                  // A: input tile of this step is in LDS
     mark(0);
-    // ---- c1: t = b1 + W1 * xa  (+ the cells of the previous step's output, DEFER) ----------------------------------
-    {
-      u32x4 aq[LD][4];
-      auto xread = [&](auto sc) {                      // B operands of k-step s' -> buffer s' % LD
-        constexpr int sp = decltype(sc)::value;
-        if constexpr (sp < S && OV_EXP != 11 && OV_EXP != 12) {
-          constexpr int c = sp / (2 * K), tap = (sp / 2) % K, kb = sp & 1;
-          const uint32_t a = xlb[tap] ^ (uint32_t)(64 * c + 32 * kb);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) aq[sp % LD][i] = *reinterpret_cast<const u32x4*>(xs + a + i * 32 * P);
-        }
+    // One k-loop for both convs.  Pair p = (c, tap): positions 2 p (f = 0) and 2 p + 1 (f = 1), each one weight record
+    // against the SAME 8 x operands, 8 MFMAs of 16 matrix cycles.  Everything else a pair has to issue -- the 8 operand
+    // reads of pair p + 1 (into the other buffer set), 2 weight requests, the next operand address -- sits BETWEEN its
+    // MFMAs, one instruction per gap: a 16-cycle MFMA covers one ~5-cycle issue slot, not five of them (as a clump
+    // at the head of a position, the way the 32x32x16 loop had them behind a 32-cycle MFMA, they left the pipe idle
+    // ~18 of every 146 cycles, profiles/r04_s28).  Two lgkmcnt waits per pair: operands 0-3 before its first MFMA
+    // (requested a pair ago), 4-7 before the fifth (requested half a pair + four MFMAs ago).
+    auto kloop = [&](f32x4 (&a)[2][8], auto is_c1, auto&& obase, auto ostride) {
+      constexpr bool C1L = decltype(is_c1)::value;
+      constexpr int POS0 = C1L ? 0 : S;                // position of this conv's first record in the weight stream
+      constexpr int NP = S / 2, STRIDE = decltype(ostride)::value;
+      u32x4 xq[2][8];
+      auto oread = [&](const unsigned char* base, int j) -> u32x4 {
+        if constexpr (OV_EXP == 11 || OV_EXP == 12) return u32x4{0u, 0u, 0u, 0u};
+        else return *reinterpret_cast<const u32x4*>(base + j * STRIDE);
       };
+      const unsigned char* pbn = obase(0, 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 8; ++j) xq[0][j] = oread(pbn, j);
 #pragma unroll
-        for (int b = 0; b < LD; ++b) aq[b][i] = u32x4{0u, 0u, 0u, 0u};
-      static_for<0, LD - 1>([&](auto sc) { xread(sc); });
-      // cells [CB(s), CB(s + 1)) are finished in k-step s; their 8-byte reads are issued a k-step earlier
-      constexpr int MAXC = (16 + S - 1) / S + 1;
-      u32x2 cx[2][MAXC];
-      f32x2 cv0[MAXC], cv1[MAXC];
-      if constexpr (DEFER) {
-        static_for<0, cells_before<S>(1)>([&](auto cc) {
-          constexpr int c = decltype(cc)::value;
-          cx[0][c] = *reinterpret_cast<const u32x2*>(cell_addr(c, pbufoff));
-        });
-      }
-      static_for<0, S>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        constexpr int C0 = cells_before<S>(s), C1 = cells_before<S>(s + 1), C2 = cells_before<S>(s + 2);
-        if constexpr (OV_EXP != 10 && OV_EXP != 12) wq[(s + WD - 1) % WD] = wnext(s + WD - 1);
-        xread(std::integral_constant<int, s + LD - 1>{});
-        constexpr int nread = DEFER ? C2 - C1 : 0;               // cell reads issued behind the operand reads
-        if constexpr (DEFER) {
-          static_for<C1, C2>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            cx[(s + 1) & 1][c - C1] = *reinterpret_cast<const u32x2*>(cell_addr(c, pbufoff));
+      for (int j = 0; j < 8; ++j) xq[1][j] = u32x4{0u, 0u, 0u, 0u};
+      pbn = obase(NP > 1 ? 1 / K : 0, NP > 1 ? 1 % K : 0);
+      static_for<0, NP>([&](auto pc) {
+        constexpr int pr = decltype(pc)::value, cb = pr & 1, nb = cb ^ 1;
+        constexpr bool more = pr + 1 < NP;
+        static_for<0, 2>([&](auto fc) {
+          constexpr int f = decltype(fc)::value, s = 2 * pr + f;
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (f == 0) __builtin_amdgcn_s_waitcnt(0xC07F | (4 << 8));     // operands 0-3 of this pair
+          static_for<0, 8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (f == 0 && j == 4) __builtin_amdgcn_s_waitcnt(0xC07F | ((more ? 4 : 0) << 8));   // operands 4-7
+            bf16x8 av, bv;
+            __builtin_memcpy(&av, &wq[(POS0 + s) % WD], 16);
+            __builtin_memcpy(&bv, &xq[cb][j], 16);
+            if constexpr (OV_EXP == 13) { asm volatile("" :: "v"(av), "v"(bv)); }
+            else a[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, a[f][j], 0, 0, 0);   // D[channel][time]
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (j < 4) {
+              if constexpr (more) xq[nb][4 * f + j] = oread(pbn, 4 * f + j);
+            } else if constexpr (j == 4) {
+              // (overwrites the ring slot of position s - 1, whose MFMAs have all been issued)
+              if constexpr (OV_EXP != 10 && OV_EXP != 12) wq[(POS0 + s + WD - 1) % WD] = wnext(POS0 + s + WD - 1);
+            } else if constexpr (j == 5 && f == 1) {
+              if constexpr (pr + 2 < NP) pbn = obase((pr + 2) / K, (pr + 2) % K);
+            }
+            __builtin_amdgcn_sched_barrier(0);
           });
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ONE wait for the step's four operands (issued a step ago; what was issued in this step stays in flight):
-        // hipcc's own staggered lgkmcnt(7 .. 4) puts an instruction between every two MFMAs, ~6 cycles each
-        {
-          // in flight behind the operands of this step: those of the next LD - 2 steps (issued earlier), of step
-          // s + LD - 1 and the cell reads (issued just now); with DEFER the older cell reads / writes sit in between,
-          // so the count is only exact without them -- a smaller count waits for more, never for less
-          constexpr int ahead = (S - 1 - s < LD - 1 ? S - 1 - s : LD - 1);
-          constexpr int left = DEFER ? ((s + LD - 1 < S ? 4 : 0) + nread) : 4 * ahead;
-          static_assert(left <= 15, "lgkmcnt immediate");
-          __builtin_amdgcn_s_waitcnt(0xC07F | (left << 8));
-        }
-        static_for<0, 4>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          bf16x8 av, bv;
-          __builtin_memcpy(&av, &wq[s % WD], 16);
-          __builtin_memcpy(&bv, &aq[s % LD][i], 16);
-          if constexpr (OV_EXP == 13) { asm volatile("" :: "v"(av), "v"(bv)); }
-          else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i], 0, 0, 0);   // D[channel][time]
-          if constexpr (DEFER && C1 > C0) {
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<C0, C1>([&](auto cc) {
-              constexpr int c = decltype(cc)::value;
-              cell_stage(cc, ic, cx[s & 1][c - C0], cv0[c - C0], cv1[c - C0], pbufoff);
-            });
-            __builtin_amdgcn_sched_barrier(0);
-          }
         });
-        __builtin_amdgcn_sched_barrier(0);
       });
-    }
+    };
+    // ---- c1: t = b1 + W1 * xa ------------------------------------------------------------------------------------
+    kloop(acc, std::true_type{},
+          [&](int c, int tap) -> const unsigned char* { return xs + (xlb[tap] ^ (uint32_t)(64 * c)); },
+          std::integral_constant<int, 16 * P>{});
     mark(1);
     // t: activated in fp32, rounded once, zero outside [0, L) (c2 pads t, not x); 4 consecutive channels per store.
     // (Two copies under a uniform branch: written as one, hipcc turns the row test into a select per value.)
@@ -621,16 +520,16 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
       auto t_write = [&](auto edge) {
         constexpr bool EDGE = decltype(edge)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          unsigned char* hrow = hb + (2 * P2 + trow0 + 32 * i + l31) * PH + (32 * nt + 4 * half) * 2;
-          const bool inside = !EDGE || t0 + trow0 + 32 * i + l31 < L;
+        for (int j = 0; j < 8; ++j) {
+          unsigned char* hrow = hb + (2 * P2 + trow0 + 16 * j + l15) * PH + (32 * nt + 4 * g4) * 2;
+          const bool inside = !EDGE || t0 + trow0 + 16 * j + l15 < L;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x2 a = lrelu2(f32x2{acc[i][4 * q], acc[i][4 * q + 1]}, slope);
-            const f32x2 c = lrelu2(f32x2{acc[i][4 * q + 2], acc[i][4 * q + 3]}, slope);
+          for (int f = 0; f < 2; ++f) {
+            const f32x2 a = lrelu2(f32x2{acc[f][j][0], acc[f][j][1]}, slope);
+            const f32x2 c = lrelu2(f32x2{acc[f][j][2], acc[f][j][3]}, slope);
             u32x2 o = {pack2(a[0], a[1]), pack2(c[0], c[1])};
             if (EDGE && !inside) o = u32x2{0u, 0u};
-            *reinterpret_cast<u32x2*>(hrow + 16 * q) = o;
+            *reinterpret_cast<u32x2*>(hrow + 32 * f) = o;
           }
         }
       };
@@ -641,52 +540,10 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
     __syncthreads();                                  // B: t in LDS
     mark(3);
     // ---- c2 out of the t tile: output row o (global t0 - P2 + o) needs t rows [o, o + K - 1] of the tile ----
-    // (DEFER: into accE, finished during the next step's c1)
-    {
-      f32x16 (&a2)[4] = DEFER ? accE : acc;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(bsm + C + 32 * nt + 8 * q + 4 * half);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) a2[i][4 * q + e] = v[e];
-      }
-      u32x4 aq[LD][4];
-      auto hread = [&](auto sc) {
-        constexpr int sp = decltype(sc)::value;
-        if constexpr (sp < S && OV_EXP != 11 && OV_EXP != 12) {
-          constexpr int c = sp / (2 * K), tap = (sp / 2) % K, kb = sp & 1;
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            aq[sp % LD][i] = *reinterpret_cast<const u32x4*>(hb + hl_off + (tap + 32 * i) * PH + 64 * c + 32 * kb);
-        }
-      };
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int b = 0; b < LD; ++b) aq[b][i] = u32x4{0u, 0u, 0u, 0u};
-      static_for<0, LD - 1>([&](auto sc) { hread(sc); });
-      static_for<0, S>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        if constexpr (OV_EXP != 10 && OV_EXP != 12) wq[(S + s + WD - 1) % WD] = wnext(S + s + WD - 1);
-        hread(std::integral_constant<int, s + LD - 1>{});
-        __builtin_amdgcn_sched_barrier(0);
-        {
-          constexpr int ahead = (S - 1 - s < LD - 1 ? S - 1 - s : LD - 1);
-          __builtin_amdgcn_s_waitcnt(0xC07F | ((4 * ahead) << 8));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          bf16x8 av, bv;
-          __builtin_memcpy(&av, &wq[(S + s) % WD], 16);
-          __builtin_memcpy(&bv, &aq[s % LD][i], 16);
-          if (OV_EXP == 13) { asm volatile("" :: "v"(av), "v"(bv)); continue; }
-          a2[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, a2[i], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      });
-    }
+    bias_init(acc, bsm + C);
+    kloop(acc, std::false_type{},
+          [&](int c, int tap) -> const unsigned char* { return hb + hl_off + tap * PH + 64 * c; },
+          std::integral_constant<int, 16 * PH>{});
     mark(4);
     __syncthreads();                                  // C: every wave is done reading the t tile
     mark(5);
@@ -700,29 +557,22 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
     // ---- epilogue, in place over the input tile: cell = (acc + x~ [+ add]) * scale, activated for its consumer ----
     // All 16 cells of the lane are read first: as read-modify-write per cell the accesses may alias as far as hipcc
     // can tell, and the 16 LDS round trips run one after the other (5 000 ticks per step, profiles/r04_s2).
-    if constexpr (DEFER) {
-      pend = !warm;
-      pbufoff = bufoff;
-    } else if (!warm) {
-      unsigned char* xw = xs + bufoff;
-      u32x2 xv[4][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xv[i][q] = *reinterpret_cast<const u32x2*>(xw + ecell[q] + i * 32 * P);
+    if (!warm) {
+      u32x2 xv[16];
+      static_for<0, 16>([&](auto cc) { xv[decltype(cc)::value] = *reinterpret_cast<const u32x2*>(cell_addr(decltype(cc)::value, bufoff)); });
       // (one copy per case under uniform branches: as run-time flags hipcc evaluates both sides with selects)
       // Stage by stage over four cells, not cell by cell: one wave per SIMD has nobody to cover the ~8-cycle result
       // latency of a VALU instruction, so the seven dependent instructions of a cell must be interleaved with other
       // cells' (hipcc does not do it across the inline-asm min / max).
       auto finish = [&](auto act, auto scl) {
         constexpr bool ACT = decltype(act)::value, SCL = decltype(scl)::value;
-        static_for<0, 4>([&](auto ic) {                      // four cells (eight independent chains) at a time
-          constexpr int i = decltype(ic)::value;
+        static_for<0, 4>([&](auto gc) {                      // four cells (eight independent chains) at a time
+          constexpr int c0 = 4 * decltype(gc)::value;
           f32x2 v[4][2], m[4][2];
           static_for<0, 4>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
-            v[q][0] = unpack2(xv[i][q][0]);
-            v[q][1] = unpack2(xv[i][q][1]);
+            v[q][0] = unpack2(xv[c0 + q][0]);
+            v[q][1] = unpack2(xv[c0 + q][1]);
           });
           static_for<0, 4>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
@@ -730,9 +580,9 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
             m[q][1] = v[q][1] * inv_slope;
           });
           static_for<0, 4>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            v[q][0] = f32x2{vmin(v[q][0][0], m[q][0][0]), vmin(v[q][0][1], m[q][0][1])} + f32x2{acc[i][4 * q], acc[i][4 * q + 1]};
-            v[q][1] = f32x2{vmin(v[q][1][0], m[q][1][0]), vmin(v[q][1][1], m[q][1][1])} + f32x2{acc[i][4 * q + 2], acc[i][4 * q + 3]};
+            constexpr int q = decltype(qc)::value, c = c0 + q, j = c >> 1, f = c & 1;
+            v[q][0] = f32x2{vmin(v[q][0][0], m[q][0][0]), vmin(v[q][0][1], m[q][0][1])} + f32x2{acc[f][j][0], acc[f][j][1]};
+            v[q][1] = f32x2{vmin(v[q][1][0], m[q][1][0]), vmin(v[q][1][1], m[q][1][1])} + f32x2{acc[f][j][2], acc[f][j][3]};
           });
           if constexpr (SCL) {
             static_for<0, 4>([&](auto qc) { constexpr int q = decltype(qc)::value; v[q][0] *= scale; v[q][1] *= scale; });
@@ -751,7 +601,7 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
           }
           static_for<0, 4>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
-            *reinterpret_cast<u32x2*>(xw + ecell[q] + i * 32 * P) =
+            *reinterpret_cast<u32x2*>(cell_addr(c0 + q, bufoff)) =
                 u32x2{pack2(v[q][0][0], v[q][0][1]), pack2(v[q][1][0], v[q][1][1])};
           });
         });
@@ -762,17 +612,6 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
     }
     mark(6);
     tk = nx;
-  }
-  if constexpr (DEFER) {                              // the last step's cells: nothing left to hide them behind
-    if (pend) {
-      u32x2 xv[16];
-      static_for<0, 16>([&](auto cc) { xv[decltype(cc)::value] = *reinterpret_cast<const u32x2*>(cell_addr(decltype(cc)::value, pbufoff)); });
-      static_for<0, 16>([&](auto cc) {
-        f32x2 v0, v1;
-        static_for<0, 4>([&](auto st) { cell_stage(cc, st, xv[decltype(cc)::value], v0, v1, pbufoff); });
-      });
-    }
-    mark(6);
   }
   __syncthreads();                                    // A(end): the last output tile is complete
   if (dbg && lane == 0) {
@@ -796,25 +635,24 @@ inline int cu_count(std::atomic<int>* cache) {
   return cus;
 }
 
-template <int K, int DIL, int C, int WD, bool DEFER>
+template <int K, int DIL, int C, int WD>
 int launch(const ov_respair2_bf16_params* p, hipStream_t stream) {
-  using G = Geo<K, DIL, C, WD, DEFER>;
+  using G = Geo<K, DIL, C, WD>;
   static std::atomic<int> cache[16];
   const int slots = cu_count(cache);                  // one workgroup per CU (its LDS tile fills the CU)
   const long SS = (long)p->B * ((p->L + G::P2 + G::TT - 1) / G::TT);
   long nwg = p->nwg > 0 ? p->nwg : slots;
   if (nwg > SS) nwg = SS;
-  hipLaunchKernelGGL((respair2_bf16_kernel<K, DIL, C, WD, DEFER>), dim3((unsigned)nwg), dim3(64 * (NMW + NLD)), 0, stream, *p);
+  hipLaunchKernelGGL((respair2_bf16_kernel<K, DIL, C, WD>), dim3((unsigned)nwg), dim3(64 * (NMW + NLD)), 0, stream, *p);
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
 }
 
 template <int K, int DIL>
 int launch_by_width(const ov_respair2_bf16_params* p, hipStream_t stream) {
-  const bool defer = !(p->exp_flags & 2);     // (bit 1: the epilogue as its own phase -- A/B measurements)
-  // C = 32: 2 S = 4 K k-steps per step: a 4-deep ring; the 45 KB of both convs' weights are L1 / L2 hits for all waves
-  if (p->C == 32) return defer ? launch<K, DIL, 32, 4, true>(p, stream) : launch<K, DIL, 32, 4, false>(p, stream);
-  if (p->C == 64) return defer ? launch<K, DIL, 64, 8, true>(p, stream) : launch<K, DIL, 64, 8, false>(p, stream);
-  if (p->C == 128) return defer ? launch<K, DIL, 128, 8, true>(p, stream) : launch<K, DIL, 128, 8, false>(p, stream);
+  // C = 32: 2 S = 4 K positions per step: a 4-deep ring; the 45 KB of both convs' weights are L1 / L2 hits for all waves
+  if (p->C == 32) return launch<K, DIL, 32, 4>(p, stream);
+  if (p->C == 64) return launch<K, DIL, 64, 8>(p, stream);
+  if (p->C == 128) return launch<K, DIL, 128, 8>(p, stream);
   return OV_E_UNSUPPORTED;
 }
 

@@ -371,6 +371,7 @@ TORCH_LIBRARY(openvoice_amd, m) {
   bind_host<&ov_conv1d_pack_f32>(m, "conv1d_pack_f32");
   bind_host<&ov_wn_pack_f32>(m, "wn_pack_f32");
   bind_host<&ov_conv1d_bf16_pack>(m, "conv1d_bf16_pack");
+  bind_host<&ov_conv1d_bf16_pack16>(m, "conv1d_bf16_pack16");
   bind_value<&ov_conv1d_pack_size>(m, "conv1d_pack_size");
   bind_value<&ov_conv1d_pack_rows>(m, "conv1d_pack_rows");
   bind_value<&ov_wn_pack_size>(m, "wn_pack_size");

@@ -9,10 +9,11 @@ make -j8 > /dev/null
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -Wno-unused-result -Wno-pass-failed"
 for e in "$@"; do
   d=build_exp$e; mkdir -p $d
-  /opt/rocm/bin/hipcc $FLAGS -DOV_EXP=$e -c conv1d_bf16_pair2.hip -o $d/conv1d_bf16_pair2.o &
-  /opt/rocm/bin/hipcc $FLAGS -DOV_EXP=$e -c ov_api.hip -o $d/ov_api.o &
+  for f in conv1d_bf16_pair2 conv1d_bf16_pair2_k3 conv1d_bf16_pair2_k7 conv1d_bf16_pair2_k11 ov_api; do
+    /opt/rocm/bin/hipcc $FLAGS -DOV_EXP=$e -c $f.hip -o $d/$f.o &
+  done
   wait
-  objs=$(ls build/*.o | grep -v "conv1d_bf16_pair2.o\|ov_api.o")
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs $d/conv1d_bf16_pair2.o $d/ov_api.o -o $d/libopenvoice_amd_exp$e.so
+  objs=$(ls build/*.o | grep -v "conv1d_bf16_pair2\|ov_api.o")
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs $d/conv1d_bf16_pair2*.o $d/ov_api.o -o $d/libopenvoice_amd_exp$e.so
   echo "built $d/libopenvoice_amd_exp$e.so"
 done

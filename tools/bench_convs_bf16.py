@@ -44,7 +44,7 @@ def pair2_table(args):
     from openvoice_amd.bf16 import launch_pair2_bf16, launch_pair_bf16, pair_bf16_supported
     dev, B = "cuda:0", args.batch
     print(f"B={B}: pair2 (ov_resblock_pair2_bf16cl) vs c1 + c2 launches [vs first-generation pair]; TF/s = both convs")
-    print(f"{'C':>4} {'L':>7} {'k':>2} {'d':>1} {'pair2 ms':>9} {'TF/s':>7} {'GB/s':>7} {'+add ms':>8} {'c1+c2 ms':>9} {'pair1 ms':>9} {'no-defer':>9}")
+    print(f"{'C':>4} {'L':>7} {'k':>2} {'d':>1} {'pair2 ms':>9} {'TF/s':>7} {'GB/s':>7} {'+add ms':>8} {'c1+c2 ms':>9} {'pair1 ms':>9}")
     for c, L in [(128, 55104), (64, 110208), (32, 220416)]:
         x = torch.randn(B, L, c, device=dev).to(torch.bfloat16)
         xa = F.leaky_relu(x.float(), 0.1).to(torch.bfloat16)
@@ -59,13 +59,12 @@ def pair2_table(args):
                     launch_conv_bf16(c2, t, out, in_slope=1.0, res=x)
                 ms = timed(lambda: launch_pair2_bf16(c1, c2, xa, out, out_slope=0.1), args.reps, 100.0)
                 msa = timed(lambda: launch_pair2_bf16(c1, c2, xa, out, add=add, scale=1.0 / 3.0), args.reps, 100.0)
-                msn = timed(lambda: launch_pair2_bf16(c1, c2, xa, out, out_slope=0.1, exp_flags=2), args.reps, 100.0)
                 ms2 = timed(two, args.reps, 100.0)
                 ms1 = (timed(lambda: launch_pair_bf16(c1, c2, x, out), args.reps, 100.0)
                        if pair_bf16_supported(c, k, d) else float("nan"))
                 tf = 2 * 2.0 * c * c * k * L * B / ms / 1e9
                 print(f"{c:>4} {L:>7} {k:>2} {d:>1} {ms:9.3f} {tf:7.1f} {2 * 2.0 * B * c * L / ms / 1e6:7.0f} {msa:8.3f} "
-                      f"{ms2:9.3f} {ms1:9.3f} {msn:9.3f}", flush=True)
+                      f"{ms2:9.3f} {ms1:9.3f}", flush=True)
         del x, xa, t, out, add
     print("done")
 
