@@ -129,6 +129,35 @@ def test_bf16_weight_packer_layout_and_rounding(cout, cin, k):
     assert lib.ov_conv1d_bf16cl(None, None) == -1
 
 
+@pytest.mark.parametrize("c,k", [(32, 3), (64, 7), (128, 11)])
+def test_bf16_pair2_weight_stream_is_in_16x16x32_fragment_order(c, k):
+    """ov_conv1d_bf16_pack16 (the fused pair's weights): record ((nt * chunks + ch) * K + tap) * 2 + f, lane l, element i
+    holds bf16(W[32 nt + 16 f + (l & 15)][32 ch + 8 (l >> 4) + i][tap]) -- the A operand of v_mfma_f32_16x16x32_bf16 --
+    the same multiset of values as ov_conv1d_bf16_pack's stream, one trailing zero record."""
+    lib = _lib.load()
+    w = torch.randn(c, c, k, generator=torch.Generator().manual_seed(c + k))
+    n = lib.ov_conv1d_bf16_pack_size(c, c, k)
+    dst, old = torch.full((n,), -1, dtype=torch.int16), torch.full((n,), -1, dtype=torch.int16)
+    assert lib.ov_conv1d_bf16_pack16(w.data_ptr(), c, c, k, dst.data_ptr()) == 0
+    assert lib.ov_conv1d_bf16_pack(w.data_ptr(), c, c, k, old.data_ptr()) == 0
+    ntiles = chunks = c // 32
+    got = dst.view(torch.bfloat16).float().reshape(ntiles * chunks * k * 2 + 1, 64, 8)
+    want = w.to(torch.bfloat16).float()
+    lane = torch.arange(64)
+    for nt in range(ntiles):
+        for ch in range(chunks):
+            for tap in range(k):
+                for f in range(2):
+                    rec = got[((nt * chunks + ch) * k + tap) * 2 + f]
+                    for i in range(8):
+                        exp = want[32 * nt + 16 * f + (lane & 15), 32 * ch + 8 * (lane >> 4) + i, tap]
+                        assert torch.equal(rec[:, i], exp), (nt, ch, tap, f, i)
+    assert torch.all(got[-1] == 0)
+    assert torch.equal(dst.sort().values, old.sort().values)
+    assert lib.ov_conv1d_bf16_pack16(None, c, c, k, dst.data_ptr()) == -1
+    assert lib.ov_conv1d_bf16_pack16(w.data_ptr(), c, 40, k, dst.data_ptr()) == -1   # Cin must be a multiple of 32
+
+
 def test_respair_params_struct_matches_header_field_order_and_size():
     header = open(os.path.join(REPO, "include", "openvoice_amd.h")).read()
     body = header[header.index("typedef struct ov_respair_params {"):header.index("} ov_respair_params;")]
