@@ -445,9 +445,8 @@ typedef struct ov_respair2_bf16_params {
   float slope;          /* leaky-ReLU slope of x and t, 0 < slope <= 1 */
   float scale;
   float out_slope;      /* 0 or 1.0f = store the raw sum */
-  int32_t exp_flags;    /* 0 in production.  bit 1 (value 2) = run the epilogue as its own phase instead of deferred
-                         * into the next step's c1 loop (bit-identical; tests).  MEASUREMENT ONLY: bit 0 = the loader
-                         * waves idle after the first tile (wrong results); value 8 = loader busy-work (phase form) */
+  int32_t exp_flags;    /* 0 in production.  MEASUREMENT ONLY: bit 0 = the loader waves idle after the first tile (wrong
+                         * results); value 8 = ~500 VALU instructions of busy work per step on the loader waves */
   unsigned long long* dbg; /* measurement only, NULL in production: [workgroups][4 matrix + 4 loader waves][8] ticks per phase */
 } ov_respair2_bf16_params;
 int ov_resblock_pair2_bf16cl(const ov_respair2_bf16_params* p, ov_stream_t stream);
