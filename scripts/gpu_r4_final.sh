@@ -4,7 +4,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-O=gpurun_out/r4final; mkdir -p $O
+O=gpurun_out/${OUT:-r4final}; mkdir -p $O
 echo "== gpu tests"; timeout 1500 python -m pytest tests -q -m gpu --timeout 900 2>&1 | grep -v amdgpu.ids | grep "passed\|failed\|rror" | tail -6 | tee $O/gpu_tests.txt
 echo "== smoke"; timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -1 | tee $O/smoke.log
 echo "== bench (driver defaults)"; timeout 400 python bench.py 2>&1 | grep -v amdgpu.ids | tail -1 | tee $O/bench_default.log | cut -c1-200
