@@ -159,8 +159,21 @@ def cpu_baseline(sd, cfg, seconds, budget_s=20.0, want_reference=True, batch32=F
     torch.set_num_threads(cores)
     est32 = 32.0 * el / n
     if not batch32:
+        # bounded stand-in for the B = 32 leg of SURVEY.md section 8d: a batch of 32 SHORT utterances (a tenth of the
+        # workload's length, >= 0.5 s) -- the same batched operators and thread count, a few seconds of CPU
         out["batch32"] = None
-        sample.append(f"B=32 not run (--cpu-batch32; estimated {est32:.0f} s)")
+        short_s = max(0.5, seconds / 10.0)
+        if seconds >= 2.0 and est32 * short_s / seconds <= 12.0:
+            wave32 = synth_wave(32, int(short_s * SAMPLE_RATE), 9, "cpu")
+            t0 = time.perf_counter()
+            convert(wave32)
+            el32 = time.perf_counter() - t0
+            out["batch32_short"] = dict(value=round(32 * short_s / el32, 3), utterances_per_s=round(32.0 / el32, 4),
+                                        utterance_s=short_s, cores=cores)
+            sample.append(f"1 x (B=32 x {short_s:.1f} s) on {cores} threads, {el32:.1f} s; the full B=32 x {seconds:.0f} s "
+                          f"leg only with --cpu-batch32 (estimated {est32:.0f} s)")
+        else:
+            sample.append(f"B=32 not run (--cpu-batch32; estimated {est32:.0f} s)")
     elif est32 <= max(30.0, 4.0 * budget_s):
         wave32 = synth_wave(32, samples, 9, "cpu")
         t0 = time.perf_counter()
