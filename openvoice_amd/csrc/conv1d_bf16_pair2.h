@@ -140,10 +140,11 @@ struct Geo {
   // Both convs' weight streams resident in LDS where they fit beside the tiles (C = 32 except K = 11 with dilation 5,
   // C = 64 with K = 3): the short k-loops of exactly these shapes otherwise wait for their weight requests behind the
   // loader waves' stores in the CU's memory pipe (c2 2 584 ticks for 768 of MFMA issue at C = 32, K = 3, profiles/r04_s34)
-  static constexpr int WBYTES = 2 * NCT * S * 1024;  // [conv][channel tile][position] records of 1 KiB
+  // WMODE 2 = both convs' streams, 1 = c1's only (C = 64, K = 7 / 11: its requests share the window with the DMA), 0 = none
   static constexpr int WOFF = (BASE + 1023) / 1024 * 1024;
-  static constexpr bool WLDS = C <= 64 && WOFF + WBYTES <= 160 * 1024;
-  static constexpr int SMEM = WLDS ? WOFF + WBYTES : BASE;
+  static constexpr int WMODE = C > 64 ? 0 : (WOFF + 2 * NCT * S * 1024 <= 160 * 1024 ? 2 : (WOFF + NCT * S * 1024 <= 160 * 1024 ? 1 : 0));
+  static constexpr int WBYTES = WMODE * NCT * S * 1024;   // [conv][channel tile][position] records of 1 KiB
+  static constexpr int SMEM = WMODE ? WOFF + WBYTES : BASE;
   static_assert(NCT * NTG == NMW && (C == 32 || C == 64 || C == 128), "4 matrix waves of 128 x 32");
   static_assert((2 * S) % WD == 0, "the weight ring slot of every k-step must be static");
   static_assert(SMEM <= 160 * 1024, "LDS");
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
   unsigned char* const xs = smem;                    // NXB input tiles
   unsigned char* const hb = smem + NXB * XB;         // the t tile
   float* const bsm = reinterpret_cast<float*>(smem + NXB * XB + RH * PH);
-  constexpr bool WLDS = G::WLDS;
+  constexpr int WMODE = G::WMODE;
   unsigned char* const wl = smem + G::WOFF;          // (WLDS) both convs' weight streams
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -169,9 +170,9 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
   const long SS = (long)p.B * nsteps;
   const long g0 = SS * blockIdx.x / gridDim.x, g1 = SS * (blockIdx.x + 1) / gridDim.x;
   if (g0 >= g1) return;
-  if constexpr (WLDS) {                               // visible after the init barrier below (all waves take part)
+  if constexpr (WMODE > 0) {                          // visible after the init barrier below (all waves take part)
     constexpr int HALF = NCT * S * 64;                // 16-byte vectors per conv
-    for (int e = tid; e < 2 * HALF; e += 64 * (NMW + NLD)) {
+    for (int e = tid; e < WMODE * HALF; e += 64 * (NMW + NLD)) {
       const u32x4* src = reinterpret_cast<const u32x4*>(e < HALF ? p.w1 : p.w2);
       reinterpret_cast<u32x4*>(wl)[e] = src[e < HALF ? e : e - HALF];
     }
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
   const unsigned char* const wlane = wl + nt * S * 1024 + lane * 16;
   auto wnext = [&](int pos) -> u32x4 {     // `pos` (the position being requested) is a compile-time constant at every call
     const int q = pos % (2 * S);
-    if constexpr (WLDS) return *reinterpret_cast<const u32x4*>(wlane + ((q / S) * NCT * S + q % S) * 1024);
+    if (WMODE == 2 || (WMODE == 1 && q < S)) return *reinterpret_cast<const u32x4*>(wlane + ((q / S) * NCT * S + q % S) * 1024);
     if (q == 0) wp = wg1;
     if (q == S) wp = wg2;
     asm volatile("" : "+s"(wp));          // opaque: keeps the request address a scalar base + lane offset
@@ -504,11 +505,12 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
         static_for<0, 2>([&](auto fc) {
           constexpr int f = decltype(fc)::value, s = 2 * pr + f;
           __builtin_amdgcn_sched_barrier(0);
-          // (WLDS: one weight read per position sits in the same in-order queue, issued after MFMA 4)
-          if constexpr (f == 0) __builtin_amdgcn_s_waitcnt(0xC07F | ((WLDS ? 6 : 4) << 8));     // operands 0-3 of this pair
+          // (WL: one weight read per position sits in the same in-order queue, issued after MFMA 4)
+          constexpr bool WL = WMODE == 2 || (WMODE == 1 && C1L);
+          if constexpr (f == 0) __builtin_amdgcn_s_waitcnt(0xC07F | ((WL ? 6 : 4) << 8));     // operands 0-3 of this pair
           static_for<0, 8>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            if constexpr (f == 0 && j == 4) __builtin_amdgcn_s_waitcnt(0xC07F | (((more ? 4 : 0) + (WLDS ? 1 : 0)) << 8));   // operands 4-7
+            if constexpr (f == 0 && j == 4) __builtin_amdgcn_s_waitcnt(0xC07F | (((more ? 4 : 0) + (WL ? 1 : 0)) << 8));   // operands 4-7
             bf16x8 av, bv;
             __builtin_memcpy(&av, &wq[(POS0 + s) % WD], 16);
             __builtin_memcpy(&bv, &xq[cb][j], 16);
