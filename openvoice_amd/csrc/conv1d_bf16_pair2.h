@@ -205,6 +205,10 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
     typedef const __attribute__((address_space(1))) unsigned char* gc_ptr;
     typedef __attribute__((address_space(1))) unsigned char* gm_ptr;
     typedef __attribute__((address_space(3))) unsigned char* lds_ptr;
+    // C = 128, K = 3: a pause of 256 cycles after every DMA instruction.  The 46 requests of a tile otherwise enter the CU's
+    // memory pipe as one burst ahead of the matrix waves' weight requests, and a k-loop of 24 positions cannot ride that
+    // out: c1 4 985 -> 4 489 ticks per step, 0.757 -> 0.731 ms (profiles/r04_s36; no effect at K >= 7, too slow at 512).
+    constexpr bool PACE_DMA = C == 128 && K == 3;
     auto dma = [&](int buf, int b, int tile) {
       const int tbase = tile * TT - P1;
       const gc_ptr xb = (gc_ptr)(p.x) + ((int64_t)b * L + tbase) * P + lw * 1024;                          // (uniform)
@@ -217,6 +221,7 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
             asm volatile("" : "+s"(bj));     // opaque per block: scalar base + per-lane offset, no 64-bit vector adds
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bj + dof),
                                              (__attribute__((address_space(3))) void*)(lb + j * (NLD * 1024)), 16, 0, 0);
+            if constexpr (PACE_DMA) __builtin_amdgcn_s_sleep(4);
           }
         return;
       }

@@ -50,6 +50,8 @@ def kernel_source_digest():
     here = os.path.dirname(os.path.abspath(__file__))
     files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h")) +
                    glob.glob(os.path.join(here, "..", "include", "*.h")) + [os.path.join(here, "engine.py")])
+    # the opt-in bf16 generator's kernels (conv1d_bf16*.hip / .h) launch nothing on the fp32 path the record is about
+    files = [f for f in files if not os.path.basename(f).startswith("conv1d_bf16")]
     h = hashlib.sha256()
     for f in files:
         h.update(os.path.basename(f).encode())
