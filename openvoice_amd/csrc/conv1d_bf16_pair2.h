@@ -20,8 +20,9 @@
 //   * the output tile is built IN PLACE over the consumed input tile (each lane overwrites exactly the 8-byte cells it
 //     read its residual from) and leaves as whole 2C-byte rows, stored by the loader waves while the matrix waves are
 //     already in the next tile.
-//   * each matrix wave (one per SIMD, 128 time rows x 32 output channels) streams its own weight fragments from L2
-//     through a static 8-deep register ring that runs seamlessly c1 -> c2 -> next tile's c1.
+//   * each matrix wave (one per SIMD, 128 time rows x 32 output channels, v_mfma_f32_16x16x32_bf16 fragments) streams
+//     its own weight fragments through a static 8-deep register ring that runs seamlessly c1 -> c2 -> next tile's c1:
+//     from L2 at C = 128, from an LDS copy of both (or c1's) streams where that fits beside the tiles (C <= 64).
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -83,7 +84,7 @@ __device__ __forceinline__ f32x2 unpack2(uint32_t w) {
 
 // compile-time loop: f(integral_constant<int, I>) for I in [I0, N).  The k-loops MUST be unrolled (ring slots, operand
 // double buffers and the per-step schedule are compile-time indices); `#pragma unroll` is a request hipcc drops silently
-// once the body grows (the deferred epilogue): it then indexes registers at run time (s_set_gpr_idx) -- 10x slower.
+// once the body grows: it then indexes registers at run time (s_set_gpr_idx) -- 10x slower.
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {
@@ -146,7 +147,7 @@ struct Geo {
   static constexpr int WBYTES = WMODE * NCT * S * 1024;   // [conv][channel tile][position] records of 1 KiB
   static constexpr int SMEM = WMODE ? WOFF + WBYTES : BASE;
   static_assert(NCT * NTG == NMW && (C == 32 || C == 64 || C == 128), "4 matrix waves of 128 x 32");
-  static_assert((2 * S) % WD == 0, "the weight ring slot of every k-step must be static");
+  static_assert((2 * S) % WD == 0, "the weight ring slot of every position must be static");
   static_assert(SMEM <= 160 * 1024, "LDS");
 };
 
