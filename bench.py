@@ -106,14 +106,15 @@ def _reference_model(sd, cfg):
         return None
 
 
-def cpu_baseline(sd, cfg, seconds, budget_s=20.0, want_reference=True, batch32=False):
+def cpu_baseline(sd, cfg, seconds, budget_s=20.0, want_reference=True, batch32=None):
     """CPU fp32 baseline on this box's host cores: the unmodified
     reference (``kind = "reference"``) where /root/reference is importable, else the oracle -- the CPU restatement
     of the same path in the same torch operators (``kind = "port"``; pinned to reference outputs by
     tests/test_oracle_golden.py).  Bounded sample: B = 1 utterances on all usable threads for ~budget_s (the
-    headline ``value``), then one B = 1 run on ONE thread; the B = 32 run on all threads (40-60 s of an otherwise idle
-    GPU lease) only with ``--cpu-batch32`` -- its figure, next to the reference's on the same host, is committed in
-    profiles/r02_cpu_reference_vs_port_build_container.json and BENCH_r02.json (0.76 utterances/s)."""
+    headline ``value``), then one B = 1 run on ONE thread, then ONE B = 32 run of the whole benchmark batch on all threads
+    when the B = 1 rate estimates it at <= 30 s (``batch32``: None = that rule, True = ``--cpu-batch32`` forces it up to
+    4 x budget, False = ``--no-cpu-batch32``); next to the reference's figure on the same host in
+    profiles/r02_cpu_reference_vs_port_build_container.json."""
     from oracle import vc_oracle
     from openvoice_amd.hostinfo import cpu_model, usable_cpus
     cores = usable_cpus(32)
@@ -155,13 +156,24 @@ def cpu_baseline(sd, cfg, seconds, budget_s=20.0, want_reference=True, batch32=F
     el1 = time.perf_counter() - t0
     out["one_thread"] = dict(value=round(seconds / el1, 3), utterances_per_s=round(1.0 / el1, 4), cores=1)
     sample.append(f"1 x (B=1) on 1 thread, {el1:.1f} s")
-    # the benchmark batch, B = 32 (skipped when the B = 1 rate says it would blow the budget)
+    # the benchmark batch, B = 32 x `seconds` (SURVEY.md section 8d's CPU leg; reference: openvoice/models.py:492-499 on the
+    # padded batch): run whenever the B = 1 rate estimates it at <= 30 s (`batch32` None = that rule, True = also up to
+    # 4 x budget_s, False = never); otherwise the bounded stand-in below
     torch.set_num_threads(cores)
     est32 = 32.0 * el / n
-    if not batch32:
-        # bounded stand-in for the B = 32 leg of SURVEY.md section 8d: a batch of 32 SHORT utterances (a tenth of the
-        # workload's length, >= 0.5 s) -- the same batched operators and thread count, a few seconds of CPU
-        out["batch32"] = None
+    limit = 30.0 if batch32 is None else (max(30.0, 4.0 * budget_s) if batch32 else -1.0)
+    out["batch32"] = None
+    if est32 <= limit:
+        wave32 = synth_wave(32, samples, 9, "cpu")
+        t0 = time.perf_counter()
+        convert(wave32)
+        el32 = time.perf_counter() - t0
+        out["batch32"] = dict(value=round(32 * seconds / el32, 3), utterances_per_s=round(32.0 / el32, 4), cores=cores,
+                              wall_s=round(el32, 2), estimated_s=round(est32, 1))
+        sample.append(f"1 x (B=32 x {seconds:g} s) on {cores} threads, {el32:.1f} s (estimated from the B=1 rate: {est32:.0f} s)")
+    else:
+        # bounded stand-in: a batch of 32 SHORT utterances (a tenth of the workload's length, >= 0.5 s) -- the same
+        # batched operators and thread count, a few seconds of CPU
         short_s = max(0.5, seconds / 10.0)
         if seconds >= 2.0 and est32 * short_s / seconds <= 12.0:
             wave32 = synth_wave(32, int(short_s * SAMPLE_RATE), 9, "cpu")
@@ -171,25 +183,33 @@ def cpu_baseline(sd, cfg, seconds, budget_s=20.0, want_reference=True, batch32=F
             out["batch32_short"] = dict(value=round(32 * short_s / el32, 3), utterances_per_s=round(32.0 / el32, 4),
                                         utterance_s=short_s, cores=cores)
             sample.append(f"1 x (B=32 x {short_s:.1f} s) on {cores} threads, {el32:.1f} s; the full B=32 x {seconds:.0f} s "
-                          f"leg only with --cpu-batch32 (estimated {est32:.0f} s)")
+                          f"leg not run (estimated {est32:.0f} s > {limit:.0f} s)")
         else:
-            sample.append(f"B=32 not run (--cpu-batch32; estimated {est32:.0f} s)")
-    elif est32 <= max(30.0, 4.0 * budget_s):
-        wave32 = synth_wave(32, samples, 9, "cpu")
-        t0 = time.perf_counter()
-        convert(wave32)
-        el32 = time.perf_counter() - t0
-        out["batch32"] = dict(value=round(32 * seconds / el32, 3), utterances_per_s=round(32.0 / el32, 4), cores=cores)
-        sample.append(f"1 x (B=32) on {cores} threads, {el32:.1f} s")
-    else:
-        out["batch32"] = None
-        sample.append(f"B=32 skipped (estimated {est32:.0f} s)")
+            sample.append(f"B=32 not run (estimated {est32:.0f} s > {limit:.0f} s)")
     what = ("UNMODIFIED reference SynthesizerTrn.voice_conversion + spectrogram_torch imported from /root/reference"
             if kind == "reference" else
             "oracle voice_conversion (CPU restatement of the reference in the same torch ops; /root/reference is not "
             "on this box)")
     out["sample"] = f"{what}, torch CPU fp32, weight-norm re-evaluated per call: " + "; ".join(sample)
     return out
+
+
+def self_launch(n):
+    """``python bench.py --gpus N`` (N > 1) started WITHOUT torch.distributed.run -- the way the driver starts the
+    1-GPU line: re-execute this same command line under ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N``
+    on a free local port, one rank per GPU, instead of failing on the launch convention.  The torchrun path itself
+    (WORLD_SIZE set by the launcher) never comes here."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: --gpus {n} without a launcher; re-executing under torch.distributed.run on port {port}",
+          file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def init_ranks(args, backend):
@@ -354,8 +374,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0,
                     help="seconds of CPU baseline sampling at B = 1 on all threads (plus one 1-thread utterance)")
-    ap.add_argument("--cpu-batch32", action="store_true",
-                    help="also time ONE B = 32 conversion on the CPU (40-60 s during which the GPU idles)")
+    ap.add_argument("--cpu-batch32", action="store_true", default=None,
+                    help="time ONE B = 32 conversion of the whole batch on the CPU even when the B = 1 rate estimates it "
+                         "above 30 s (default: run it when the estimate is <= 30 s)")
+    ap.add_argument("--no-cpu-batch32", dest="cpu_batch32", action="store_false",
+                    help="never run the B = 32 CPU leg (a short-utterance stand-in is timed instead)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle self-check of the timed batch")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (backend nccl = RCCL) and issue the per-step speaker-embedding "
@@ -375,6 +398,8 @@ def main():
     args = ap.parse_args()
     if args.steps < 1 or args.warmup < 0:
         ap.error("--steps must be >= 1 and --warmup >= 0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
     if args.dry_run:
         return dry_run(args)
 

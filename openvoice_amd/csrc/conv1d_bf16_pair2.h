@@ -171,12 +171,13 @@ __global__ __launch_bounds__(64 * (NMW + NLD)) void respair2_bf16_kernel(const o
   const long SS = (long)p.B * nsteps;
   const long g0 = SS * blockIdx.x / gridDim.x, g1 = SS * (blockIdx.x + 1) / gridDim.x;
   if (g0 >= g1) return;
-  if constexpr (WMODE > 0) {                          // visible after the init barrier below (all waves take part)
-    constexpr int HALF = NCT * S * 64;                // 16-byte vectors per conv
+  if constexpr (WMODE > 0) {                          // all 8 waves copy; the matrix waves' ring prefill below reads
+    constexpr int HALF = NCT * S * 64;                // records other waves wrote: own barrier (waits lgkmcnt(0) first)
     for (int e = tid; e < WMODE * HALF; e += 64 * (NMW + NLD)) {
       const u32x4* src = reinterpret_cast<const u32x4*>(e < HALF ? p.w1 : p.w2);
       reinterpret_cast<u32x4*>(wl)[e] = src[e < HALF ? e : e - HALF];
     }
+    __syncthreads();
   }
 
   if (wave >= NMW) {

@@ -31,12 +31,70 @@ LRELU_SLOPE = 0.1       # reference: openvoice/modules.py:14
 FINAL_LRELU_SLOPE = 0.01  # F.leaky_relu default at openvoice/models.py:287
 
 
+# What the kernel library has instances for (csrc/conv1d_inst_*.hip; everything else returns OV_E_UNSUPPORTED at the
+# first launch -- validate_config says so at load time, by field name, before any weight is packed).
+SUPPORTED_RESBLOCK_KERNELS = (3, 7, 11)
+SUPPORTED_RESBLOCK_DILATIONS = (1, 3, 5)
+
+
+def validate_config(cfg):
+    """Reject, naming the field, every hyper-parameter the kernels have no instance for.  The reference is
+    config-driven (openvoice/models.py:225-270: ``resblock`` picks ResBlock1 / ResBlock2 at :242, kernel sizes, dilations
+    and upsampling rates come from the JSON); this library instantiates the released family: ResBlock1, MRF kernels
+    3 / 7 / 11 with dilations 1 / 3 / 5, ConvTranspose1d with kernel = 2 x stride (stride a divisor of 32), channel
+    counts in whole 32-row MFMA fragments."""
+    def bad(field, value, why):
+        raise _lib.OvError(f"config field {field!r} = {value!r} is not supported by the MI355X kernels: {why}")
+
+    rb = str(cfg.get("resblock", "1"))
+    if rb != "1":
+        bad("resblock", cfg.get("resblock"), "only ResBlock1 ('1') is built (ResBlock2 is not; reference "
+            "openvoice/models.py:242, modules.py:312-357)")
+    kernels, dils = list(cfg["resblock_kernel_sizes"]), [list(d) for d in cfg["resblock_dilation_sizes"]]
+    if len(kernels) != len(dils) or not kernels:
+        bad("resblock_dilation_sizes", cfg["resblock_dilation_sizes"], f"one dilation list per entry of "
+            f"resblock_kernel_sizes ({len(kernels)}) is required")
+    for k in kernels:
+        if k not in SUPPORTED_RESBLOCK_KERNELS:
+            bad("resblock_kernel_sizes", kernels, f"kernel size {k} has no conv instance (built: "
+                f"{SUPPORTED_RESBLOCK_KERNELS})")
+    for d in dils:
+        for v in d:
+            if v not in SUPPORTED_RESBLOCK_DILATIONS:
+                bad("resblock_dilation_sizes", dils, f"dilation {v} has no conv instance (built: "
+                    f"{SUPPORTED_RESBLOCK_DILATIONS})")
+    rates, uk = list(cfg["upsample_rates"]), list(cfg["upsample_kernel_sizes"])
+    if len(rates) != len(uk) or not rates:
+        bad("upsample_kernel_sizes", uk, f"one kernel size per entry of upsample_rates ({len(rates)}) is required")
+    ch = cfg["upsample_initial_channel"]
+    for i, (u, k) in enumerate(zip(rates, uk)):
+        if k != 2 * u:
+            bad("upsample_kernel_sizes", uk, f"stage {i}: the transposed conv is built as a 3-tap phase conv, which needs "
+                f"kernel == 2 * stride (got kernel {k}, stride {u})")
+        if u <= 0 or 32 % u != 0:
+            bad("upsample_rates", rates, f"stage {i}: stride {u} must divide 32 (phases are interleaved inside one "
+                f"32-row fragment)")
+        if ch % 2 != 0 or (ch // 2) % 32 != 0:
+            bad("upsample_initial_channel", cfg["upsample_initial_channel"], f"stage {i} would have {ch // 2} channels; "
+                f"every stage needs a multiple of 32 (whole MFMA fragments)")
+        ch //= 2
+    if cfg["hidden_channels"] % 32 != 0:
+        bad("hidden_channels", cfg["hidden_channels"], "must be a multiple of 32 (the WaveNet gate rows are paired in "
+            "32-row MFMA fragments)")
+    if cfg["inter_channels"] % 64 != 0:
+        bad("inter_channels", cfg["inter_channels"], "must be a multiple of 64 (the couplings split the channels in halves "
+            "of whole 32-row fragments)")
+
+
 def generator_margin_frames(cfg, conv_pre_kernel=7, conv_post_kernel=7):
-    """Frames beyond an utterance's end that can still influence its last sample: the generator's one-sided receptive
-    field, derived from the configuration (reference: openvoice/models.py:225-291 -- conv_pre, per stage a
+    """Frames beyond an utterance's end that can still influence its last sample: an UPPER BOUND of the generator's
+    one-sided receptive field from the configuration (reference: openvoice/models.py:225-291 -- conv_pre, per stage a
     ConvTranspose1d of kernel k_u and stride u followed by the MRF whose widest ResBlock1 reaches
     (k - 1) / 2 * (sum(dilations) + len(dilations)) samples (modules.py:221-309: one dilated and one plain conv per
-    dilation), conv_post), rounded up plus one frame of slack.  16 for every released configuration."""
+    dilation), conv_post), rounded up plus one frame of slack.  The transposed-conv term charges (k_u - u + 1) / spf
+    frames per stage, more than the ceil((k_u - u) / 2 / u) + 1 inputs a stage really reaches back: the bound is loose
+    by design.  15 for the released V1 / V2 configurations (``ConverterEngine`` uses max(GENERATOR_MARGIN = 16, this):
+    tests/test_host_algebra_cpu.py::test_generator_margin_released_configs)."""
     import math
     reach = (conv_pre_kernel - 1) / 2.0                      # frames
     spf = 1                                                  # samples per frame after the stage
@@ -334,6 +392,7 @@ class ConverterEngine:
             raise _lib.OvError("ConverterEngine needs a ROCm device ('cuda:N'); there is no CPU path")
         sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
         cfg = dict(model_cfg.items()) if hasattr(model_cfg, "items") else dict(model_cfg)
+        validate_config(cfg)          # names the unsupported field before any weight is packed
         self.cfg = cfg
         self.zero_g = bool(zero_g)
         self.inter = cfg["inter_channels"]
@@ -597,7 +656,9 @@ class ConverterEngine:
         ws = self._workspace(B, T)
         Tp, mask = ws["Tp"], ws["mask"]
         if noise is None:
-            ws["noise"].normal_()        # drawn straight into the padded rows (the pad columns are never read): one launch
+            # one launch, the RNG stream of a dense torch.randn(B, C, T) (the reference's randn_like, models.py:220):
+            # the pad columns [T, Tp) are not drawn into, so a seeded conversion does not depend on the row padding
+            ws["noise"][:, :, :T].normal_()
         else:
             ws["noise"][:, :, :T].copy_(noise.to(dev, torch.float32))     # into the padded-row layout
         _lib.call("ov_sequence_mask_f32", lengths, mask, B, T, Tp)
@@ -739,7 +800,9 @@ class ConverterEngine:
             # stage 0: 108 workgroups for 512 slots; stages 1-3: one partial round of 431), so there the chains run on
             # separate HIP streams and fill each other's ramps and tails; chain j's last launch waits for chain j - 1's
             # (the running sum keeps its order: bit-identical to the serial sequence).
-            concurrent = (self.chain_streams > 1 and nk > 1 and B <= self.chain_streams_max_batch and self.profile is None)
+            concurrent = (self.chain_streams > 1 and nk > 1 and B <= self.chain_streams_max_batch and self.profile is None
+                          # the chains' extra scratch is allocated lazily: never from a capturing graph's private pool
+                          and not (torch.cuda.is_current_stream_capturing() and len(ws.get("dec_extra", [])) < 2 * (nk - 1)))
             scratch = [(t1, ra)]
             if concurrent:
                 extra = self._chain_scratch(ws, 2 * (nk - 1))

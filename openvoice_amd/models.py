@@ -12,7 +12,7 @@ import weakref
 import torch
 from torch import nn
 
-from .engine import ConverterEngine
+from .engine import ConverterEngine, validate_config
 from .params import converter_param_spec, tts_full_param_spec
 
 
@@ -55,6 +55,7 @@ class SynthesizerTrn(nn.Module):
             upsample_rates=list(upsample_rates), upsample_initial_channel=upsample_initial_channel,
             upsample_kernel_sizes=list(upsample_kernel_sizes), gin_channels=gin_channels,
             filter_channels=filter_channels, n_heads=n_heads, n_layers=n_layers, kernel_size=kernel_size)
+        validate_config(self.model_cfg)     # an unsupported hyper-parameter is named here, not as a state-dict key error
         if n_speakers == 0:     # converter variant: ref_enc, no text side (reference: models.py:450-452)
             self.ref_enc = _ReferenceEncoderHandle(self)
             spec = converter_param_spec(spec_channels, **self.model_cfg)

@@ -80,3 +80,26 @@ def test_world_size_mismatch_is_refused():
     res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--dry-run", "--gpus", "4"],
                          capture_output=True, text=True, timeout=120, env=env, cwd=REPO)
     assert res.returncode != 0 and "nproc-per-node" in res.stderr
+
+
+@pytest.mark.timeout(300)
+def test_plain_python_launch_with_gpus_2_starts_its_own_ranks():
+    """the driver starts the 1-GPU line as ``python3 bench.py --gpus 1 ...``; started the same way
+    with ``--gpus 2`` (no torch.distributed.run, no WORLD_SIZE / RANK / MASTER_* in the environment) bench.py must
+    re-execute itself under torch.distributed.run with 2 ranks instead of failing on the launch convention, and still
+    print exactly ONE complete line from rank 0."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE",
+                        "GROUP_RANK", "TORCHELASTIC_RUN_ID")}
+    env["OMP_NUM_THREADS"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--dry-run", "--gpus", "2", "--steps", "2",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=280, env=env, cwd=REPO)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "re-executing under torch.distributed.run" in res.stderr
+    (rec,) = _lines(res.stdout)
+    assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["broadcast_consistent"] is True
+    d = rec["distributed"]
+    assert d["process_group"] is True and d["backend"] == "gloo" and "rccl_ranks" in d and len(d["devices"]) == 2
+    assert len(rec["per_rank_ms_per_step"]["ranks"]) == 2
+    cb = rec["cpu_baseline"]
+    assert cb["value"] > 0 and cb["kind"] in ("port", "reference") and "batch32" in cb

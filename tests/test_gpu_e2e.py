@@ -405,3 +405,38 @@ def test_concurrent_resblock_chains_of_the_fp32_generator_are_bit_identical_to_t
         graphed = eng.graphed(B, T, 0.3)(spec, lengths, g1, g2, noise=noise)[0].clone()
         assert torch.equal(graphed, serial_fused)
         assert "dec_extra" in eng._workspace(B, T)             # the concurrent chains really had their own scratch
+
+
+def test_non_released_config_matches_oracle():
+    """The engine is shape-driven, not constant-driven (reference: openvoice/models.py:225-270 builds the generator from
+    the JSON): a configuration no released checkpoint uses -- three upsampling stages 8 x 8 x 4 from 256 channels, two
+    ResBlock kernels with two dilations each, inter = hidden = 128 -- against the oracle on the same weights."""
+    from openvoice_amd.params import synthetic_state_dict
+    from oracle import vc_oracle
+    cfg = dict(CONVERTER_MODEL_CONFIG, upsample_rates=[8, 8, 4], upsample_kernel_sizes=[16, 16, 8],
+               upsample_initial_channel=256, inter_channels=128, hidden_channels=128, resblock_kernel_sizes=[3, 7],
+               resblock_dilation_sizes=[[1, 3], [1, 5]])
+    sd = synthetic_state_dict(cfg, 513, seed=11)
+    B, T = 2, 70
+    gen = torch.Generator().manual_seed(77)
+    spec = torch.rand(B, 513, T, generator=gen).abs() * torch.linspace(3, 0.05, 513)[None, :, None]
+    g_src, g_tgt = 0.3 * torch.randn(1, 256, 1, generator=gen), 0.3 * torch.randn(1, 256, 1, generator=gen)
+    noise = torch.randn(B, cfg["inter_channels"], T, generator=gen)
+    lengths = torch.tensor([T, T - 9], dtype=torch.long)
+    with torch.no_grad():
+        o_ref, mask_ref, (z_r, zp_r, zh_r) = vc_oracle.voice_conversion(sd, cfg, spec, lengths, g_src, g_tgt, 0.3, noise)
+    model = SynthesizerTrn(0, 513, n_speakers=0, **cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).eval()
+    o_hat, y_mask, (z, z_p, z_hat) = model.voice_conversion(spec.to(DEV), lengths.to(DEV), g_src.to(DEV), g_tgt.to(DEV),
+                                                            tau=0.3, noise=noise.to(DEV))
+    torch.cuda.synchronize()
+    assert o_hat.shape == o_ref.shape == (B, 1, 256 * T) and torch.equal(y_mask.cpu(), mask_ref)
+    errs = dict(z=(z.cpu() - z_r).abs().max().item(), z_p=(z_p.cpu() - zp_r).abs().max().item(),
+                z_hat=(z_hat.cpu() - zh_r).abs().max().item(), o_hat=(o_hat.cpu() - o_ref).abs().max().item())
+    print(errs, "|o|max", o_ref.abs().max().item())
+    assert max(errs["z"], errs["z_p"], errs["z_hat"]) <= LATENT_TOL and errs["o_hat"] <= O_HAT_TOL, errs
+    # and the unsupported neighbours are named, not discovered as launch failures
+    from openvoice_amd._lib import OvError
+    with pytest.raises(OvError, match="resblock"):
+        SynthesizerTrn(0, 513, n_speakers=0, **dict(cfg, resblock="2"))

@@ -140,3 +140,41 @@ def test_generator_margin_covers_the_receptive_field_of_the_configuration():
                 z2[:, :, L + m:] = 0.0                                       # what lies beyond the computed frames
                 diff = (vc_oracle.generator(sd, z2, g, cfg)[:, :, :L * hop] - full[:, :, :L * hop]).abs().max().item()
                 assert (diff == 0.0) == enough, (cfg["resblock_kernel_sizes"], m, diff)
+
+
+def test_generator_margin_released_configs():
+    """The derived bound for the released V1 / V2 converter configurations (the same generator hyper-parameters:
+    reference checkpoints' config.json) is 15 frames; the engine rounds it up to GENERATOR_MARGIN = 16."""
+    from openvoice_amd.engine import GENERATOR_MARGIN, generator_margin_frames
+    from openvoice_amd.utils import CONVERTER_MODEL_CONFIG, default_converter_hparams
+    assert generator_margin_frames(CONVERTER_MODEL_CONFIG) == 15
+    for version in ("v1", "v2"):
+        assert generator_margin_frames(dict(default_converter_hparams(version).model.items())) == 15
+    assert max(GENERATOR_MARGIN, 15) == 16
+
+
+def test_validate_config_names_the_unsupported_field():
+    """``engine.validate_config``: the reference is config-driven (openvoice/models.py:225-270, ResBlock1 / ResBlock2 at
+    :242); the kernels cover the released family and every other value is rejected BY FIELD NAME at load time."""
+    import pytest
+    from openvoice_amd._lib import OvError
+    from openvoice_amd.engine import validate_config
+    from openvoice_amd.utils import CONVERTER_MODEL_CONFIG as base
+    validate_config(base)
+    validate_config(dict(base, upsample_rates=[8, 8, 4], upsample_kernel_sizes=[16, 16, 8], upsample_initial_channel=256,
+                         inter_channels=128, hidden_channels=128, resblock_kernel_sizes=[3, 7],
+                         resblock_dilation_sizes=[[1, 3], [1, 5]]))
+    cases = [
+        (dict(resblock="2"), "resblock", "ResBlock2"),
+        (dict(resblock_kernel_sizes=[3, 5, 11]), "resblock_kernel_sizes", "kernel size 5"),
+        (dict(resblock_dilation_sizes=[[1, 2, 5]] * 3), "resblock_dilation_sizes", "dilation 2"),
+        (dict(upsample_kernel_sizes=[16, 16, 4, 8]), "upsample_kernel_sizes", "2 * stride"),
+        (dict(upsample_rates=[8, 8, 3, 2], upsample_kernel_sizes=[16, 16, 6, 4]), "upsample_rates", "divide 32"),
+        (dict(upsample_initial_channel=256), "upsample_initial_channel", "16 channels"),
+        (dict(hidden_channels=100), "hidden_channels", "multiple of 32"),
+        (dict(inter_channels=96), "inter_channels", "multiple of 64"),
+    ]
+    for change, field, why in cases:
+        with pytest.raises(OvError) as e:
+            validate_config(dict(base, **change))
+        assert repr(field) in str(e.value) and why in str(e.value), (change, str(e.value))
