@@ -455,8 +455,53 @@ int ov_resblock_pair2_bf16cl(const ov_respair2_bf16_params* p, ov_stream_t strea
 int ov_conv1d_bf16_pack16(const float* w, int Cout, int Cin, int K, uint16_t* dst);
 int ov_resblock_pair2_bf16_supported(int C, int K, int dil);
 
+/* ---- split-precision Conv1d: fp32-level products on the bf16 matrix pipe (opt-in; csrc/conv1d_split3.h) -----------
+ * An fp32 tensor is carried as THREE bf16 planes, v = hi + mid + lo with hi = bf16(v), mid = bf16(v - hi),
+ * lo = bf16(v - hi - mid) (round to nearest even; lossless for fp32), channels-last and plane-major: [3][B][L][C].
+ * A product x * w is the six plane products of weight >= 2^-18 (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid) on
+ * v_mfma_f32_16x16x32_bf16 with fp32 accumulation (`products` = 6), or the three of weight >= 2^-9 on the hi / mid
+ * planes only (`products` = 3: 16-bit operands).
+ *   out = split3( lrelu( (conv1d(x, w) + bias [+ res~]) * scale, out_slope ) )
+ * x is read as stored (the producer stores it activated); res~ = res for res_slope = 1, else the inverse leaky ReLU of
+ * res (res >= 0 ? res : res / res_slope: the residual tensor is the conv input of the pair, stored activated).
+ * reference: openvoice/modules.py:296-306 (xt = c1(lrelu(x)); xt = c2(lrelu(xt)); x = xt + x).
+ * Cin = Cout in {128, 256}, K in {3, 7, 11}, dil in {1, 3, 5} (with res: dil = 1); out must alias neither x nor res. */
+typedef struct ov_conv1d_split3_params {
+  const uint16_t* x;     /* [3][B][L][Cin] bf16 planes */
+  const uint16_t* w;     /* ov_conv1d_split3_pack(Cout, Cin, K) */
+  const float* bias;     /* [Cout] fp32 */
+  uint16_t* out;         /* [3][B][L][Cout] bf16 planes */
+  const uint16_t* res;   /* planes like out, or NULL */
+  int64_t x_plane, out_plane, res_plane;   /* elements between consecutive planes (>= B * L * C, multiples of 8) */
+  int32_t B, L, Cin, Cout, K, dil;
+  int32_t nwg;           /* 0 = one workgroup per CU; n > 0 forces n workgroups (tests) */
+  int32_t products;      /* 6 or 3 */
+  float res_slope;       /* 0 < res_slope <= 1 */
+  float out_slope;       /* 0 < out_slope <= 1; 1 = store the raw result */
+  float scale;
+  int32_t reserved0;
+  unsigned long long* dbg; /* measurement only, NULL in production: [workgroups][4 matrix waves][8] ticks per phase */
+} ov_conv1d_split3_params;
+int ov_conv1d_split3(const ov_conv1d_split3_params* p, ov_stream_t stream);
+/* Elements (uint16) of the packed three-plane weight stream; 0 when Cout or Cin is not a multiple of 32. */
+size_t ov_conv1d_split3_pack_size(int Cout, int Cin, int K);
+/* HOST w [Cout][Cin][K] fp32 -> 16x16x32 A-fragment order, record (((ct * Cin/32 + c) * K + tap) * 3 + plane) * 2 + f,
+ * one trailing all-zero record. */
+int ov_conv1d_split3_pack(const float* w, int Cout, int Cin, int K, uint16_t* dst);
+int ov_conv1d_split3_supported(int Cin, int Cout, int K, int dil);
+/* Layout kernels around an MRF stage that runs on ov_conv1d_split3 (the fp32 engine keeps [B][C][L], time contiguous):
+ * planes [3][B][L][C] = split3(lrelu(x, slope)) of x [B][C][L] fp32 (reference: the leaky_relu of modules.py:298 moved
+ * to the producer), and out [B][C][L] fp32 = (a~ [+ b~] [+ c~]) * scale, each operand de-activated with in_slope (the
+ * MRF sum / mean, models.py:280-286).  C even, <= 512. */
+int ov_split3_from_f32(const float* x, uint16_t* planes, int64_t plane_stride, int B, int C, int L, float slope,
+                       ov_stream_t stream);
+int ov_split3_to_f32(const uint16_t* a, const uint16_t* b, const uint16_t* c, int64_t plane_stride, float* out, int B,
+                     int C, int L, float in_slope, float scale, ov_stream_t stream);
+
 /* Library/ABI version (major*100 + minor).  2.01: ov_conv1d_params.col_limit, ov_conv_post_tanh_limited_f32,
- * ov_frame_limits_i32. */
+ * ov_frame_limits_i32.  2.02: ov_unpad_rows_f32, ov_conv1d_bf16_pack16, ov_resblock_pair2_bf16cl (+ _supported).
+ * 2.03: ov_conv1d_split3 (+ _pack_size, _pack, _supported), ov_split3_from_f32, ov_split3_to_f32.  The Python binding
+ * refuses a library older than the entry points it calls (openvoice_amd/_lib.py MIN_VERSION). */
 int ov_version(void);
 /* 0 for a production build; non-zero = a measurement build with parts of the kernels compiled out (results are
  * meaningless; openvoice_amd/_lib.py refuses to load it unless OPENVOICE_AMD_ALLOW_EXPERIMENT=1). */

@@ -22,6 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OPENVOICE_AMD_LIB") or os.path.join(_HERE, "libopenvoice_amd.so")
 
 OV_OK = 0
+MIN_VERSION = 203     # ov_version() of the newest entry point this package calls (include/openvoice_amd.h)
 OV_ERRORS = {-1: "OV_E_BADARG", -2: "OV_E_UNSUPPORTED", -3: "OV_E_ALIGN", -4: "OV_E_LAUNCH"}
 
 EPI_LINEAR, EPI_GATE, EPI_RESSKIP, EPI_COUPLE, EPI_POSTERIOR, EPI_CONVT, EPI_MAGNITUDE = range(7)
@@ -89,6 +90,16 @@ class Respair2Bf16Params(ctypes.Structure):
                 ("out_slope", ctypes.c_float), ("exp_flags", ctypes.c_int32), ("dbg", _fp)]
 
 
+class ConvSplit3Params(ctypes.Structure):
+    """Mirror of ``ov_conv1d_split3_params`` (include/openvoice_amd.h)."""
+    _fields_ = [("x", _fp), ("w", _fp), ("bias", _fp), ("out", _fp), ("res", _fp),
+                ("x_plane", ctypes.c_int64), ("out_plane", ctypes.c_int64), ("res_plane", ctypes.c_int64),
+                ("B", ctypes.c_int32), ("L", ctypes.c_int32), ("Cin", ctypes.c_int32), ("Cout", ctypes.c_int32),
+                ("K", ctypes.c_int32), ("dil", ctypes.c_int32), ("nwg", ctypes.c_int32), ("products", ctypes.c_int32),
+                ("res_slope", ctypes.c_float), ("out_slope", ctypes.c_float), ("scale", ctypes.c_float),
+                ("reserved0", ctypes.c_int32), ("dbg", _fp)]
+
+
 class WnLayerParams(ctypes.Structure):
     """Mirror of ``ov_wn_layer_params`` (include/openvoice_amd.h)."""
     _fields_ = [("x", _fp), ("out", _fp), ("skip", _fp), ("w_in", _fp), ("b_in", _fp), ("cond", _fp), ("w_rs", _fp),
@@ -136,6 +147,12 @@ SIGNATURES = {
     "ov_resblock_pair2_bf16cl": (ctypes.c_int, [ctypes.POINTER(Respair2Bf16Params), _fp]),
     "ov_resblock_pair2_bf16_supported": (ctypes.c_int, [_i, _i, _i]),
     "ov_conv_post_tanh_bf16": (ctypes.c_int, [_fp, _fp, _fp, _i, _i, _i, _i, ctypes.c_float, _fp]),
+    "ov_conv1d_split3": (ctypes.c_int, [ctypes.POINTER(ConvSplit3Params), _fp]),
+    "ov_conv1d_split3_pack_size": (ctypes.c_size_t, [_i, _i, _i]),
+    "ov_conv1d_split3_pack": (ctypes.c_int, [_fp, _i, _i, _i, _fp]),
+    "ov_conv1d_split3_supported": (ctypes.c_int, [_i, _i, _i, _i]),
+    "ov_split3_from_f32": (ctypes.c_int, [_fp, _fp, _i64, _i, _i, _i, ctypes.c_float, _fp]),
+    "ov_split3_to_f32": (ctypes.c_int, [_fp, _fp, _fp, _i64, _fp, _i, _i, _i, ctypes.c_float, ctypes.c_float, _fp]),
     "ov_frame_hops_f32": (ctypes.c_int, [_fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
     "ov_embed_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, ctypes.c_float, _fp]),
     "ov_layernorm_ch_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, ctypes.c_float, _i, _fp]),
@@ -167,6 +184,10 @@ def load():
             raise OvError(f"{LIB_PATH} not found: build the HIP extension first "
                           f"(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
         lib = ctypes.CDLL(LIB_PATH)
+        lib.ov_version.restype, lib.ov_version.argtypes = ctypes.c_int, []
+        if lib.ov_version() < MIN_VERSION:       # before the symbol lookups: a stale library fails HERE, by version
+            raise OvError(f"{LIB_PATH} is version {lib.ov_version()}, this package needs >= {MIN_VERSION}: rebuild it "
+                          f"(make -C openvoice_amd/csrc)")
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = restype
@@ -200,7 +221,8 @@ _ops = None
 # entry points whose return value is a quantity, not an OV_* status
 VALUE_FUNCS = {"ov_version", "ov_build_experiment", "ov_conv1d_pack_size", "ov_conv1d_pack_rows", "ov_wn_pack_size",
                "ov_conv1d_bf16_pack_size", "ov_resblock_pair_supported", "ov_wn_layer_supported", "ov_wn_layer_tile",
-               "ov_resblock_pair_bf16_supported", "ov_resblock_pair2_bf16_supported"}
+               "ov_resblock_pair_bf16_supported", "ov_resblock_pair2_bf16_supported", "ov_conv1d_split3_pack_size",
+               "ov_conv1d_split3_supported"}
 
 
 def binding():
@@ -230,6 +252,9 @@ def torch_ops():
                               f"libopenvoice_amd.so)")
         torch.ops.load_library(SHIM_PATH)
         ops = torch.ops.openvoice_amd
+        if ops.version() < MIN_VERSION:
+            raise OvError(f"{LIB_PATH} is version {ops.version()}, this package needs >= {MIN_VERSION}: rebuild it "
+                          f"(make -C openvoice_amd/csrc)")
         exp = ops.build_experiment()
         if exp != 0 and os.environ.get("OPENVOICE_AMD_ALLOW_EXPERIMENT") != "1":
             raise OvError(f"{LIB_PATH} is a measurement build (OV_EXP={exp}); rebuild with "

@@ -1,0 +1,537 @@
+// Split-precision Conv1d of the generator's MRF stages: fp32-level products on the bf16 matrix pipe (VERDICT r04 item 1,
+// DESIGN.md section 10 item 5).  reference: openvoice/modules.py:296-309 (the convs of ResBlock1.forward).
+//
+// On gfx950 the fp32 MFMA runs at 1/16 of the bf16 rate, and the fp32 conv family sits at 0.83 of that roof.  Here every
+// fp32 operand is carried as THREE bf16 planes
+//     v = hi + mid + lo,   hi = bf16(v),  mid = bf16(v - hi),  lo = bf16(v - hi - mid)       (all subtractions exact)
+// which is LOSSLESS for fp32 (3 x 8 significand bits + the sign of each residual cover the 24 bits; proof in DESIGN.md
+// section 3.10), and a product x * w is evaluated as the six plane products of weight >= 2^-18
+//     hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid                                      (dropped: 2^-26 and below)
+// on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: 6 bf16 MFMAs where the fp32 pipe needs 16 bf16-MFMA-times.
+//
+// Data layout: activations channels-last, plane-major: [3][B][L][C] bf16 (plane 0 alone is the bf16 generator's tensor).
+// The producer splits in its epilogue (this kernel's out is already split, activated for its consumer); a residual
+// stored activated is inverted exactly-to-rounding in fp32 on read (as conv1d_bf16_pair2.h does).
+//
+// Kernel shape (the pair2 skeleton): ONE persistent workgroup per CU, 4 matrix waves (one per SIMD, 128 time rows x 32
+// output channels each = a 128 x 128 output tile per step) + 4 helper waves: two stream the input in -- per 32 input
+// channels one chunk of [3 planes][rows + halo][64 B], LDS-DMA (global_load_lds_dwordx4), double buffered, XOR-swizzled
+// through the DMA source addresses -- and two move the finished tile out (the matrix waves split it into planes IN LDS,
+// in place over the residual planes when there is a residual; the helper waves store whole rows).  Six MFMAs per
+// (operand, weight-record) pair mean 0.25 ds_read_b128 + 0.06 weight records per MFMA -- a quarter of what the bf16
+// pair kernel moves per MFMA -- so the k-loop is MFMA-issue-bound by construction.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+#include <type_traits>
+
+#include "openvoice_amd.h"
+
+#ifndef OV_CONV1D_SPLIT3_H
+#define OV_CONV1D_SPLIT3_H
+
+namespace ovks3 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int NMW = 4;       // matrix waves: one per SIMD
+constexpr int NIN = 2;       // helper waves that stream the input chunks (and the residual tile) in
+constexpr int NOUT = 2;      // helper waves that store the output tile
+constexpr int TT = 128;      // time rows per step
+constexpr int COT = 128;     // output channels per step (4 matrix waves x 32)
+constexpr int OP = 2 * COT;  // row pitch of one plane of the output half-tile (bytes)
+constexpr int OROWS = 64;    // rows per output half-tile
+constexpr int OPL = OROWS * OP;          // bytes per plane of a half-tile (16 KiB = 16 blocks of 4 rows)
+constexpr int OH = 3 * OPL;              // bytes per half-tile
+
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {       // one v_cvt_pk_bf16_f32, round to nearest even
+  const bf16x2 h = __builtin_convertvector(f32x2{lo, hi}, bf16x2);
+  uint32_t u;
+  __builtin_memcpy(&u, &h, 4);
+  return u;
+}
+__device__ __forceinline__ f32x2 unpack2(uint32_t w) {
+  return f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+}
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmin(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// (utterance, time tile, output-channel block) of a flattened step index; the channel block runs fastest, so the two
+// blocks of a 256-channel layer read the same input tile back to back (the second one from L2)
+struct Step {
+  int b, tile, mb;
+  __device__ __forceinline__ Step(long s, int ntiles, int nmb) {
+    const long bt = s / nmb;
+    mb = (int)(s - bt * nmb);
+    b = (int)(bt / ntiles);
+    tile = (int)(bt - (long)b * ntiles);
+  }
+};
+
+template <int K, int DIL, int CIN, bool RES>
+struct Geo {
+  static constexpr int NCH = CIN / 32;               // 32-channel input chunks
+  static constexpr int P1 = (K - 1) * DIL / 2;       // halo rows on each side
+  static constexpr int R1 = TT + 2 * P1;             // rows of an input chunk
+  static constexpr int NBLK = (R1 + 15) / 16;        // 1 KiB DMA blocks (16 rows x 64 B) per plane of a chunk
+  static constexpr int XPL = NBLK * 1024;            // bytes per plane of a chunk buffer
+  static constexpr int XB = 3 * XPL;                 // bytes per chunk buffer
+  static constexpr int NOH = RES ? 2 : 1;            // output half-tile buffers (with a residual: both halves resident)
+  static constexpr int OOFF = 2 * XB;
+  static constexpr int BOFF = OOFF + NOH * OH;
+  static constexpr int SMEM = BOFF + COT * 4;
+  static constexpr int NPAIR = NCH * K;              // (chunk, tap) pairs of one step = 6 weight records each
+  static_assert(NCH % 2 == 0, "the chunk loop is unrolled by two (static weight-ring slots for odd K)");
+  static_assert(SMEM <= 160 * 1024, "LDS");
+};
+
+template <int K, int DIL, int CIN, bool RES, int NPROD>
+__global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(const ov_conv1d_split3_params p) {
+  using G = Geo<K, DIL, CIN, RES>;
+  constexpr int NCH = G::NCH, P1 = G::P1, R1 = G::R1, NBLK = G::NBLK, XPL = G::XPL, XB = G::XB, NOH = G::NOH;
+  constexpr int NPL = NPROD == 6 ? 3 : 2;            // planes the k-loop reads (3 products: hi*hi + hi*mid + mid*hi)
+  static_assert(NPROD == 6 || NPROD == 3, "6 (fp32-level) or 3 (16-bit operands) plane products");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[G::SMEM];
+  unsigned char* const xs = smem;                    // 2 chunk buffers: [plane][row][64 B], swizzled
+  unsigned char* const ob = smem + G::OOFF;          // NOH output half-tiles: [plane][row][256 B], swizzled
+  float* const bsm = reinterpret_cast<float*>(smem + G::BOFF);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = p.L;
+  const int ntiles = (L + TT - 1) / TT;
+  const int nmb = p.Cout / COT;
+  const long SS = (long)p.B * ntiles * nmb;
+  const long g0 = SS * blockIdx.x / gridDim.x, g1 = SS * (blockIdx.x + 1) / gridDim.x;
+  if (g0 >= g1) return;
+  typedef const __attribute__((address_space(1))) unsigned char* gc_ptr;
+  typedef __attribute__((address_space(1))) unsigned char* gm_ptr;
+  typedef __attribute__((address_space(3))) unsigned char* lds_ptr;
+  // the packer's trailing all-zero record: DMA source of every vector outside [0, L)
+  const gc_ptr zsrc = (gc_ptr)(p.w) + (size_t)(p.Cout / 32) * G::NPAIR * 6 * 1024;
+  const int64_t PGI = 2 * (int64_t)CIN, PGO = 2 * (int64_t)p.Cout;   // global row pitches (bytes)
+
+  if (wave >= NMW && wave < NMW + NIN) {
+    // ================================ input waves ================================================
+    // Chunk n (global count over this workgroup's steps) lives in buffer n & 1.  After barrier A(n) -- chunk n landed,
+    // and every matrix wave is past the k-loop of chunk n - 1 -- the DMA of chunk n + 1 goes into the other buffer.
+    // Block (plane, blk) = rows [16 blk, 16 blk + 16) of one plane: lane -> (row lrow = lane / 4, physical 16-byte slot
+    // sp = lane % 4), which holds logical slot sp ^ g(row), g(row) = (row >> 2) & 3 = (lrow >> 2) & 3.
+    const int iw = wave - NMW;
+    const int lrow = lane >> 2, sp = lane & 3;
+    const uint32_t dof = (uint32_t)(lrow * PGI + 16 * (sp ^ ((lrow >> 2) & 3)));
+    auto dma_chunk = [&](int buf, const Step& st, int c) {
+      const int tbase = st.tile * TT - P1;
+      const lds_ptr lb = (lds_ptr)(xs) + buf * XB;
+      const bool interior = tbase >= 0 && tbase + NBLK * 16 <= L;
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        const gc_ptr xb = (gc_ptr)(p.x) + (int64_t)pl * p.x_plane * 2 + ((int64_t)st.b * L + tbase) * PGI + 64 * c;   // (uniform)
+#pragma unroll
+        for (int q = 0; q < (NBLK + NIN - 1) / NIN; ++q) {
+          const int blk = q * NIN + iw;
+          if (blk < NBLK) {
+            gc_ptr bj = xb + (int64_t)blk * 16 * PGI;
+            asm volatile("" : "+s"(bj));
+            gc_ptr src = bj + dof;
+            if (!interior) {
+              const int t = tbase + blk * 16 + lrow;
+              if (t < 0 || t >= L) src = zsrc + lane * 16;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lb + pl * XPL + blk * 1024), 16, 0, 0);
+          }
+        }
+      }
+    };
+    // Residual tile (RES): both half-tiles [plane][64 rows][256 B] into the output buffers, where the matrix waves
+    // replace each cell by its result.  Block blk = 4 rows; lane -> (row lrow4 = lane / 16, physical slot sp16 = lane %
+    // 16) holding logical slot sp16 ^ (row & 15), row & 15 = 4 (blk & 3) + lrow4; this wave takes the blocks with
+    // blk & 3 in {2 iw, 2 iw + 1}: two per-lane constants.
+    const int lrow4 = lane >> 4, sp16 = lane & 15;
+    uint32_t rdof[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) rdof[e] = (uint32_t)(lrow4 * PGO + 16 * (sp16 ^ (4 * (2 * iw + e) + lrow4)));
+    auto dma_residual = [&](const Step& st) {
+      if constexpr (RES) {
+        const int t0 = st.tile * TT;
+        const bool interior = t0 + TT <= L;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            const gc_ptr rb = (gc_ptr)(p.res) + (int64_t)pl * p.res_plane * 2 + ((int64_t)st.b * L + t0 + OROWS * h) * PGO + OP * st.mb;
+            const lds_ptr lb = (lds_ptr)(ob) + h * OH + pl * OPL;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const int blk = 4 * q + 2 * iw + e;
+                gc_ptr bj = rb + (int64_t)blk * 4 * PGO;
+                asm volatile("" : "+s"(bj));
+                gc_ptr src = bj + rdof[e];
+                if (!interior && t0 + OROWS * h + 4 * blk + lrow4 >= L) src = zsrc + lane * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(lb + blk * 1024), 16, 0, 0);
+              }
+          }
+      }
+    };
+    long s = g0;
+    Step cur(s, ntiles, nmb);
+    dma_chunk(0, cur, 0);
+    __builtin_amdgcn_s_barrier();                            // (init: biases in LDS)
+    int n = 0;
+    for (; s < g1; ++s) {
+      const Step nxt(s + 1 < g1 ? s + 1 : s, ntiles, nmb);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c, ++n) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunk n (and, at c = 1, the residual tile) has landed
+        __builtin_amdgcn_s_barrier();                          // A(s, c)
+        if (c + 1 < NCH) dma_chunk((n + 1) & 1, cur, c + 1);
+        else if (s + 1 < g1) dma_chunk((n + 1) & 1, nxt, 0);
+        // the output buffers are free from A(s, 0) on: the output waves fetched step s - 1's last half before it
+        if (c == 0) dma_residual(cur);
+      }
+      __builtin_amdgcn_s_barrier();                            // E0
+      __builtin_amdgcn_s_barrier();                            // E1
+      __builtin_amdgcn_s_barrier();                            // E2
+      cur = nxt;
+    }
+    return;
+  }
+
+  if (wave >= NMW + NIN) {
+    // ================================ output waves ===============================================
+    // Half-tile h of step s: LDS -> registers after barrier E0 (h = 0) / E2 (h = 1), registers -> HBM right after (the
+    // stores never gate a barrier: these waves wait for nothing but their own LDS reads).  Block (plane, blk): 4 rows
+    // x 256 B, lane -> (row lane / 16, physical slot lane % 16); this wave takes blk & 3 in {2 ow, 2 ow + 1}.
+    const int ow = wave - NMW - NIN;
+    const int lrow4 = lane >> 4, sp16 = lane & 15;
+    uint32_t odof[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) odof[e] = (uint32_t)(lrow4 * PGO + 16 * (sp16 ^ (4 * (2 * ow + e) + lrow4)));
+    u32x4 ov[3][4][2];
+    auto fetch = [&](int hbuf) {
+      const unsigned char* lb = ob + hbuf * OH + lane * 16;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) ov[pl][q][e] = *reinterpret_cast<const u32x4*>(lb + pl * OPL + (4 * q + 2 * ow + e) * 1024);
+    };
+    auto store = [&](const Step& st, int h) {
+      const int t0 = st.tile * TT + OROWS * h;
+      const bool interior = t0 + OROWS <= L;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        const gm_ptr obase = (gm_ptr)(p.out) + (int64_t)pl * p.out_plane * 2 + ((int64_t)st.b * L + t0) * PGO + OP * st.mb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int blk = 4 * q + 2 * ow + e;
+            gm_ptr bj = obase + (int64_t)blk * 4 * PGO;
+            asm volatile("" : "+s"(bj));
+            __attribute__((address_space(1))) u32x4* dst = reinterpret_cast<__attribute__((address_space(1))) u32x4*>(bj + odof[e]);
+            if (interior || t0 + 4 * blk + lrow4 < L) *dst = ov[pl][q][e];
+          }
+      }
+    };
+    __builtin_amdgcn_s_barrier();                            // (init)
+    for (long s = g0; s < g1; ++s) {
+      const Step st(s, ntiles, nmb);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) __builtin_amdgcn_s_barrier();   // A(s, c)
+      __builtin_amdgcn_s_barrier();                            // E0: half 0 is complete in its buffer
+      fetch(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                            // E1: buffer 0 may be overwritten (NOH = 1: by half 1)
+      store(st, 0);
+      __builtin_amdgcn_s_barrier();                            // E2: half 1 is complete
+      fetch(NOH - 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // ... and read before A(s + 1, 0) lets anything overwrite it
+      store(st, 1);
+    }
+    return;
+  }
+
+  // ================================== matrix waves ================================================
+  // v_mfma_f32_16x16x32_bf16, D[channel][time] = W (16 channels x 32 k) * x (32 k x 16 time rows), fragments as in
+  // conv1d_bf16_pair2.h: a wave's 128 x 32 tile is 8 (time, j) x 2 (channel, f) fragments; a lane holds time row
+  // 16 j + (lane & 15) and channels 16 f + 4 (lane >> 4) + {0..3} of fragment (f, j).
+  __builtin_amdgcn_s_setprio(2);
+  const int g4 = lane >> 4, l15 = lane & 15;
+
+  // per-lane LDS offset of the x operand of tap `tap`: row l15 + tap DIL (+ 16 j: same swizzle), logical slot g4
+  uint32_t xl_tap[K];
+#pragma unroll
+  for (int tap = 0; tap < K; ++tap) {
+    const int row = l15 + tap * DIL;
+    xl_tap[tap] = (uint32_t)(row * 64 + 16 * (g4 ^ ((row >> 2) & 3)));
+  }
+  // epilogue cells: cell (f, jj) of half h = row 16 jj + l15 of the half-tile, channels 32 wave + 16 f + 4 g4 + {0..3}:
+  // logical 16-byte slot 4 wave + 2 f + (g4 >> 1), 8 bytes at 8 (g4 & 1) inside it; row & 15 = l15
+  uint32_t ecell[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) ecell[f] = (uint32_t)(l15 * OP + 16 * ((4 * wave + 2 * f + (g4 >> 1)) ^ l15) + 8 * (g4 & 1));
+
+  // packed weights (ov_conv1d_split3_pack): record (((ct * NCH + c) * K + tap) * 3 + plane) * 2 + f for the 32-channel
+  // output tile ct = 4 mb + wave: the 6 records of a (chunk, tap) pair are consecutive, a step's stream is sequential.
+  typedef const __attribute__((address_space(1))) u32x4* gw_ptr;
+  const gw_ptr wall = (gw_ptr)(p.w);
+  gw_ptr wp = wall;
+  u32x4 wq[2][3][2];                       // [pair parity][plane][f]: the pair in use + the pair being requested
+  auto wrequest = [&](int par, int r) {    // record r (= 2 plane + f) of the next pair; r, par compile-time
+    asm volatile("" : "+s"(wp));           // opaque: scalar base + lane offset, not hoisted out of the step loop
+    if (NPL == 3 || r < 4) wq[par][r >> 1][r & 1] = wp[lane + 64 * r];
+  };
+
+  // measurement only (p.dbg != NULL): ticks 0 at barriers A, 1 k-loops, 2 epilogue arithmetic, 3 at barriers E, 7 steps
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = 0;
+  const bool dbg = p.dbg != nullptr;
+  auto mark = [&](int ph) {
+    if (dbg) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      tph[ph] += now - tlast;
+      tlast = now;
+    }
+  };
+  const float scale = p.scale, oslope = p.out_slope, inv_rslope = 1.0f / p.res_slope;
+  const bool scaled = scale != 1.0f, act_out = oslope != 1.0f, res_act = p.res_slope != 1.0f;
+
+  __syncthreads();                                    // (init; the helper waves' matching s_barrier)
+  if (dbg) tlast = __builtin_readcyclecounter();
+  int n = 0, nstep = 0;
+  {                                                   // first pair of the first step
+    const Step st(g0, ntiles, nmb);
+    wp = wall + (size_t)(4 * st.mb + wave) * G::NPAIR * 6 * 64;
+    static_for<0, 6>([&](auto rc) { wrequest(0, decltype(rc)::value); });
+    wp += 6 * 64;
+  }
+  for (long s = g0; s < g1; ++s, ++nstep) {
+    const Step st(s, ntiles, nmb);
+    const Step nx(s + 1 < g1 ? s + 1 : s, ntiles, nmb);
+    if (tid < COT) bsm[tid] = p.bias[COT * st.mb + tid];   // (read after barrier A(s, 0); last read before E0 of s - 1)
+    f32x4 acc[2][8];
+    // ---- k-loops: two chunks per iteration (static ring parity: 2 K pairs) ------------------------------------------
+    for (int it = 0; it < NCH / 2; ++it) {
+      static_for<0, 2>([&](auto cc) {
+        constexpr int ci = decltype(cc)::value;
+        __syncthreads();                              // A(s, c): chunk n is in LDS
+        mark(0);
+        if (ci == 0 && it == 0) {
+          // (bias in LDS since the barrier above)
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(bsm + 32 * wave + 16 * f + 4 * g4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[f][j] = v;
+          }
+        }
+        const uint32_t bufoff = (uint32_t)((n & 1) * XB);
+        ++n;
+        uint32_t xlb[K];
+#pragma unroll
+        for (int tap = 0; tap < K; ++tap) {
+          xlb[tap] = xl_tap[tap] + bufoff;
+          asm volatile("" : "+v"(xlb[tap]));
+        }
+        // One (chunk, tap) pair = 4 blocks of 24 MFMAs: block jh covers time fragments j = 2 jh, 2 jh + 1 with all six
+        // plane products against the pair's six weight records; the same accumulator recurs every 4th MFMA.  Between
+        // the MFMAs, one instruction per gap: the 6 operand reads of the next block, 2 weight requests of the next pair.
+        u32x4 xq[2][3][2];                            // [block parity][plane][jj]
+        auto oread = [&](uint32_t base, int pl, int j) -> u32x4 {
+          return *reinterpret_cast<const u32x4*>(xs + base + pl * XPL + j * 1024);
+        };
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) xq[0][pl][jj] = oread(xlb[0], pl, jj);
+        static_for<0, K>([&](auto tc) {
+          constexpr int tap = decltype(tc)::value;
+          constexpr int par = (ci * K + tap) & 1;     // weight-ring parity of this pair (2 K pairs per iteration: static)
+          if constexpr (ci == 1 && tap == K - 1) {
+            // the next pair is chunk pair 0 of the next iteration -- or of the next step (whose output tile may differ)
+            if (it + 1 == NCH / 2) wp = wall + (size_t)(4 * nx.mb + wave) * G::NPAIR * 6 * 64;
+          }
+          static_for<0, 4>([&](auto jc) {
+            constexpr int jh = decltype(jc)::value, blk = 4 * tap + jh, cb = blk & 1, nb = cb ^ 1;
+            constexpr bool more = blk + 1 < 4 * K;    // the first block of the next chunk is read after its barrier
+            constexpr int ntap = (blk + 1) / 4, njh = (blk + 1) % 4;
+            // products (weight plane, x plane), smallest first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+            constexpr int WPL[6] = {2, 0, 1, 1, 0, 0}, XPLN[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int P0 = NPROD == 6 ? 0 : 3;
+            static_for<P0, 6>([&](auto pc) {
+              constexpr int pr = decltype(pc)::value;
+              static_for<0, 4>([&](auto ac) {
+                constexpr int a = decltype(ac)::value, jj = a >> 1, f = a & 1, m = (pr - P0) * 4 + a;   // m-th MFMA of the block
+                bf16x8 av, bv;
+                __builtin_memcpy(&av, &wq[par][WPL[pr]][f], 16);
+                __builtin_memcpy(&bv, &xq[cb][XPLN[pr]][jj], 16);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[f][2 * jh + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[f][2 * jh + jj], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (m < 2 * NPL) {
+                  if constexpr (more) xq[nb][m >> 1][m & 1] = oread(xlb[ntap < K ? ntap : 0], m >> 1, 2 * njh + (m & 1));
+                } else if constexpr ((m == 8 || m == 10) && jh < 3) {
+                  wrequest(par ^ 1, 2 * jh + (m == 10 ? 1 : 0));
+                } else if constexpr (m == 11 && jh == 3) {
+                  wp += 6 * 64;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+              });
+            });
+          });
+        });
+        mark(1);
+      });
+    }
+    // ---- epilogue: two half-tiles of 64 rows, split into planes in LDS (in place over the residual planes) ---------
+    auto half = [&](auto hc) {
+      constexpr int h = decltype(hc)::value;
+      unsigned char* const obuf = ob + (h < NOH ? h : NOH - 1) * OH;
+      u32x2 rv[RES ? 3 : 1][8];
+      if constexpr (RES) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+          for (int c = 0; c < 8; ++c)
+            rv[pl][c] = *reinterpret_cast<const u32x2*>(obuf + pl * OPL + ecell[c & 1] + (c >> 1) * 16 * OP);
+      }
+      static_for<0, 8>([&](auto cc) {
+        constexpr int c = decltype(cc)::value, f = c & 1, jj = c >> 1, j = 4 * h + jj;
+        f32x2 v[2] = {f32x2{acc[f][j][0], acc[f][j][1]}, f32x2{acc[f][j][2], acc[f][j][3]}};
+        if constexpr (RES) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            f32x2 r = (unpack2(rv[0][c][e]) + unpack2(rv[1][c][e])) + unpack2(rv[2][c][e]);   // exact: the planes of an fp32 value
+            if (res_act) {
+              const f32x2 m = r * inv_rslope;
+              r = f32x2{vmin(r[0], m[0]), vmin(r[1], m[1])};
+            }
+            v[e] += r;
+          }
+        }
+        if (scaled) { v[0] *= scale; v[1] *= scale; }
+        if (act_out) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const f32x2 m = v[e] * oslope;
+            v[e] = f32x2{vmax(v[e][0], m[0]), vmax(v[e][1], m[1])};
+          }
+        }
+        // split: hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid); the subtractions are exact in fp32
+        u32x2 pl3[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          pl3[pl] = u32x2{pack2(v[0][0], v[0][1]), pack2(v[1][0], v[1][1])};
+          if (pl < 2) {
+            v[0] -= unpack2(pl3[pl][0]);
+            v[1] -= unpack2(pl3[pl][1]);
+          }
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          *reinterpret_cast<u32x2*>(obuf + pl * OPL + ecell[f] + jj * 16 * OP) = pl3[pl];
+      });
+    };
+    half(std::integral_constant<int, 0>{});
+    mark(2);
+    __syncthreads();                                  // E0: half 0 is in its buffer
+    __syncthreads();                                  // E1: the output waves hold it in registers
+    mark(3);
+    half(std::integral_constant<int, 1>{});
+    mark(2);
+    __syncthreads();                                  // E2: half 1 is in its buffer
+    mark(3);
+  }
+  if (dbg && lane == 0) {
+    tph[7] = (unsigned long long)nstep;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) p.dbg[((size_t)blockIdx.x * NMW + wave) * 8 + q] = tph[q];
+  }
+}
+
+inline int cu_count(std::atomic<int>* cache) {
+  int dev = 0;
+  const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16;
+  if (known) {
+    const int v = cache[dev].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+  }
+  int cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  if (known) cache[dev].store(cus, std::memory_order_relaxed);
+  return cus;
+}
+
+template <int K, int DIL, int CIN, bool RES, int NPROD>
+int launch(const ov_conv1d_split3_params* p, hipStream_t stream) {
+  static std::atomic<int> cache[16];
+  const int slots = cu_count(cache);                  // one workgroup per CU
+  const long SS = (long)p->B * ((p->L + TT - 1) / TT) * (p->Cout / COT);
+  long nwg = p->nwg > 0 ? p->nwg : slots;
+  if (nwg > SS) nwg = SS;
+  hipLaunchKernelGGL((conv1d_split3_kernel<K, DIL, CIN, RES, NPROD>), dim3((unsigned)nwg), dim3(64 * (NMW + NIN + NOUT)), 0,
+                     stream, *p);
+  return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
+}
+
+template <int K, int DIL, int CIN>
+int launch_by_form(const ov_conv1d_split3_params* p, hipStream_t stream) {
+  if (p->products != 6 && p->products != 3) return OV_E_UNSUPPORTED;
+  if (p->res) {                                       // the residual form (conv2 of a ResBlock pair: dilation 1)
+    if constexpr (DIL == 1) return p->products == 6 ? launch<K, DIL, CIN, true, 6>(p, stream) : launch<K, DIL, CIN, true, 3>(p, stream);
+    else return OV_E_UNSUPPORTED;
+  }
+  return p->products == 6 ? launch<K, DIL, CIN, false, 6>(p, stream) : launch<K, DIL, CIN, false, 3>(p, stream);
+}
+
+template <int K, int DIL>
+int launch_by_width(const ov_conv1d_split3_params* p, hipStream_t stream) {
+  if (p->Cin == 128) return launch_by_form<K, DIL, 128>(p, stream);
+  if (p->Cin == 256) return launch_by_form<K, DIL, 256>(p, stream);
+  return OV_E_UNSUPPORTED;
+}
+
+// one translation unit per kernel size (conv1d_split3_k3 / k7 / k11.hip compile in parallel)
+int split3_launch_k3(const ov_conv1d_split3_params* p, hipStream_t stream);
+int split3_launch_k7(const ov_conv1d_split3_params* p, hipStream_t stream);
+int split3_launch_k11(const ov_conv1d_split3_params* p, hipStream_t stream);
+
+template <int K>
+int split3_launch_by_dilation(const ov_conv1d_split3_params* p, hipStream_t stream) {
+  if (p->dil == 1) return launch_by_width<K, 1>(p, stream);
+  if (p->dil == 3) return launch_by_width<K, 3>(p, stream);
+  if (p->dil == 5) return launch_by_width<K, 5>(p, stream);
+  return OV_E_UNSUPPORTED;
+}
+
+}  // namespace ovks3
+#endif

@@ -300,3 +300,23 @@ def test_header_is_plain_c_and_cxx(tmp_path):
         r = subprocess.run([cc, std, "-x", lang, "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only",
                             "-I", os.path.dirname(header), str(src)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_conv_split3_params_struct_matches_header_field_order():
+    header = open(os.path.join(REPO, "include", "openvoice_amd.h")).read()
+    body = header[header.index("typedef struct ov_conv1d_split3_params {"):header.index("} ov_conv1d_split3_params;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        first, *rest = decl.split(",")
+        names.append(re.findall(r"(\w+)$", first.strip())[0])
+        names += [r.strip() for r in rest]
+    assert names == [f[0] for f in _lib.ConvSplit3Params._fields_]
+    import ctypes
+    assert ctypes.sizeof(_lib.ConvSplit3Params) == 120     # 5 pointers, 3 int64, 8 int32, 3 float, 1 int32, 1 pointer
+    lib = _lib.load()
+    assert lib.ov_conv1d_split3(None, None) == -1
+    assert lib.ov_version() >= _lib.MIN_VERSION == 203
