@@ -465,7 +465,7 @@ int ov_resblock_pair2_bf16_supported(int C, int K, int dil);
  * x is read as stored (the producer stores it activated); res~ = res for res_slope = 1, else the inverse leaky ReLU of
  * res (res >= 0 ? res : res / res_slope: the residual tensor is the conv input of the pair, stored activated).
  * reference: openvoice/modules.py:296-306 (xt = c1(lrelu(x)); xt = c2(lrelu(xt)); x = xt + x).
- * Cin = Cout in {128, 256}, K in {3, 7, 11}, dil in {1, 3, 5} (with res: dil = 1); out must alias neither x nor res. */
+ * Cin = Cout in {64, 128, 256}, K in {3, 7, 11}, dil in {1, 3, 5} (with res: dil = 1); out must alias neither x nor res. */
 typedef struct ov_conv1d_split3_params {
   const uint16_t* x;     /* [3][B][L][Cin] bf16 planes */
   const uint16_t* w;     /* ov_conv1d_split3_pack(Cout, Cin, K) */

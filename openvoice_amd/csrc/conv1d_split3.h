@@ -44,11 +44,11 @@ constexpr int NMW = 4;       // matrix waves: one per SIMD
 constexpr int NIN = 2;       // helper waves that stream the input chunks (and the residual tile) in
 constexpr int NOUT = 2;      // helper waves that store the output tile
 constexpr int TT = 128;      // time rows per step
-constexpr int COT = 128;     // output channels per step (4 matrix waves x 32)
-constexpr int OP = 2 * COT;  // row pitch of one plane of the output half-tile (bytes)
-constexpr int OROWS = 64;    // rows per output half-tile
-constexpr int OPL = OROWS * OP;          // bytes per plane of a half-tile (16 KiB = 16 blocks of 4 rows)
-constexpr int OH = 3 * OPL;              // bytes per half-tile
+// Output tile of a step: TT rows x COT channels, COT = 128 (4 matrix waves side by side along the channels, 128 rows
+// each) or 64 (C = 64: 2 x 2 waves of 64 rows x 32 channels).  It leaves through LDS in NR rounds of 3 planes x 16 KiB:
+// COT = 128: two half-tiles of 64 rows x 256 B; COT = 64: the whole tile, 128 rows x 128 B.
+constexpr int OPL = 16 * 1024;           // bytes per plane of a round (16 blocks of 1 KiB)
+constexpr int OH = 3 * OPL;              // bytes per round
 
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {       // one v_cvt_pk_bf16_f32, round to nearest even
   const bf16x2 h = __builtin_convertvector(f32x2{lo, hi}, bf16x2);
@@ -90,32 +90,41 @@ struct Step {
   }
 };
 
-template <int K, int DIL, int CIN, bool RES>
+template <int K, int DIL, int CIN, int COT, bool RES>
 struct Geo {
+  static constexpr int NCT = COT / 32;               // matrix waves along the channels
+  static constexpr int NTG = NMW / NCT;              // ... along time
+  static constexpr int JW = 8 / NTG;                 // 16-row time fragments per wave
+  static constexpr int NR = COT == 128 ? 2 : 1;      // output rounds per step
+  static constexpr int OP = 2 * COT;                 // row pitch of an output round (bytes)
+  static constexpr int OROWS = OPL / OP;             // its rows: 64 (two rounds) or 128 (one)
+  static constexpr int RPBO = 1024 / OP;             // rows per 1 KiB block of a round: 4 or 8
   static constexpr int NCH = CIN / 32;               // 32-channel input chunks
   static constexpr int P1 = (K - 1) * DIL / 2;       // halo rows on each side
   static constexpr int R1 = TT + 2 * P1;             // rows of an input chunk
   static constexpr int NBLK = (R1 + 15) / 16;        // 1 KiB DMA blocks (16 rows x 64 B) per plane of a chunk
   static constexpr int XPL = NBLK * 1024;            // bytes per plane of a chunk buffer
   static constexpr int XB = 3 * XPL;                 // bytes per chunk buffer
-  static constexpr int NOH = RES ? 2 : 1;            // output half-tile buffers (with a residual: both halves resident)
+  static constexpr int NOH = RES ? NR : 1;           // round buffers (with a residual every round is resident)
   static constexpr int OOFF = 2 * XB;
   static constexpr int BOFF = OOFF + NOH * OH;
   static constexpr int SMEM = BOFF + COT * 4;
   static constexpr int NPAIR = NCH * K;              // (chunk, tap) pairs of one step = 6 weight records each
   static_assert(NCH % 2 == 0, "the chunk loop is unrolled by two (static weight-ring slots for odd K)");
+  static_assert(COT == 128 || COT == 64, "4 matrix waves: 1 x 4 or 2 x 2");
   static_assert(SMEM <= 160 * 1024, "LDS");
 };
 
-template <int K, int DIL, int CIN, bool RES, int NPROD>
+template <int K, int DIL, int CIN, int COT, bool RES, int NPROD>
 __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(const ov_conv1d_split3_params p) {
-  using G = Geo<K, DIL, CIN, RES>;
+  using G = Geo<K, DIL, CIN, COT, RES>;
   constexpr int NCH = G::NCH, P1 = G::P1, R1 = G::R1, NBLK = G::NBLK, XPL = G::XPL, XB = G::XB, NOH = G::NOH;
+  constexpr int NCT = G::NCT, JW = G::JW, NR = G::NR, OP = G::OP, OROWS = G::OROWS, RPBO = G::RPBO;
   constexpr int NPL = NPROD == 6 ? 3 : 2;            // planes the k-loop reads (3 products: hi*hi + hi*mid + mid*hi)
   static_assert(NPROD == 6 || NPROD == 3, "6 (fp32-level) or 3 (16-bit operands) plane products");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[G::SMEM];
   unsigned char* const xs = smem;                    // 2 chunk buffers: [plane][row][64 B], swizzled
-  unsigned char* const ob = smem + G::OOFF;          // NOH output half-tiles: [plane][row][256 B], swizzled
+  unsigned char* const ob = smem + G::OOFF;          // NOH output rounds: [plane][row][OP bytes], swizzled
   float* const bsm = reinterpret_cast<float*>(smem + G::BOFF);
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -166,33 +175,37 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
         }
       }
     };
-    // Residual tile (RES): both half-tiles [plane][64 rows][256 B] into the output buffers, where the matrix waves
-    // replace each cell by its result.  Block blk = 4 rows; lane -> (row lrow4 = lane / 16, physical slot sp16 = lane %
-    // 16) holding logical slot sp16 ^ (row & 15), row & 15 = 4 (blk & 3) + lrow4; this wave takes the blocks with
-    // blk & 3 in {2 iw, 2 iw + 1}: two per-lane constants.
-    const int lrow4 = lane >> 4, sp16 = lane & 15;
-    uint32_t rdof[2];
+    // Residual tile (RES): every round [plane][OROWS rows][OP bytes] into the output buffers, where the matrix waves
+    // replace each cell by its result.  Block blk = RPBO rows; lane -> (row lrow = lane / SPRO, physical 16-byte slot
+    // sp = lane % SPRO) holding logical slot sp ^ g(row); COT = 128: g(row) = row & 15 = 4 (blk & 3) + lrow, this wave
+    // takes the blocks with blk & 3 in {2 iw, 2 iw + 1}; COT = 64: g(row) = (row >> 1) & 7 = 4 (blk & 1) + (lrow >> 1),
+    // this wave takes blk & 1 = iw.  One per-lane constant per swizzle phase.
+    constexpr int SPRO = OP / 16, NE = COT == 128 ? 2 : 1, NQ = 8 / NE;   // blocks of a plane per wave: NQ x NE = 8
+    const int lrowo = lane / SPRO, spo = lane % SPRO;
+    auto oblk = [&](int w, int q, int e) { return COT == 128 ? 4 * q + 2 * w + e : 2 * q + w; };
+    auto ophase = [&](int w, int e) { return COT == 128 ? 4 * (2 * w + e) + lrowo : 4 * w + (lrowo >> 1); };
+    uint32_t rdof[NE];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) rdof[e] = (uint32_t)(lrow4 * PGO + 16 * (sp16 ^ (4 * (2 * iw + e) + lrow4)));
+    for (int e = 0; e < NE; ++e) rdof[e] = (uint32_t)(lrowo * PGO + 16 * (spo ^ ophase(iw, e)));
     auto dma_residual = [&](const Step& st) {
       if constexpr (RES) {
         const int t0 = st.tile * TT;
         const bool interior = t0 + TT <= L;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < NR; ++h)
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) {
             const gc_ptr rb = (gc_ptr)(p.res) + (int64_t)pl * p.res_plane * 2 + ((int64_t)st.b * L + t0 + OROWS * h) * PGO + OP * st.mb;
             const lds_ptr lb = (lds_ptr)(ob) + h * OH + pl * OPL;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < NQ; ++q)
 #pragma unroll
-              for (int e = 0; e < 2; ++e) {
-                const int blk = 4 * q + 2 * iw + e;
-                gc_ptr bj = rb + (int64_t)blk * 4 * PGO;
+              for (int e = 0; e < NE; ++e) {
+                const int blk = oblk(iw, q, e);
+                gc_ptr bj = rb + (int64_t)blk * RPBO * PGO;
                 asm volatile("" : "+s"(bj));
                 gc_ptr src = bj + rdof[e];
-                if (!interior && t0 + OROWS * h + 4 * blk + lrow4 >= L) src = zsrc + lane * 16;
+                if (!interior && t0 + OROWS * h + RPBO * blk + lrowo >= L) src = zsrc + lane * 16;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(lb + blk * 1024), 16, 0, 0);
               }
@@ -225,23 +238,26 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
 
   if (wave >= NMW + NIN) {
     // ================================ output waves ===============================================
-    // Half-tile h of step s: LDS -> registers after barrier E0 (h = 0) / E2 (h = 1), registers -> HBM right after (the
-    // stores never gate a barrier: these waves wait for nothing but their own LDS reads).  Block (plane, blk): 4 rows
-    // x 256 B, lane -> (row lane / 16, physical slot lane % 16); this wave takes blk & 3 in {2 ow, 2 ow + 1}.
+    // Round h of step s: LDS -> registers after barrier E0 (h = 0) / E2 (h = 1), registers -> HBM right after (the
+    // stores never gate a barrier: these waves wait for nothing but their own LDS reads).  Blocks and swizzle phases
+    // as in the input waves' residual pass: this wave takes blk & 3 in {2 ow, 2 ow + 1} (COT = 128) / blk & 1 = ow (64).
     const int ow = wave - NMW - NIN;
-    const int lrow4 = lane >> 4, sp16 = lane & 15;
-    uint32_t odof[2];
+    constexpr int SPRO = OP / 16, NE = COT == 128 ? 2 : 1, NQ = 8 / NE;
+    const int lrowo = lane / SPRO, spo = lane % SPRO;
+    auto oblk = [&](int w, int q, int e) { return COT == 128 ? 4 * q + 2 * w + e : 2 * q + w; };
+    auto ophase = [&](int w, int e) { return COT == 128 ? 4 * (2 * w + e) + lrowo : 4 * w + (lrowo >> 1); };
+    uint32_t odof[NE];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) odof[e] = (uint32_t)(lrow4 * PGO + 16 * (sp16 ^ (4 * (2 * ow + e) + lrow4)));
-    u32x4 ov[3][4][2];
+    for (int e = 0; e < NE; ++e) odof[e] = (uint32_t)(lrowo * PGO + 16 * (spo ^ ophase(ow, e)));
+    u32x4 ov[3][NQ][NE];
     auto fetch = [&](int hbuf) {
       const unsigned char* lb = ob + hbuf * OH + lane * 16;
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
-          for (int e = 0; e < 2; ++e) ov[pl][q][e] = *reinterpret_cast<const u32x4*>(lb + pl * OPL + (4 * q + 2 * ow + e) * 1024);
+          for (int e = 0; e < NE; ++e) ov[pl][q][e] = *reinterpret_cast<const u32x4*>(lb + pl * OPL + oblk(ow, q, e) * 1024);
     };
     auto store = [&](const Step& st, int h) {
       const int t0 = st.tile * TT + OROWS * h;
@@ -250,14 +266,14 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
       for (int pl = 0; pl < 3; ++pl) {
         const gm_ptr obase = (gm_ptr)(p.out) + (int64_t)pl * p.out_plane * 2 + ((int64_t)st.b * L + t0) * PGO + OP * st.mb;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const int blk = 4 * q + 2 * ow + e;
-            gm_ptr bj = obase + (int64_t)blk * 4 * PGO;
+          for (int e = 0; e < NE; ++e) {
+            const int blk = oblk(ow, q, e);
+            gm_ptr bj = obase + (int64_t)blk * RPBO * PGO;
             asm volatile("" : "+s"(bj));
             __attribute__((address_space(1))) u32x4* dst = reinterpret_cast<__attribute__((address_space(1))) u32x4*>(bj + odof[e]);
-            if (interior || t0 + 4 * blk + lrow4 < L) *dst = ov[pl][q][e];
+            if (interior || t0 + RPBO * blk + lrowo < L) *dst = ov[pl][q][e];
           }
       }
     };
@@ -266,41 +282,48 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
       const Step st(s, ntiles, nmb);
 #pragma unroll
       for (int c = 0; c < NCH; ++c) __builtin_amdgcn_s_barrier();   // A(s, c)
-      __builtin_amdgcn_s_barrier();                            // E0: half 0 is complete in its buffer
+      __builtin_amdgcn_s_barrier();                            // E0: round 0 is complete in its buffer
       fetch(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                            // E1: buffer 0 may be overwritten (NOH = 1: by half 1)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (read before E1 / A(s + 1, 0) lets anything overwrite it)
+      __builtin_amdgcn_s_barrier();                            // E1: buffer 0 may be overwritten (NOH = 1: by round 1)
       store(st, 0);
-      __builtin_amdgcn_s_barrier();                            // E2: half 1 is complete
-      fetch(NOH - 1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // ... and read before A(s + 1, 0) lets anything overwrite it
-      store(st, 1);
+      __builtin_amdgcn_s_barrier();                            // E2: round 1 is complete
+      if constexpr (NR == 2) {
+        fetch(NOH - 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        store(st, 1);
+      }
     }
     return;
   }
 
   // ================================== matrix waves ================================================
   // v_mfma_f32_16x16x32_bf16, D[channel][time] = W (16 channels x 32 k) * x (32 k x 16 time rows), fragments as in
-  // conv1d_bf16_pair2.h: a wave's 128 x 32 tile is 8 (time, j) x 2 (channel, f) fragments; a lane holds time row
-  // 16 j + (lane & 15) and channels 16 f + 4 (lane >> 4) + {0..3} of fragment (f, j).
+  // conv1d_bf16_pair2.h: a wave's (16 JW) x 32 tile is JW (time, j) x 2 (channel, f) fragments; a lane holds time row
+  // trow0 + 16 j + (lane & 15) and channels 32 ct + 16 f + 4 (lane >> 4) + {0..3} of fragment (f, j).
   __builtin_amdgcn_s_setprio(2);
   const int g4 = lane >> 4, l15 = lane & 15;
+  const int ct = wave % NCT, trow0 = (wave / NCT) * 16 * JW;
 
-  // per-lane LDS offset of the x operand of tap `tap`: row l15 + tap DIL (+ 16 j: same swizzle), logical slot g4
+  // per-lane LDS offset of the x operand of tap `tap`: row trow0 + l15 + tap DIL (+ 16 j: same swizzle), logical slot g4
   uint32_t xl_tap[K];
 #pragma unroll
   for (int tap = 0; tap < K; ++tap) {
-    const int row = l15 + tap * DIL;
+    const int row = trow0 + l15 + tap * DIL;
     xl_tap[tap] = (uint32_t)(row * 64 + 16 * (g4 ^ ((row >> 2) & 3)));
   }
-  // epilogue cells: cell (f, jj) of half h = row 16 jj + l15 of the half-tile, channels 32 wave + 16 f + 4 g4 + {0..3}:
-  // logical 16-byte slot 4 wave + 2 f + (g4 >> 1), 8 bytes at 8 (g4 & 1) inside it; row & 15 = l15
+  // epilogue cells: cell (f, jj) of a round = row erow0 + 16 jj + l15 of the round's buffer (COT = 128: two rounds of
+  // the wave's rows 64 h + ..., erow0 = 0; COT = 64: one round, erow0 = trow0), channels 32 ct + 16 f + 4 g4 + {0..3}:
+  // logical 16-byte slot 4 ct + 2 f + (g4 >> 1), 8 bytes at 8 (g4 & 1) inside it; the row's swizzle depends on l15 only
+  const int erow0 = COT == 128 ? 0 : trow0;
+  const int eswz = COT == 128 ? l15 : (l15 >> 1) & 7;
   uint32_t ecell[2];
 #pragma unroll
-  for (int f = 0; f < 2; ++f) ecell[f] = (uint32_t)(l15 * OP + 16 * ((4 * wave + 2 * f + (g4 >> 1)) ^ l15) + 8 * (g4 & 1));
+  for (int f = 0; f < 2; ++f)
+    ecell[f] = (uint32_t)((erow0 + l15) * OP + 16 * ((4 * ct + 2 * f + (g4 >> 1)) ^ eswz) + 8 * (g4 & 1));
 
   // packed weights (ov_conv1d_split3_pack): record (((ct * NCH + c) * K + tap) * 3 + plane) * 2 + f for the 32-channel
-  // output tile ct = 4 mb + wave: the 6 records of a (chunk, tap) pair are consecutive, a step's stream is sequential.
+  // output tile NCT mb + ct: the 6 records of a (chunk, tap) pair are consecutive, a step's stream is sequential.
   typedef const __attribute__((address_space(1))) u32x4* gw_ptr;
   const gw_ptr wall = (gw_ptr)(p.w);
   gw_ptr wp = wall;
@@ -329,7 +352,7 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
   int n = 0, nstep = 0;
   {                                                   // first pair of the first step
     const Step st(g0, ntiles, nmb);
-    wp = wall + (size_t)(4 * st.mb + wave) * G::NPAIR * 6 * 64;
+    wp = wall + (size_t)(NCT * st.mb + ct) * G::NPAIR * 6 * 64;
     static_for<0, 6>([&](auto rc) { wrequest(0, decltype(rc)::value); });
     wp += 6 * 64;
   }
@@ -337,7 +360,7 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
     const Step st(s, ntiles, nmb);
     const Step nx(s + 1 < g1 ? s + 1 : s, ntiles, nmb);
     if (tid < COT) bsm[tid] = p.bias[COT * st.mb + tid];   // (read after barrier A(s, 0); last read before E0 of s - 1)
-    f32x4 acc[2][8];
+    f32x4 acc[2][JW];
     // ---- k-loops: two chunks per iteration (static ring parity: 2 K pairs) ------------------------------------------
     for (int it = 0; it < NCH / 2; ++it) {
       static_for<0, 2>([&](auto cc) {
@@ -348,9 +371,9 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
           // (bias in LDS since the barrier above)
 #pragma unroll
           for (int f = 0; f < 2; ++f) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(bsm + 32 * wave + 16 * f + 4 * g4);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(bsm + 32 * ct + 16 * f + 4 * g4);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[f][j] = v;
+            for (int j = 0; j < JW; ++j) acc[f][j] = v;
           }
         }
         const uint32_t bufoff = (uint32_t)((n & 1) * XB);
@@ -361,9 +384,9 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
           xlb[tap] = xl_tap[tap] + bufoff;
           asm volatile("" : "+v"(xlb[tap]));
         }
-        // One (chunk, tap) pair = 4 blocks of 24 MFMAs: block jh covers time fragments j = 2 jh, 2 jh + 1 with all six
-        // plane products against the pair's six weight records; the same accumulator recurs every 4th MFMA.  Between
-        // the MFMAs, one instruction per gap: the 6 operand reads of the next block, 2 weight requests of the next pair.
+        // One (chunk, tap) pair = JW / 2 blocks of 24 MFMAs: block jh covers time fragments j = 2 jh, 2 jh + 1 with all
+        // six plane products against the pair's six weight records; the same accumulator recurs every 4th MFMA.  Between
+        // the MFMAs, one instruction per gap: the 6 operand reads of the next block, weight requests of the next pair.
         u32x4 xq[2][3][2];                            // [block parity][plane][jj]
         auto oread = [&](uint32_t base, int pl, int j) -> u32x4 {
           return *reinterpret_cast<const u32x4*>(xs + base + pl * XPL + j * 1024);
@@ -377,12 +400,14 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
           constexpr int par = (ci * K + tap) & 1;     // weight-ring parity of this pair (2 K pairs per iteration: static)
           if constexpr (ci == 1 && tap == K - 1) {
             // the next pair is chunk pair 0 of the next iteration -- or of the next step (whose output tile may differ)
-            if (it + 1 == NCH / 2) wp = wall + (size_t)(4 * nx.mb + wave) * G::NPAIR * 6 * 64;
+            if (it + 1 == NCH / 2) wp = wall + (size_t)(NCT * nx.mb + ct) * G::NPAIR * 6 * 64;
           }
-          static_for<0, 4>([&](auto jc) {
-            constexpr int jh = decltype(jc)::value, blk = 4 * tap + jh, cb = blk & 1, nb = cb ^ 1;
-            constexpr bool more = blk + 1 < 4 * K;    // the first block of the next chunk is read after its barrier
-            constexpr int ntap = (blk + 1) / 4, njh = (blk + 1) % 4;
+          constexpr int JB = JW / 2;                  // blocks per pair
+          constexpr int SPB = NPROD == 6 ? 4 : 2;     // weight-request gaps per block (after MFMAs 8, 10, 12, 14)
+          static_for<0, JB>([&](auto jc) {
+            constexpr int jh = decltype(jc)::value, blk = JB * tap + jh, cb = blk & 1, nb = cb ^ 1;
+            constexpr bool more = blk + 1 < JB * K;   // the first block of the next chunk is read after its barrier
+            constexpr int ntap = (blk + 1) / JB, njh = (blk + 1) % JB;
             // products (weight plane, x plane), smallest first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
             constexpr int WPL[6] = {2, 0, 1, 1, 0, 0}, XPLN[6] = {0, 2, 1, 0, 1, 0};
             constexpr int P0 = NPROD == 6 ? 0 : 3;
@@ -398,9 +423,9 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (m < 2 * NPL) {
                   if constexpr (more) xq[nb][m >> 1][m & 1] = oread(xlb[ntap < K ? ntap : 0], m >> 1, 2 * njh + (m & 1));
-                } else if constexpr ((m == 8 || m == 10) && jh < 3) {
-                  wrequest(par ^ 1, 2 * jh + (m == 10 ? 1 : 0));
-                } else if constexpr (m == 11 && jh == 3) {
+                } else if constexpr (m >= 8 && m % 2 == 0 && (m - 8) / 2 < SPB && jh * SPB + (m - 8) / 2 < 6) {
+                  wrequest(par ^ 1, jh * SPB + (m - 8) / 2);
+                } else if constexpr (m == 11 && jh == JB - 1) {
                   wp += 6 * 64;
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -411,7 +436,7 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
         mark(1);
       });
     }
-    // ---- epilogue: two half-tiles of 64 rows, split into planes in LDS (in place over the residual planes) ---------
+    // ---- epilogue: NR rounds of 4 time fragments per wave, split into planes in LDS (in place over the residual) -----
     auto half = [&](auto hc) {
       constexpr int h = decltype(hc)::value;
       unsigned char* const obuf = ob + (h < NOH ? h : NOH - 1) * OH;
@@ -465,7 +490,7 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
     __syncthreads();                                  // E0: half 0 is in its buffer
     __syncthreads();                                  // E1: the output waves hold it in registers
     mark(3);
-    half(std::integral_constant<int, 1>{});
+    if constexpr (NR == 2) half(std::integral_constant<int, 1>{});
     mark(2);
     __syncthreads();                                  // E2: half 1 is in its buffer
     mark(3);
@@ -493,12 +518,13 @@ inline int cu_count(std::atomic<int>* cache) {
 
 template <int K, int DIL, int CIN, bool RES, int NPROD>
 int launch(const ov_conv1d_split3_params* p, hipStream_t stream) {
+  constexpr int COT = CIN == 64 ? 64 : 128;
   static std::atomic<int> cache[16];
   const int slots = cu_count(cache);                  // one workgroup per CU
   const long SS = (long)p->B * ((p->L + TT - 1) / TT) * (p->Cout / COT);
   long nwg = p->nwg > 0 ? p->nwg : slots;
   if (nwg > SS) nwg = SS;
-  hipLaunchKernelGGL((conv1d_split3_kernel<K, DIL, CIN, RES, NPROD>), dim3((unsigned)nwg), dim3(64 * (NMW + NIN + NOUT)), 0,
+  hipLaunchKernelGGL((conv1d_split3_kernel<K, DIL, CIN, COT, RES, NPROD>), dim3((unsigned)nwg), dim3(64 * (NMW + NIN + NOUT)), 0,
                      stream, *p);
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
 }
@@ -515,23 +541,19 @@ int launch_by_form(const ov_conv1d_split3_params* p, hipStream_t stream) {
 
 template <int K, int DIL>
 int launch_by_width(const ov_conv1d_split3_params* p, hipStream_t stream) {
+  if (p->Cin == 64) return launch_by_form<K, DIL, 64>(p, stream);
   if (p->Cin == 128) return launch_by_form<K, DIL, 128>(p, stream);
   if (p->Cin == 256) return launch_by_form<K, DIL, 256>(p, stream);
   return OV_E_UNSUPPORTED;
 }
 
-// one translation unit per kernel size (conv1d_split3_k3 / k7 / k11.hip compile in parallel)
-int split3_launch_k3(const ov_conv1d_split3_params* p, hipStream_t stream);
-int split3_launch_k7(const ov_conv1d_split3_params* p, hipStream_t stream);
-int split3_launch_k11(const ov_conv1d_split3_params* p, hipStream_t stream);
-
-template <int K>
-int split3_launch_by_dilation(const ov_conv1d_split3_params* p, hipStream_t stream) {
-  if (p->dil == 1) return launch_by_width<K, 1>(p, stream);
-  if (p->dil == 3) return launch_by_width<K, 3>(p, stream);
-  if (p->dil == 5) return launch_by_width<K, 5>(p, stream);
-  return OV_E_UNSUPPORTED;
-}
+// one translation unit per (kernel size, dilation): conv1d_split3_k3d1.hip ... k11d5.hip compile in parallel (the
+// unrolled k-loops make these the slowest files of the library)
+#define OV_SPLIT3_DECLARE(K, D) int split3_launch_k##K##d##D(const ov_conv1d_split3_params* p, hipStream_t stream);
+OV_SPLIT3_DECLARE(3, 1) OV_SPLIT3_DECLARE(3, 3) OV_SPLIT3_DECLARE(3, 5)
+OV_SPLIT3_DECLARE(7, 1) OV_SPLIT3_DECLARE(7, 3) OV_SPLIT3_DECLARE(7, 5)
+OV_SPLIT3_DECLARE(11, 1) OV_SPLIT3_DECLARE(11, 3) OV_SPLIT3_DECLARE(11, 5)
+#undef OV_SPLIT3_DECLARE
 
 }  // namespace ovks3
 #endif

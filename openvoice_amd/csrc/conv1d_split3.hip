@@ -128,7 +128,7 @@ int ov_conv1d_split3_pack(const float* w, int Cout, int Cin, int K, uint16_t* ds
 
 int ov_conv1d_split3_supported(int Cin, int Cout, int K, int dil) {
   const bool kd = (K == 3 || K == 7 || K == 11) && (dil == 1 || dil == 3 || dil == 5);
-  return kd && (Cin == 128 || Cin == 256) && Cout == Cin ? 1 : 0;
+  return kd && (Cin == 64 || Cin == 128 || Cin == 256) && Cout == Cin ? 1 : 0;
 }
 
 int ov_conv1d_split3(const ov_conv1d_split3_params* p, ov_stream_t stream) {
@@ -146,9 +146,11 @@ int ov_conv1d_split3(const ov_conv1d_split3_params* p, ov_stream_t stream) {
       (p->x_plane % 8) || (p->out_plane % 8) || (p->res && (p->res_plane % 8)))
     return OV_E_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (p->K == 3) return split3_launch_k3(p, st);
-  if (p->K == 7) return split3_launch_k7(p, st);
-  if (p->K == 11) return split3_launch_k11(p, st);
+#define OV_SPLIT3_CASE(KK, DD) if (p->K == KK && p->dil == DD) return split3_launch_k##KK##d##DD(p, st);
+  OV_SPLIT3_CASE(3, 1) OV_SPLIT3_CASE(3, 3) OV_SPLIT3_CASE(3, 5)
+  OV_SPLIT3_CASE(7, 1) OV_SPLIT3_CASE(7, 3) OV_SPLIT3_CASE(7, 5)
+  OV_SPLIT3_CASE(11, 1) OV_SPLIT3_CASE(11, 3) OV_SPLIT3_CASE(11, 5)
+#undef OV_SPLIT3_CASE
   return OV_E_UNSUPPORTED;
 }
 

@@ -490,6 +490,10 @@ class ConverterEngine:
         # ~1e-2 of the fp32 path instead of ~1e-5).  Built lazily by use_bf16_generator().
         self._state_dict_for_bf16 = sd
         self.generator_bf16 = None
+        # opt-in split-precision MRF stages: fp32-level products on the bf16 matrix pipe
+        self._split3_on = False
+        self.split3_products = 6
+        self.split_resblocks = None      # per stage: None, or [[(c1, c2) PackedConvSplit3 pairs] per ResBlock]
 
     # ---- launch helpers --------------------------------------------------------------------------
     def _stream(self):
@@ -722,7 +726,7 @@ class ConverterEngine:
         """``voice_conversion`` for one fixed (B, T, tau) as a captured HIP graph (see ``GraphedConversion``);
         the most recent ``max_cached`` shapes stay resident."""
         key = (int(B), int(T), float(tau), int(src_rows), int(tgt_rows), bool(getattr(self, "_bf16_on", False)),
-               bool(skip_padding))
+               bool(skip_padding), bool(self._split3_on), self.split3_products)
         cache = self.__dict__.setdefault("_graphs", {})
         g = cache.pop(key, None)
         if g is None:
@@ -740,6 +744,92 @@ class ConverterEngine:
             self.generator_bf16 = GeneratorBf16(self._state_dict_for_bf16, self.cfg, self.device)
         self._bf16_on = bool(enable)
         return self
+
+    def use_split_bf16x3(self, enable=True, products=6):
+        """Run the MRF ResBlocks of every generator stage that has split-precision instances (C = 128 / 256 here: stages
+        0 and 1 of the released configuration, 60 % of a conversion's FLOPs) on ``ov_conv1d_split3``: every fp32 operand
+        carried as three bf16 planes (lossless), every product as the six plane products of weight >= 2^-18 on the bf16
+        matrix pipe with fp32 accumulation -- fp32-level results (measured against float64 the error is BELOW the fp32
+        MFMA kernels', profiles/r05_s1_split3_gate.json) at 1.8x their speed.  ``products=3`` uses the hi / mid planes
+        only (16-bit operands, ~3e-5 relative).  Off by default: the contract path is the fp32 kernels
+        (reference: openvoice/modules.py:296-309, models.py:280-286)."""
+        if products not in (6, 3):
+            raise _lib.OvError(f"use_split_bf16x3: products must be 6 or 3, got {products!r}")
+        if enable and self.split_resblocks is None:
+            from . import split3
+            sd, cfg = self._state_dict_for_bf16, self.cfg
+            kernels, dils = cfg["resblock_kernel_sizes"], cfg["resblock_dilation_sizes"]
+            ch = cfg["upsample_initial_channel"]
+            stages = []
+            for i in range(len(cfg["upsample_rates"])):
+                ch //= 2
+                ok = all(split3.supported(ch, ch, rk, d) and split3.supported(ch, ch, rk, 1)
+                         for rk, rd in zip(kernels, dils) for d in rd)
+                if not ok:
+                    stages.append(None)
+                    continue
+                stage = []
+                for j, (rk, rd) in enumerate(zip(kernels, dils)):
+                    rb = f"dec.resblocks.{i * len(kernels) + j}"
+                    stage.append([(split3.PackedConvSplit3(effective_weight(sd, f"{rb}.convs1.{n}"), sd[f"{rb}.convs1.{n}.bias"],
+                                                           self.device, dil=d),
+                                   split3.PackedConvSplit3(effective_weight(sd, f"{rb}.convs2.{n}"), sd[f"{rb}.convs2.{n}.bias"],
+                                                           self.device, dil=1)) for n, d in enumerate(rd)])
+                stages.append(stage)
+            self.split_resblocks = stages
+        self._split3_on = bool(enable)
+        self.split3_products = products
+        self.__dict__.pop("_graphs", None)        # captured graphs hold the other path's launches
+        return self
+
+    def _split_buffers(self, ws, B, ch, L):
+        """Plane tensors (3, B, L, ch) bf16 of the split-precision stages: the activated stage input, the conv1 output,
+        two ping-pong pair outputs and one result per ResBlock; allocated once per workspace at the largest stage."""
+        nk = len(self.cfg["resblock_kernel_sizes"])
+        need = 3 * B * L * ch
+        bufs = ws.get("split3")
+        if bufs is None or bufs[0].numel() < need:
+            bufs = ws["split3"] = [torch.empty(need, dtype=torch.bfloat16, device=self.device) for _ in range(4 + nk)]
+        return [b[:need].view(3, B, L, ch) for b in bufs]
+
+    def _mrf_split(self, stage, u, acc, ws, B, ch, L):
+        """One MRF stage on the split-precision kernels: u (B, ch, L) fp32 raw -> acc (B, ch, L) fp32 = mean of the
+        ResBlock1 outputs.  Tensors between the launches are plane tensors stored ACTIVATED (the producer applies the
+        next conv's leaky ReLU before it splits); conv2 reads its residual from the pair's activated input and inverts
+        the activation in fp32; the last pair of a ResBlock stores raw; the sum / mean is the layout kernel back."""
+        from . import split3
+        nk = len(stage)
+        bufs = self._split_buffers(ws, B, ch, L)
+        xa, t, ping, pong, results = bufs[0], bufs[1], bufs[2], bufs[3], bufs[4:]
+        prod = self.split3_products
+
+        def timed(tag, flops, fn):
+            if self.profile is None:
+                fn()
+                return
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            self.profile.append((tag, flops, e0, e1))
+
+        uv = u[:B * ch * L].view(B, ch, L)
+        timed("split_layout", 0.0, lambda: split3.to_planes(uv, LRELU_SLOPE, out=xa))
+        for j, pairs in enumerate(stage):
+            cur = xa
+            for n, (c1, c2) in enumerate(pairs):
+                last = n == len(pairs) - 1
+                flops = 2.0 * ch * ch * c1.K * L * B
+                timed("mrf_split", flops, lambda: split3.launch_conv_split3(c1, cur, t, out_slope=LRELU_SLOPE, products=prod))
+                dst = results[j] if last else (pong if cur is ping else ping)
+                timed("mrf_split", flops, lambda: split3.launch_conv_split3(c2, t, dst, res=cur, res_slope=LRELU_SLOPE,
+                                                                       out_slope=1.0 if last else LRELU_SLOPE, products=prod))
+                cur = dst
+        ops = list(results[:nk]) + [None] * (3 - nk)
+        if nk > 3:
+            raise _lib.OvError("split-precision MRF: at most 3 ResBlocks per stage")
+        av = acc[:B * ch * L].view(B, ch, L)
+        timed("split_layout", 0.0, lambda: split3.from_planes(ops[0], ops[1], ops[2], in_slope=1.0, scale=1.0 / nk, out=av))
 
     def frame_limits(self, lengths, T):
         """Two int32 [B] device vectors (``ov_frame_limits_i32``, no host sync): the frames of each utterance the
@@ -793,6 +883,13 @@ class ConverterEngine:
                 free.append(x)
             L *= s
             x_ld = L
+            if self._split3_on and self.split_resblocks[i] is not None:
+                # split-precision stage (opt-in): computes whole tensors (no length-aware work lists: a superset)
+                acc = free.pop()
+                self._mrf_split(self.split_resblocks[i], u, acc, ws, B, ch, L)
+                free.append(u)
+                x = acc
+                continue
             t1, ra, acc = free.pop(), free.pop(), free.pop()
             bs = ch * L
             # MRF: mean of the 3 ResBlock1 outputs (models.py:280-286, modules.py:296-306).  The three ResBlocks of a

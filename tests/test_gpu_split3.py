@@ -70,7 +70,7 @@ def test_layout_kernels_round_trip_exactly():
     assert (inv - x).abs().max().item() <= 2.0 ** -22 * x.abs().max().item()
 
 
-@pytest.mark.parametrize("c", [128, 256])
+@pytest.mark.parametrize("c", [64, 128, 256])
 @pytest.mark.parametrize("k,d", KD)
 def test_split3_conv_matches_float64(c, k, d):
     assert supported(c, c, k, d)
@@ -82,7 +82,7 @@ def test_split3_conv_matches_float64(c, k, d):
 
 
 @pytest.mark.parametrize("L", [1, 5, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 1030])
-@pytest.mark.parametrize("c,k,d", [(128, 11, 5), (128, 3, 1), (256, 7, 3)])
+@pytest.mark.parametrize("c,k,d", [(128, 11, 5), (128, 3, 1), (256, 7, 3), (64, 11, 5), (64, 3, 1)])
 def test_split3_lengths_around_the_step(c, k, d, L):
     B = 3
     w, b, layer = _layer(c, k, d, seed=L)
@@ -93,13 +93,13 @@ def test_split3_lengths_around_the_step(c, k, d, L):
 @pytest.mark.parametrize("nwg", [1, 2, 3, 7, 1000])
 def test_split3_forced_workgroup_counts(nwg):
     """Ranges of steps that start / end mid-utterance and span utterances; C = 256 also splits the channel blocks."""
-    for c, k, d, L in [(128, 7, 1, 530), (256, 3, 3, 390)]:
+    for c, k, d, L in [(128, 7, 1, 530), (256, 3, 3, 390), (64, 7, 5, 530)]:
         w, b, layer = _layer(c, k, d, seed=nwg)
         x = _rand(3, c, L, seed=nwg + 1)
         _check(_run(x, layer, nwg=nwg), _reference(x, w, b, k, d), 1e-5)
 
 
-@pytest.mark.parametrize("c,k", [(128, 3), (128, 11), (256, 7)])
+@pytest.mark.parametrize("c,k", [(128, 3), (128, 11), (256, 7), (64, 3), (64, 11)])
 @pytest.mark.parametrize("L", [64, 200, 515])
 def test_split3_residual_form(c, k, L):
     """conv2 of a ResBlock pair (modules.py:301-306): the residual is the pair's input, stored activated; the output is
@@ -115,8 +115,9 @@ def test_split3_residual_form(c, k, L):
     _check(_run(t, layer, res_planes=raw, res_slope=1.0, scale=1.0 / 3.0), ref, 1e-5)
 
 
-def test_split3_three_products_is_the_16_bit_mode():
-    c, k, d = 128, 11, 1
+@pytest.mark.parametrize("c", [64, 128])
+def test_split3_three_products_is_the_16_bit_mode(c):
+    k, d = 11, 1
     w, b, layer = _layer(c, k, d)
     x = _rand(2, c, 400, seed=5)
     ref = _reference(x, w, b, k, d)
@@ -145,4 +146,4 @@ def test_split3_rejects_what_it_has_no_instance_for():
     with pytest.raises(OvError):
         launch_conv_split3(layer, x, out, products=4)
     with pytest.raises(OvError):
-        PackedConvSplit3(_rand(64, 64, 3), None, DEV)
+        PackedConvSplit3(_rand(32, 32, 3), None, DEV)

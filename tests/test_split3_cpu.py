@@ -57,14 +57,18 @@ def test_weight_packer_record_order(cout, cin, k):
     assert torch.equal(rec, want.contiguous())
     assert (dst[-512:] == 0).all()
     assert lib.ov_conv1d_split3_pack_size(100, 128, 3) == 0 and lib.ov_conv1d_split3_supported(128, 128, 11, 5) == 1
-    assert lib.ov_conv1d_split3_supported(64, 64, 3, 1) == 0 and lib.ov_conv1d_split3_supported(128, 128, 5, 1) == 0
+    assert lib.ov_conv1d_split3_supported(64, 64, 3, 1) == 1 and lib.ov_conv1d_split3_supported(128, 128, 5, 1) == 0
+    assert lib.ov_conv1d_split3_supported(32, 32, 3, 1) == 0 and lib.ov_conv1d_split3_supported(128, 256, 3, 1) == 0
 
 
-def _check_input_addresses(K, DIL, CIN, L, tile, c):
-    """conv1d_split3.h, input waves' dma_chunk() against the matrix waves' operand reads (xl_tap / oread)."""
+def _check_input_addresses(K, DIL, CIN, L, tile, c, COT=128):
+    """conv1d_split3.h, input waves' dma_chunk() against the matrix waves' operand reads (xl_tap / oread); COT = 64:
+    2 x 2 matrix waves, the upper pair starts at row trow0 = 64 with JW = 4 time fragments."""
     TT, P1 = 128, (K - 1) * DIL // 2
     NBLK = (TT + 2 * P1 + 15) // 16
     PGI = 2 * CIN
+    NCT = COT // 32
+    JW = 8 // (4 // NCT)
     lds = np.full(NBLK * 512, -2, dtype=np.int64)            # per bf16 element: global element id, -1 = zero record
     tbase = tile * TT - P1
     for blk in range(NBLK):
@@ -74,52 +78,68 @@ def _check_input_addresses(K, DIL, CIN, L, tile, c):
             t = tbase + blk * 16 + lrow
             d = (blk * 1024 + lane * 16) // 2
             lds[d:d + 8] = -1 if (t < 0 or t >= L) else ((tbase + blk * 16) * PGI + 64 * c + dof) // 2 + np.arange(8)
-    for tap in range(K):
-        for lane in range(64):
-            l15, g4 = lane & 15, lane >> 4
-            row = l15 + tap * DIL
-            base = row * 64 + 16 * (g4 ^ ((row >> 2) & 3))
-            for j in range(8):
-                t = tile * TT - P1 + 16 * j + l15 + tap * DIL
-                want = np.full(8, -1) if (t < 0 or t >= L) else t * CIN + 32 * c + 8 * g4 + np.arange(8)
-                a = (base + j * 1024) // 2
-                assert (lds[a:a + 8] == want).all(), (tap, lane, j)
-
-
-def _check_output_addresses(COUT, mb):
-    """conv1d_split3.h, the matrix waves' epilogue cells (ecell) against the output waves' fetch / store (odof)."""
-    OP, PGO = 256, 2 * COUT
-    for h in range(2):
-        lds = np.full(64 * OP // 2, -2, dtype=np.int64)
-        for wave in range(4):
+    for wave in range(4):
+        trow0 = (wave // NCT) * 16 * JW
+        for tap in range(K):
             for lane in range(64):
                 l15, g4 = lane & 15, lane >> 4
+                row = trow0 + l15 + tap * DIL
+                base = row * 64 + 16 * (g4 ^ ((row >> 2) & 3))
+                for j in range(JW):
+                    t = tile * TT - P1 + trow0 + 16 * j + l15 + tap * DIL
+                    want = np.full(8, -1) if (t < 0 or t >= L) else t * CIN + 32 * c + 8 * g4 + np.arange(8)
+                    a = (base + j * 1024) // 2
+                    assert (lds[a:a + 8] == want).all(), (wave, tap, lane, j)
+
+
+def _check_output_addresses(COUT, mb, COT=128):
+    """conv1d_split3.h, the matrix waves' epilogue cells (ecell) against the output waves' fetch / store (oblk, ophase,
+    odof) -- and thereby the input waves' residual DMA, which uses the same block / phase functions."""
+    NCT = COT // 32
+    JW = 8 // (4 // NCT)
+    NR, OP, PGO = (2 if COT == 128 else 1), 2 * COT, 2 * COUT
+    OROWS, RPBO, SPRO = 16384 // OP, 1024 // OP, OP // 16
+    NE = 2 if COT == 128 else 1
+    NQ = 8 // NE
+    covered = np.zeros((128, COT), dtype=np.int64)
+    for h in range(NR):
+        lds = np.full(16384 // 2, -2, dtype=np.int64)
+        for wave in range(4):
+            ct, trow0 = wave % NCT, (wave // NCT) * 16 * JW
+            erow0 = 0 if COT == 128 else trow0
+            for lane in range(64):
+                l15, g4 = lane & 15, lane >> 4
+                eswz = l15 if COT == 128 else (l15 >> 1) & 7
                 for f in range(2):
-                    ecell = l15 * OP + 16 * ((4 * wave + 2 * f + (g4 >> 1)) ^ l15) + 8 * (g4 & 1)
+                    ecell = (erow0 + l15) * OP + 16 * ((4 * ct + 2 * f + (g4 >> 1)) ^ eswz) + 8 * (g4 & 1)
                     for jj in range(4):
                         a = (ecell + jj * 16 * OP) // 2
                         assert (lds[a:a + 4] == -2).all()
-                        lds[a:a + 4] = (64 * h + 16 * jj + l15) * COUT + 128 * mb + 32 * wave + 16 * f + 4 * g4 + np.arange(4)
+                        trow = trow0 + 16 * (4 * h + jj) + l15          # acc[f][4 h + jj] of this wave
+                        lds[a:a + 4] = trow * COUT + COT * mb + 32 * ct + 16 * f + 4 * g4 + np.arange(4)
         assert (lds >= 0).all()
-        out = np.full(64 * COUT, -2, dtype=np.int64)
+        out = np.full(OROWS * COUT, -2, dtype=np.int64)
         for ow in range(2):
             for lane in range(64):
-                lrow4, sp16 = lane >> 4, lane & 15
-                for q in range(4):
-                    for e in range(2):
-                        blk = 4 * q + 2 * ow + e
-                        odof = lrow4 * PGO + 16 * (sp16 ^ (4 * (2 * ow + e) + lrow4))
-                        s, d = (blk * 1024 + lane * 16) // 2, (blk * 4 * PGO + OP * mb + odof) // 2
-                        out[d:d + 8] = lds[s:s + 8]
-        for r in range(64):
-            got = out[r * COUT + 128 * mb: r * COUT + 128 * mb + 128]
-            assert (got == (64 * h + r) * COUT + 128 * mb + np.arange(128)).all(), (h, r)
+                lrowo, spo = lane // SPRO, lane % SPRO
+                for q in range(NQ):
+                    for e in range(NE):
+                        blk = 4 * q + 2 * ow + e if COT == 128 else 2 * q + ow
+                        phase = 4 * (2 * ow + e) + lrowo if COT == 128 else 4 * ow + (lrowo >> 1)
+                        odof = lrowo * PGO + 16 * (spo ^ phase)
+                        s_, d = (blk * 1024 + lane * 16) // 2, (blk * RPBO * PGO + OP * mb + odof) // 2
+                        out[d:d + 8] = lds[s_:s_ + 8]
+        for r in range(OROWS):
+            got = out[r * COUT + COT * mb: r * COUT + COT * mb + COT]
+            assert (got == (OROWS * h + r) * COUT + COT * mb + np.arange(COT)).all(), (h, r)
+            covered[OROWS * h + r] += 1
+    assert (covered == 1).all()
 
 
 def test_kernel_lds_address_algebra():
     for K, D in [(11, 1), (11, 5), (3, 1), (7, 3)]:
-        for CIN in (128, 256):
+        for CIN, COT in ((128, 128), (256, 128), (64, 64)):
             for L, tile in [(1000, 0), (1000, 3), (1000, 7), (130, 1), (5, 0)]:
-                _check_input_addresses(K, D, CIN, L, tile, CIN // 32 - 1)
-    for COUT, mb in [(128, 0), (256, 0), (256, 1)]:
-        _check_output_addresses(COUT, mb)
+                _check_input_addresses(K, D, CIN, L, tile, CIN // 32 - 1, COT)
+    for COUT, mb, COT in [(128, 0, 128), (256, 0, 128), (256, 1, 128), (64, 0, 64)]:
+        _check_output_addresses(COUT, mb, COT)

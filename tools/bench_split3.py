@@ -6,7 +6,7 @@ d = 1, batch 32 x 55 104 columns -- against the fp32 MFMA conv on the same tenso
   (b) error: max-abs vs a float64 conv of the same fp32 operands, for both kernels, on the calibrated AND the gain-4
       stress weights; the gate is split <= 4 x fp32.
 
-Prints a table and one JSON line; --shapes adds the other (C, K, dilation) of stages 0 / 1.
+Prints a table and one JSON line; --shapes adds the other (C, K, dilation) of stages 0 / 1 / 2.
 reference: openvoice/modules.py:296-309."""
 import argparse
 import json
@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=861)
     ap.add_argument("--reps", type=int, default=10)
-    ap.add_argument("--shapes", action="store_true", help="every (K, dilation) of stages 0 and 1, not only the gate shape")
+    ap.add_argument("--shapes", action="store_true", help="every (K, dilation) of stages 0, 1 and 2, not only the gate shape")
     ap.add_argument("--products3", action="store_true", help="also the 3-product (16-bit operand) mode")
     ap.add_argument("--dbg", action="store_true", help="phase timers of the split kernel")
     ap.add_argument("--out", default=None)
@@ -132,10 +132,11 @@ def main():
     if args.shapes:
         shapes += [(128, k, d) for k in (3, 7, 11) for d in (1, 3, 5) if (k, d) != (11, 1)]
         shapes += [(256, k, d) for k in (3, 7, 11) for d in (1, 3, 5)]
+        shapes += [(64, k, d) for k in (3, 7, 11) for d in (1, 3, 5)]
     prods = (6, 3) if args.products3 else (6,)
     rows = []
     for C, K, d in shapes:
-        L = args.frames * (8 if C == 256 else 64)
+        L = args.frames * {256: 8, 128: 64, 64: 128}[C]
         row = one_shape(sds, C, K, d, args.batch, L, args.reps, dbg=args.dbg, products=prods)
         rows.append(row)
         c, s = row["calibrated"], row["stress_gain4"]
