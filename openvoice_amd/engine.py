@@ -746,12 +746,13 @@ class ConverterEngine:
         return self
 
     def use_split_bf16x3(self, enable=True, products=6):
-        """Run the MRF ResBlocks of every generator stage that has split-precision instances (C = 128 / 256 here: stages
-        0 and 1 of the released configuration, 60 % of a conversion's FLOPs) on ``ov_conv1d_split3``: every fp32 operand
+        """Run the MRF ResBlocks of every generator stage that has split-precision instances (C = 64 / 128 / 256: stages
+        0-2 of the released configuration, 80 % of a conversion's FLOPs) on ``ov_conv1d_split3``: every fp32 operand
         carried as three bf16 planes (lossless), every product as the six plane products of weight >= 2^-18 on the bf16
-        matrix pipe with fp32 accumulation -- fp32-level results (measured against float64 the error is BELOW the fp32
-        MFMA kernels', profiles/r05_s1_split3_gate.json) at 1.8x their speed.  ``products=3`` uses the hi / mid planes
-        only (16-bit operands, ~3e-5 relative).  Off by default: the contract path is the fp32 kernels
+        matrix pipe with fp32 accumulation -- fp32-level results (against float64 the error is BELOW the fp32 MFMA
+        kernels' on every shape, profiles/r05_s2_split3_table_all_shapes.txt) at 1.2-2.1x their speed: 106.4 instead of
+        139.8 ms per batch-32 conversion.  ``products=3`` uses the hi / mid planes only (16-bit operands, ~2e-5 per conv,
+        84.2 ms).  Off by default: the contract path is the fp32 kernels
         (reference: openvoice/modules.py:296-309, models.py:280-286)."""
         if products not in (6, 3):
             raise _lib.OvError(f"use_split_bf16x3: products must be 6 or 3, got {products!r}")
