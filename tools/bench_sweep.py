@@ -21,6 +21,9 @@ def main():
                     help="small batches only: the concurrent ResBlock chains (engine.chain_streams = 3) against the "
                          "serial one-stream order, same process, outputs compared bit for bit; also the captured-graph "
                          "replay of the concurrent order")
+    ap.add_argument("--split-ab", action="store_true",
+                    help="every batch size also with the opt-in split-precision MRF stages (engine.use_split_bf16x3, 6 and "
+                         "3 plane products); reports the two paths' waveforms' distance on a fixed noise tensor")
     ap.add_argument("--no-ragged", action="store_true")
     args = ap.parse_args()
     from bench import SAMPLE_RATE, synth_wave
@@ -79,6 +82,19 @@ def main():
             dtg = timeit(lambda: fixed(graph=True))
             rows[-1].update(ms_serial_order=round(dt1 * 1e3, 3), ms_graph_replay=round(dtg * 1e3, 3),
                             bit_identical_to_serial=bool(torch.equal(o3, o1)), graph_bit_identical=bool(torch.equal(og, o1)))
+        if args.split_ab:
+            spec = spectrogram_torch(wave, d.filter_length, d.sampling_rate, d.hop_length, d.win_length, center=False)
+            lengths = torch.full((B,), spec.shape[2], dtype=torch.int64, device=dev)
+            noise = torch.randn(B, 192, spec.shape[2], generator=torch.Generator().manual_seed(B)).to(dev)
+            fixed = lambda: model.voice_conversion(spec, lengths, se[0], se[1], tau=0.3, noise=noise)[0]
+            o32 = fixed().clone()
+            for products in (6, 3):
+                eng.use_split_bf16x3(True, products=products)
+                dts = timeit(step)
+                diff = (fixed() - o32).abs().max().item()
+                rows[-1][f"ms_split{products}"] = round(dts * 1e3, 3)
+                rows[-1][f"split{products}_vs_fp32_max_abs"] = diff
+            eng.use_split_bf16x3(False)
         print(json.dumps(rows[-1]), flush=True)
     if args.no_ragged:
         return
