@@ -72,6 +72,26 @@ def pmc_traffic(batch, frames, fuse_pairs, pair_policy, launches_per_step, chain
         return None, "no PMC record committed"
 
 
+def bf16_counter_record(batch, frames):
+    """The committed rocprofv3 counter record of the opt-in bf16 generator (tools/bf16_counters.py ->
+    profiles/bf16_counters_latest.json): HBM traffic per pass, matrix-busy fraction, shader clock.  Returned only when
+    it was taken on the running tree's bf16 kernel sources at this batch / frame count."""
+    from openvoice_amd.hostinfo import bf16_source_digest
+    path = os.path.join(REPO, "profiles", "bf16_counters_latest.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)
+    except (OSError, ValueError):
+        return None, "no bf16 counter record committed (algorithmic bytes reported)"
+    if rec.get("bf16_source_digest") != bf16_source_digest():
+        return None, (f"profiles/bf16_counters_latest.json was measured on bf16 sources {rec.get('bf16_source_digest')}, this "
+                      f"tree is {bf16_source_digest()} (algorithmic bytes reported)")
+    if (rec.get("batch"), rec.get("frames")) != (batch, frames):
+        return None, (f"profiles/bf16_counters_latest.json is for batch {rec.get('batch')} x {rec.get('frames')} frames, this run "
+                      f"is {batch} x {frames} (algorithmic bytes reported)")
+    return rec, "rocprofv3 PMC passes, profiles/bf16_counters_latest.json (FETCH_SIZE x 2 + WRITE_SIZE, calibrated)"
+
+
 SAMPLE_RATE = 22050
 
 
@@ -634,9 +654,22 @@ def main():
                                "layout_kernels_ms": round(by_tag.get("split_layout", [0, 0, 0.0])[2] * 1e3, 3)}
             out["note"] = "opt-in configuration (--split-bf16x3), not the contract line"
         if args.bf16_generator:
-            out["roofline"] = {"bound": "hbm", "achieved": round(gen_bytes / t_mrf / 1e9, 1), "peak": 8000.0,
-                               "unit": "GB/s", "frac": round(gen_bytes / t_mrf / 8e12, 4), "traffic": None,
-                               "kernel": "ovk16::conv1d_bf16cl_kernel (whole bf16 generator, algorithmic bytes)",
+            # this configuration is judged against BOTH roofs -- HBM bytes (PMC-measured where a
+            # counter record of THESE kernel sources at this shape is committed, algorithmic otherwise) / 6.3 and 8.0
+            # TB/s, and the generator's FLOPs / the dense bf16 MFMA peak
+            gen_flops = 529.44e9 * B * frames / 861.0
+            rec, rec_note = bf16_counter_record(B, frames)
+            traffic_b = rec["traffic_GB_per_pass"] * 1e9 if rec else None
+            out["roofline"] = {"bound": "hbm", "achieved": round((traffic_b or gen_bytes) / t_mrf / 1e9, 1), "peak": 8000.0,
+                               "unit": "GB/s", "frac": round((traffic_b or gen_bytes) / t_mrf / 8e12, 4),
+                               "frac_of_achievable_6300": round((traffic_b or gen_bytes) / t_mrf / 6.3e12, 4),
+                               "traffic": traffic_b, "traffic_source": rec_note,
+                               "alg_bytes": round(gen_bytes), "alg_GBps": round(gen_bytes / t_mrf / 1e9, 1),
+                               "mfma": {"achieved_tflops": round(gen_flops / t_mrf / 1e12, 1), "peak_tflops": BF16_MFMA_PEAK_TFLOPS,
+                                        "frac": round(gen_flops / t_mrf / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+                                        "mfma_busy": rec.get("mfma_busy") if rec else None,
+                                        "shader_clock_ghz": rec.get("shader_clock_ghz") if rec else None},
+                               "kernel": "ovk16q::respair2_bf16_kernel + ovk16::conv1d_bf16cl_kernel (whole bf16 generator)",
                                "generator_ms": round(t_mrf * 1e3, 3)}
             out["note"] = "opt-in configuration (--bf16-generator), not the contract line"
         rc = 0

@@ -50,8 +50,9 @@ def kernel_source_digest():
     here = os.path.dirname(os.path.abspath(__file__))
     files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h")) +
                    glob.glob(os.path.join(here, "..", "include", "*.h")) + [os.path.join(here, "engine.py")])
-    # the opt-in bf16 generator's kernels (conv1d_bf16*.hip / .h) launch nothing on the fp32 path the record is about
-    files = [f for f in files if not os.path.basename(f).startswith("conv1d_bf16")]
+    # the opt-in paths' kernels (bf16 generator: conv1d_bf16*; split-precision MRF: conv1d_split3*) launch nothing on
+    # the fp32 path the record is about
+    files = [f for f in files if not os.path.basename(f).startswith(("conv1d_bf16", "conv1d_split3"))]
     h = hashlib.sha256()
     for f in files:
         h.update(os.path.basename(f).encode())
@@ -69,3 +70,18 @@ def launch_config_digest(batch, frames, fuse_pairs, pair_policy, chain_streams=1
     policy = sorted(f"{c}x{k}" for c, k in pair_policy) if fuse_pairs else []
     text = f"{kernel_source_digest()}|B={int(batch)}|T={int(frames)}|fuse={int(bool(fuse_pairs))}|{','.join(policy)}|cs={int(chain_streams)}"
     return hashlib.sha256(text.encode()).hexdigest()[:16]
+
+
+def bf16_source_digest():
+    """sha256 (16 hex digits) over what decides the opt-in bf16 generator's launches: its kernels and bf16.py.  The
+    counter record profiles/bf16_counters_latest.json carries it (tools/bf16_counters.py)."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "csrc", "conv1d_bf16*")) + [os.path.join(here, "bf16.py")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

@@ -106,6 +106,10 @@ def main():
                    "half of its wave-cycles are waits even when its four matrix waves never stall; mfma_busy is per SIMD "
                    "and is not affected")
     out["by_kernel"] = busy
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from openvoice_amd.hostinfo import bf16_source_digest
+    out["bf16_source_digest"] = bf16_source_digest()      # bench.py --bf16-generator reports the record only on a match
+    out["batch"], out["frames"] = 64, 861                  # tools/bench_decoder_bf16.py defaults (BASELINE.json configs[4])
     json.dump(out, sys.stdout, indent=1)
     print()
 
