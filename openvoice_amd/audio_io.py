@@ -4,10 +4,12 @@ The reference delegates both to third-party packages that are not part of its tr
 ``librosa.load(path, sr=hps.data.sampling_rate)`` (reference: openvoice/api.py:123,144) and
 ``soundfile.write`` (openvoice/api.py:98,160).  When those packages are importable they are used,
 so behaviour is then the reference's by construction.  When they are absent (this image), a small
-RIFF/WAVE reader + polyphase resampler stands in: PCM 8/16/24/32-bit and IEEE float32/64 WAV,
-channel mean for mono, ``scipy.signal.resample_poly`` for rate conversion.  Parity of this
-stand-in with librosa's ``soxr_hq``/``kaiser_best`` resampler is NOT pinned (SURVEY.md section 8c
-item (i)): the parity boundary of this repo starts at the float32 waveform at the model rate.
+RIFF/WAVE reader + a restatement of resampy's published ``kaiser_best`` windowed-sinc resampler (what
+librosa 0.9.1's ``load(sr=...)`` applies) stand in: PCM 8/16/24/32-bit and IEEE float32/64 WAV, channel
+mean for mono (``librosa.to_mono``), ``resample_kaiser_best`` for rate conversion.  Parity of the resampler
+with resampy's own output is NOT pinned (neither package is in this image): it
+follows the published algorithm and filter constants and is tested against closed-form band-limited
+interpolation; the parity boundary of this repo starts at the float32 waveform at the model rate.
 Compressed formats (mp3 ...) need librosa/audioread and raise a clear error without them.
 """
 import struct
@@ -58,9 +60,88 @@ def _read_wav(path):
     return x, rate
 
 
-def resample(x, sr_in, sr_out):
+# resampy's published ``kaiser_best`` filter (librosa 0.9.1's default ``res_type``, reference call sites
+# openvoice/api.py:123,144 through ``librosa.load(path, sr=...)``): a Kaiser-windowed sinc with 64 zero crossings,
+# 2^9 table samples per crossing, these two constants
+KAISER_BEST = dict(num_zeros=64, precision=9, rolloff=0.9475937167399596, beta=14.769656459379492)
+_kaiser_best_window = None
+
+
+def _sinc_window(num_zeros, precision, rolloff, beta):
+    """Right half of the interpolation filter, ``num_zeros * 2^precision + 1`` samples (resampy.filters.sinc_window):
+    ``rolloff * sinc(rolloff * t)`` for t in [0, num_zeros], tapered by the right half of a Kaiser(beta) window."""
+    n = (1 << precision) * num_zeros
+    t = np.linspace(0.0, num_zeros, num=n + 1, endpoint=True)
+    taper = np.kaiser(2 * n + 1, beta)[n:]
+    return taper * (rolloff * np.sinc(rolloff * t))
+
+
+def resample_kaiser_best(x, sr_in, sr_out):
+    """Band-limited sinc interpolation, a restatement of resampy's published algorithm (Smith's "Digital Audio
+    Resampling", resampy.interpn.resample_f) with its ``kaiser_best`` filter: output sample t sits at input time
+    ``t * sr_in / sr_out`` = n + frac; the filter table is read at steps of ``int(scale * 2^precision)`` entries
+    (``scale = min(1, sr_out / sr_in)``: the cutoff follows the lower rate) from offset ``scale * frac * 2^precision`` with
+    linear interpolation between entries -- left wing over x[n], x[n-1], ..., right wing (offset from ``scale * (1 -
+    frac)``) over x[n+1], ... -- and the table is scaled by ``scale`` when downsampling.  Evaluated phase by phase:
+    with integer rates the fractional position takes ``sr_out / gcd`` values, each one fixed set of weights applied to
+    a strided window view of x (one matrix-vector product per phase) instead of resampy's per-sample loops; the weights
+    are the algorithm's, the summation order is BLAS's.  Output length ``ceil(len * ratio)`` as
+    ``librosa.resample(fix=True)`` returns it.
+    PARITY UNPINNED: neither resampy nor librosa is in this image, so agreement with their output is by construction of
+    the published algorithm only (tests: closed-form band-limited interpolation of sinusoids, stop-band rejection)."""
+    global _kaiser_best_window
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    if int(sr_in) == int(sr_out) or x.size == 0:
+        return x.astype(np.float32)
+    if _kaiser_best_window is None:
+        _kaiser_best_window = _sinc_window(**KAISER_BEST)
+    g = gcd(int(sr_in), int(sr_out))
+    P, Q = int(sr_out) // g, int(sr_in) // g                  # input time of output t = t * Q / P
+    ratio = P / Q
+    scale = min(1.0, ratio)
+    num_table = 1 << KAISER_BEST["precision"]
+    win = _kaiser_best_window * scale if ratio < 1.0 else _kaiser_best_window
+    delta = np.zeros_like(win)
+    delta[:-1] = np.diff(win)
+    nwin, n_orig = win.shape[0], x.shape[0]
+    index_step = int(scale * num_table)
+    n_out = int(np.ceil(n_orig * ratio))
+    taps = (nwin - 1) // index_step + 1                       # an upper bound of either wing's length
+    k = np.arange(taps)
+    xpad = np.concatenate([np.zeros(taps), x, np.zeros(taps + Q + 1)])   # x[i] = xpad[i + taps]
+    y = np.zeros(n_out, dtype=np.float64)
+    for r in range(min(P, n_out)):
+        n0, rem = divmod(r * Q, P)                            # outputs t = r + P m sit at n0 + m Q + rem / P
+        m = (n_out - 1 - r) // P + 1
+        h = np.zeros(2 * taps)                                # weights of x[n - taps + 1 ... n + taps]
+        for wing, f in ((0, scale * rem / P), (1, scale - scale * rem / P)):
+            index_frac = f * num_table
+            offset = int(index_frac)
+            eta = index_frac - offset
+            idx = offset + k * index_step
+            ok = idx < nwin
+            w = np.where(ok, win[np.minimum(idx, nwin - 1)] + eta * delta[np.minimum(idx, nwin - 1)], 0.0)
+            if wing == 0:
+                h[taps - 1 - k] = w                           # x[n - k]
+            else:
+                h[taps + k] = w                               # x[n + k + 1]
+        first = n0 + 1                                        # xpad index of x[n0 - taps + 1]
+        view = np.lib.stride_tricks.as_strided(xpad[first:], shape=(m, 2 * taps), strides=(Q * xpad.strides[0], xpad.strides[0]),
+                                               writeable=False)
+        y[r::P] = view @ h
+    return y.astype(np.float32)
+
+
+def resample(x, sr_in, sr_out, res_type="kaiser_best"):
+    """Rate conversion of a mono waveform.  ``kaiser_best`` (default): the restatement above of what
+    ``librosa.load(path, sr=...)`` applies in the reference (librosa 0.9.1 -> resampy ``kaiser_best``); ``polyphase``:
+    ``scipy.signal.resample_poly`` (round 1-4's stand-in, kept for comparison)."""
     if sr_in == sr_out:
         return x
+    if res_type == "kaiser_best":
+        return resample_kaiser_best(x, sr_in, sr_out)
+    if res_type != "polyphase":
+        raise ValueError(f"unknown res_type {res_type!r}")
     from scipy.signal import resample_poly
     g = gcd(int(sr_in), int(sr_out))
     return resample_poly(x.astype(np.float64), int(sr_out) // g, int(sr_in) // g).astype(np.float32)

@@ -117,6 +117,9 @@ struct Geo {
 
 template <int K, int DIL, int CIN, int COT, bool RES, int NPROD>
 __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(const ov_conv1d_split3_params p) {
+#ifdef OV_HOST_ONLY_KERNELS   // `make sanitize`: ASan / UBSan instrument the HOST side only; the unrolled device body (minutes
+  (void)p;                    // of compile time per translation unit) is not what that build tests
+#else
   using G = Geo<K, DIL, CIN, COT, RES>;
   constexpr int NCH = G::NCH, P1 = G::P1, R1 = G::R1, NBLK = G::NBLK, XPL = G::XPL, XB = G::XB, NOH = G::NOH;
   constexpr int NCT = G::NCT, JW = G::JW, NR = G::NR, OP = G::OP, OROWS = G::OROWS, RPBO = G::RPBO;
@@ -500,6 +503,7 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
 #pragma unroll
     for (int q = 0; q < 8; ++q) p.dbg[((size_t)blockIdx.x * NMW + wave) * 8 + q] = tph[q];
   }
+#endif
 }
 
 inline int cu_count(std::atomic<int>* cache) {

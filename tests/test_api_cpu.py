@@ -179,3 +179,49 @@ def test_cleaned_symbol_text_needs_no_front_end():
     hps = utils.HParams(symbols=list("_abc"), data=dict(text_cleaners=["x"], add_blank=True))
     assert api.BaseSpeakerTTS.get_text("a?cb", hps, True).tolist() == [0, 1, 0, 3, 0, 2, 0]
     assert utils.cleaned_text_to_sequence("cab!", list("_abc")) == [3, 1, 2]
+
+
+def test_kaiser_best_resampler_is_band_limited_interpolation():
+    """``audio_io.resample_kaiser_best``: the restatement of resampy's published ``kaiser_best`` windowed-sinc resampler
+    (what ``librosa.load(path, sr=...)`` applies at the reference's call sites openvoice/api.py:123,144).  Parity with
+    resampy itself is UNPINNED (not in this image); checked against what the algorithm must do by construction: a
+    sinusoid below the cutoff is reproduced at the new rate (exactly-to-1e-7 where the table step is an integer,
+    within the algorithm's own step-truncation gain error elsewhere), one above the new Nyquist is rejected, the output
+    length is librosa's ``ceil(n * ratio)``, and the polyphase evaluation equals the per-sample definition."""
+    for sr_in, sr_out, bar in [(44100, 22050, 1e-6), (16000, 22050, 1e-6), (48000, 22050, 1e-3), (22050, 16000, 1e-3)]:
+        t = np.arange(sr_in // 2) / sr_in
+        x = 0.8 * np.sin(2 * np.pi * 997.0 * t + 0.3)
+        y = audio_io.resample_kaiser_best(x, sr_in, sr_out)
+        assert y.dtype == np.float32 and len(y) == int(np.ceil(len(x) * sr_out / sr_in))
+        ref = 0.8 * np.sin(2 * np.pi * 997.0 * np.arange(len(y)) / sr_out + 0.3)
+        edge = int(0.05 * sr_out)
+        assert np.abs(y[edge:-edge] - ref[edge:-edge]).max() <= bar, (sr_in, sr_out)
+        if sr_out < sr_in:                                   # a tone 15 % above the new Nyquist must not alias back
+            xs = np.sin(2 * np.pi * 0.575 * sr_out * t)
+            assert np.abs(audio_io.resample_kaiser_best(xs, sr_in, sr_out)[edge:-edge]).max() <= 1e-3
+    # the definition, sample by sample (resampy.interpn.resample_f), on a short random signal
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(700)
+    sr_in, sr_out = 48000, 22050
+    got = audio_io.resample_kaiser_best(x, sr_in, sr_out).astype(np.float64)
+    win = audio_io._sinc_window(**audio_io.KAISER_BEST)
+    ratio = sr_out / sr_in
+    scale, num_table = min(1.0, ratio), 1 << audio_io.KAISER_BEST["precision"]
+    win = win * scale
+    delta = np.append(np.diff(win), 0.0)
+    step, want = int(scale * num_table), np.zeros(len(got))
+    for t in range(len(got)):
+        time = t * 320 / 147                                  # sr_in / sr_out, exactly
+        n = int(time)
+        for wing, frac in ((0, scale * (time - n)), (1, scale - scale * (time - n))):
+            off, eta = int(frac * num_table), frac * num_table - int(frac * num_table)
+            i = 0
+            while off + i * step < len(win):
+                src = n - i if wing == 0 else n + i + 1
+                if 0 <= src < len(x):
+                    want[t] += (win[off + i * step] + eta * delta[off + i * step]) * x[src]
+                i += 1
+    assert np.abs(got - want).max() <= 2e-6                   # float32 output rounding
+    assert audio_io.resample(x, 22050, 22050) is x
+    with pytest.raises(ValueError):
+        audio_io.resample(x, 48000, 22050, "sinc_fastest")
