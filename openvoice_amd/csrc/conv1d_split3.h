@@ -106,7 +106,11 @@ struct Geo {
   static constexpr int XPL = NBLK * 1024;            // bytes per plane of a chunk buffer
   static constexpr int XB = 3 * XPL;                 // bytes per chunk buffer
   static constexpr int NOH = RES ? NR : 1;           // round buffers (with a residual every round is resident)
-  static constexpr int OOFF = 2 * XB;
+  // Chunk buffers: a ring of three where LDS allows (chunks are requested TWO ahead: an LDS-DMA round trip under load is
+  // several microseconds, longer than the k-loop of one chunk at C = 64 -- its matrix pipes were 0.43-0.51 busy at 2.2 GHz
+  // with a ring of two, profiles/r05_s4_pmc_mfma_busy_split_path.txt), else two (the C = 128 residual form)
+  static constexpr int NBUF = 3 * XB + NOH * OH + COT * 4 <= 160 * 1024 ? 3 : 2;
+  static constexpr int OOFF = NBUF * XB;
   static constexpr int BOFF = OOFF + NOH * OH;
   static constexpr int SMEM = BOFF + COT * 4;
   static constexpr int NPAIR = NCH * K;              // (chunk, tap) pairs of one step = 6 weight records each
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
 #else
   using G = Geo<K, DIL, CIN, COT, RES>;
   constexpr int NCH = G::NCH, P1 = G::P1, R1 = G::R1, NBLK = G::NBLK, XPL = G::XPL, XB = G::XB, NOH = G::NOH;
-  constexpr int NCT = G::NCT, JW = G::JW, NR = G::NR, OP = G::OP, OROWS = G::OROWS, RPBO = G::RPBO;
+  constexpr int NCT = G::NCT, JW = G::JW, NR = G::NR, OP = G::OP, OROWS = G::OROWS, RPBO = G::RPBO, NBUF = G::NBUF;
   constexpr int NPL = NPROD == 6 ? 3 : 2;            // planes the k-loop reads (3 products: hi*hi + hi*mid + mid*hi)
   static_assert(NPROD == 6 || NPROD == 3, "6 (fp32-level) or 3 (16-bit operands) plane products");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[G::SMEM];
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
 
   if (wave >= NMW && wave < NMW + NIN) {
     // ================================ input waves ================================================
-    // Chunk n (global count over this workgroup's steps) lives in buffer n & 1.  After barrier A(n) -- chunk n landed,
+    // Chunk n (global count over this workgroup's steps) lives in buffer n % NBUF.  After barrier A(n) -- chunk n landed,
     // and every matrix wave is past the k-loop of chunk n - 1 -- the DMA of chunk n + 1 goes into the other buffer.
     // Block (plane, blk) = rows [16 blk, 16 blk + 16) of one plane: lane -> (row lrow = lane / 4, physical 16-byte slot
     // sp = lane % 4), which holds logical slot sp ^ g(row), g(row) = (row >> 2) & 3 = (lrow >> 2) & 3.
@@ -215,26 +219,41 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
           }
       }
     };
-    long s = g0;
-    Step cur(s, ntiles, nmb);
-    dma_chunk(0, cur, 0);
-    __builtin_amdgcn_s_barrier();                            // (init: biases in LDS)
-    int n = 0;
-    for (; s < g1; ++s) {
-      const Step nxt(s + 1 < g1 ? s + 1 : s, ntiles, nmb);
-#pragma unroll
-      for (int c = 0; c < NCH; ++c, ++n) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunk n (and, at c = 1, the residual tile) has landed
-        __builtin_amdgcn_s_barrier();                          // A(s, c)
-        if (c + 1 < NCH) dma_chunk((n + 1) & 1, cur, c + 1);
-        else if (s + 1 < g1) dma_chunk((n + 1) & 1, nxt, 0);
-        // the output buffers are free from A(s, 0) on: the output waves fetched step s - 1's last half before it
-        if (c == 0) dma_residual(cur);
+    // Chunk n = (step g0 + n / NCH, channel chunk n % NCH).  Ring of NBUF buffers: chunks n + 1 ... n + NBUF - 2 are in
+    // flight while chunk n is consumed, chunk n + NBUF - 1 is requested after barrier A(n) into the buffer chunk n - 1
+    // occupied (every matrix wave is past its k-loop by then).  LDS-DMA loads complete in issue order, so "chunk n has
+    // landed" = at most the DMA instructions of the younger chunks outstanding: s_waitcnt vmcnt(DPC) for a ring of
+    // three (DPC = this wave's DMA instructions per chunk, a compile-time count), vmcnt(0) for a ring of two and at the
+    // tail.  The residual tile of a step is requested at its chunk 0 BEFORE that iteration's chunk request, so the wait
+    // in front of the step's last chunk barrier covers it (the epilogue follows that chunk's k-loop).
+    constexpr int DPC0 = NPL * ((NBLK + NIN - 1) / NIN), DPC1 = NPL * (NBLK / NIN);   // input wave 0 / 1 (NIN = 2)
+    static_assert(NIN == 2 && DPC0 < 48, "vmcnt immediates");
+    const long total = (g1 - g0) * NCH;
+    auto request = [&](long n) {
+      if (n < total) {
+        const Step st(g0 + n / NCH, ntiles, nmb);
+        dma_chunk((int)(n % NBUF), st, (int)(n % NCH));
       }
-      __builtin_amdgcn_s_barrier();                            // E0
-      __builtin_amdgcn_s_barrier();                            // E1
-      __builtin_amdgcn_s_barrier();                            // E2
-      cur = nxt;
+    };
+    for (int q = 0; q < NBUF - 1; ++q) request(q);
+    __builtin_amdgcn_s_barrier();                            // (init: biases in LDS)
+    for (long n = 0; n < total; ++n) {
+      const int c = (int)(n % NCH);
+      if (NBUF == 3 && n + 1 < total) {
+        if (iw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPC0) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPC1) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();                          // A(n): chunk n (and, from c = 1 on, the residual tile) landed
+      // the output buffers are free from A(s, 0) on: the output waves fetched step s - 1's last round before it
+      if (c == 0) dma_residual(Step(g0 + n / NCH, ntiles, nmb));
+      request(n + NBUF - 1);
+      if (c == NCH - 1) {
+        __builtin_amdgcn_s_barrier();                          // E0
+        __builtin_amdgcn_s_barrier();                          // E1
+        __builtin_amdgcn_s_barrier();                          // E2
+      }
     }
     return;
   }
@@ -379,8 +398,8 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
             for (int j = 0; j < JW; ++j) acc[f][j] = v;
           }
         }
-        const uint32_t bufoff = (uint32_t)((n & 1) * XB);
-        ++n;
+        const uint32_t bufoff = (uint32_t)(n * XB);
+        n = n + 1 == NBUF ? 0 : n + 1;
         uint32_t xlb[K];
 #pragma unroll
         for (int tap = 0; tap < K; ++tap) {
