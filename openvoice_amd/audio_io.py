@@ -10,7 +10,9 @@ mean for mono (``librosa.to_mono``), ``resample_kaiser_best`` for rate conversio
 with resampy's own output is NOT pinned (neither package is in this image): it
 follows the published algorithm and filter constants and is tested against closed-form band-limited
 interpolation; the parity boundary of this repo starts at the float32 waveform at the model rate.
-Compressed formats (mp3 ...) need librosa/audioread and raise a clear error without them.
+MP3 (MPEG-1 Layer III: what resources/*.mp3 are) is decoded by ``openvoice_amd.mp3``, a decoder written from the
+standard's decoding process and PINNED against FFmpeg's output (Chromium's build of it: oracle/make_mp3_golden.py,
+tests/test_mp3_cpu.py: identical sample counts, max-abs 5e-5 = 1.5 LSB of 16-bit PCM on the reference's four files).
 """
 import struct
 from math import gcd
@@ -147,15 +149,32 @@ def resample(x, sr_in, sr_out, res_type="kaiser_best"):
     return resample_poly(x.astype(np.float64), int(sr_out) // g, int(sr_in) // g).astype(np.float32)
 
 
+def read_native(path):
+    """``(float32 [samples, channels], file rate)`` of a WAV or MPEG-1 Layer III file, no resampling."""
+    with open(path, "rb") as fh:
+        head = fh.read(12)
+    if head[:4] == b"RIFF" and head[8:12] == b"WAVE":
+        return _read_wav(path)
+    from . import mp3
+    with open(path, "rb") as fh:
+        pcm, rate = mp3.decode(fh.read())
+    return pcm.T, rate
+
+
 def load(path, sr):
-    """``(mono float32 waveform at ``sr``, sr)`` -- the contract of ``librosa.load(path, sr=sr)``."""
+    """``(mono float32 waveform at ``sr``, sr)`` -- the contract of ``librosa.load(path, sr=sr)``; ``sr=None`` keeps the
+    file's own rate."""
     try:
         import librosa  # noqa: F401  (third-party; used when present so decoding equals the reference's)
         return librosa.load(path, sr=sr)
     except ImportError:
         pass
-    x, rate = _read_wav(path)
+    # RIFF/WAVE natively; anything else is tried as MPEG-1 Layer III (resources/*.mp3 of the reference, BASELINE.json
+    # configs[0]) with the from-scratch decoder of openvoice_amd/mp3.py, pinned against FFmpeg's output
+    x, rate = read_native(path)
     mono = x.mean(axis=1) if x.shape[1] > 1 else x[:, 0]
+    if sr is None:
+        return np.ascontiguousarray(mono, dtype=np.float32), rate
     return np.ascontiguousarray(resample(mono, rate, sr), dtype=np.float32), sr
 
 

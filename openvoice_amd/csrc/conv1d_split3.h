@@ -251,8 +251,10 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
       request(n + NBUF - 1);
       if (c == NCH - 1) {
         __builtin_amdgcn_s_barrier();                          // E0
-        __builtin_amdgcn_s_barrier();                          // E1
-        __builtin_amdgcn_s_barrier();                          // E2
+        if constexpr (NR == 2) {
+          __builtin_amdgcn_s_barrier();                        // E1
+          __builtin_amdgcn_s_barrier();                        // E2
+        }
       }
     }
     return;
@@ -307,10 +309,10 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
       __builtin_amdgcn_s_barrier();                            // E0: round 0 is complete in its buffer
       fetch(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (read before E1 / A(s + 1, 0) lets anything overwrite it)
-      __builtin_amdgcn_s_barrier();                            // E1: buffer 0 may be overwritten (NOH = 1: by round 1)
+      if constexpr (NR == 2) __builtin_amdgcn_s_barrier();     // E1: buffer 0 may be overwritten (NOH = 1: by round 1)
       store(st, 0);
-      __builtin_amdgcn_s_barrier();                            // E2: round 1 is complete
       if constexpr (NR == 2) {
+        __builtin_amdgcn_s_barrier();                          // E2: round 1 is complete
         fetch(NOH - 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         store(st, 1);
@@ -425,15 +427,19 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
             if (it + 1 == NCH / 2) wp = wall + (size_t)(NCT * nx.mb + ct) * G::NPAIR * 6 * 64;
           }
           constexpr int JB = JW / 2;                  // blocks per pair
-          constexpr int SPB = NPROD == 6 ? 4 : 2;     // weight-request gaps per block (after MFMAs 8, 10, 12, 14)
+          constexpr int MPB = 4 * NPROD;              // MFMAs per block
+          constexpr int RQ0 = 2 * NPL + (NPROD == 6 ? 2 : 0);   // first weight-request gap (after the operand reads), then every 2nd
           static_for<0, JB>([&](auto jc) {
             constexpr int jh = decltype(jc)::value, blk = JB * tap + jh, cb = blk & 1, nb = cb ^ 1;
             constexpr bool more = blk + 1 < JB * K;   // the first block of the next chunk is read after its barrier
             constexpr int ntap = (blk + 1) / JB, njh = (blk + 1) % JB;
-            // products (weight plane, x plane), smallest first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
-            constexpr int WPL[6] = {2, 0, 1, 1, 0, 0}, XPLN[6] = {0, 2, 1, 0, 1, 0};
-            constexpr int P0 = NPROD == 6 ? 0 : 3;
-            static_for<P0, 6>([&](auto pc) {
+            // products (weight plane, x plane), ordered by WEIGHT plane -- hi*lo, hi*mid, hi*hi, mid*hi, mid*mid, lo*hi -- so
+            // that the records requested first (hi) are the ones needed first and the lo records have 20 more MFMAs to
+            // arrive: at C = 64 a pair is only 48 MFMAs (770 cycles) and the k-loops ran at 0.61 of their MFMA issue time
+            // waiting for weights (profiles/r05_s5_split3_table_3_deep_chunk_ring.txt); 3 products: hi*mid, hi*hi, mid*hi
+            constexpr int WPL[6] = {0, 0, 0, 1, 1, 2}, XPLN[6] = {2, 1, 0, 0, 1, 0};
+            constexpr int P0 = NPROD == 6 ? 0 : 1;
+            static_for<P0, P0 + NPROD>([&](auto pc) {
               constexpr int pr = decltype(pc)::value;
               static_for<0, 4>([&](auto ac) {
                 constexpr int a = decltype(ac)::value, jj = a >> 1, f = a & 1, m = (pr - P0) * 4 + a;   // m-th MFMA of the block
@@ -445,9 +451,9 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (m < 2 * NPL) {
                   if constexpr (more) xq[nb][m >> 1][m & 1] = oread(xlb[ntap < K ? ntap : 0], m >> 1, 2 * njh + (m & 1));
-                } else if constexpr (m >= 8 && m % 2 == 0 && (m - 8) / 2 < SPB && jh * SPB + (m - 8) / 2 < 6) {
-                  wrequest(par ^ 1, jh * SPB + (m - 8) / 2);
-                } else if constexpr (m == 11 && jh == JB - 1) {
+                } else if constexpr (jh == 0 && m >= RQ0 && (m - RQ0) % 2 == 0 && (m - RQ0) / 2 < 2 * NPL) {
+                  wrequest(par ^ 1, (m - RQ0) / 2);   // all of the next pair's records in the first block: earliest possible
+                } else if constexpr (m == MPB - 1 && jh == JB - 1) {
                   wp += 6 * 64;
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -509,12 +515,15 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
     };
     half(std::integral_constant<int, 0>{});
     mark(2);
-    __syncthreads();                                  // E0: half 0 is in its buffer
-    __syncthreads();                                  // E1: the output waves hold it in registers
-    mark(3);
-    if constexpr (NR == 2) half(std::integral_constant<int, 1>{});
-    mark(2);
-    __syncthreads();                                  // E2: half 1 is in its buffer
+    __syncthreads();                                  // E0: round 0 is in its buffer
+    if constexpr (NR == 2) {
+      __syncthreads();                                // E1: the output waves hold it in registers
+      mark(3);
+      half(std::integral_constant<int, 1>{});
+      mark(2);
+      __syncthreads();                                // E2: round 1 is in its buffer
+    }
+    // (one round: the output waves fetch it before they arrive at A(s + 1, 0), and nothing writes the buffer before that)
     mark(3);
   }
   if (dbg && lane == 0) {

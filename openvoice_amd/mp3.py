@@ -1,0 +1,476 @@
+"""MPEG-1 Audio Layer III decoder, written from the standard's decoding process (ISO/IEC 11172-3, 2.4.3.4): the decode half
+of ``librosa.load(path)`` for the reference's MP3 inputs (reference call sites: openvoice/api.py:123,144;
+BASELINE.json configs[0] names resources/example_reference.mp3).  Pure numpy, host side only -- file decoding is not on the
+hot path (it happens once per utterance, before the waveform reaches the GPU).
+
+    pcm, rate = decode(open(path, "rb").read())        # float32 [channels, samples], the file's own sampling rate
+
+Scope: MPEG-1 Layer III (32 / 44.1 / 48 kHz), mono / stereo / joint stereo with MS coding, long / short / mixed blocks,
+bit reservoir, CRC-protected frames (the CRC is skipped, not checked), ID3v2 tags, the Xing / Info header frame with LAME's
+gapless fields (encoder delay and padding are trimmed the way FFmpeg trims them).  NOT built: MPEG-2 / 2.5 (LSF) frames
+and intensity stereo -- both raise ``Mp3Error`` naming the feature (none of the reference's resources uses them).
+
+Tables: the standard's Huffman code tables (Annex B, Table B.7), synthesis window (Table B.3) and scalefactor-band
+partitions (Table B.8) are normative data that no formula produces; ``mp3_tables.npz`` holds them, read out of the image's
+bundled Chromium / FFmpeg build and validated structurally by tools/extract_mp3_tables.py.  Everything else -- IMDCT and
+window shapes, alias-reduction butterflies, the synthesis matrix, requantisation -- is computed here from its definition.
+
+Pinned: tests/test_mp3_cpu.py compares the output with Chromium's (FFmpeg's) decode of the same files
+(oracle/make_mp3_golden.py -> tests/golden/mp3_*.npz)."""
+import os
+
+import numpy as np
+
+
+class Mp3Error(ValueError):
+    pass
+
+
+_T = None                       # tables, loaded on first use
+BITRATES = (0, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320)          # kbit/s, MPEG-1 Layer III
+RATES = (44100, 48000, 32000)
+LINBITS = (0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 2, 3, 4, 6, 8, 10, 13, 4, 5, 6, 7, 8, 9, 11, 13)
+TABLE_OF = (0, 1, 2, 3, 0, 5, 6, 7, 8, 9, 10, 11, 12, 13, 0, 15) + (16,) * 8 + (24,) * 8   # table_select -> code table
+SLEN = ((0, 0, 0, 0, 3, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4), (0, 1, 2, 3, 0, 1, 2, 3, 1, 2, 3, 1, 2, 3, 2, 3))
+PRETAB = (0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 3, 2, 0)
+ALIAS_C = (-0.6, -0.535, -0.33, -0.185, -0.095, -0.041, -0.0142, -0.0037)
+
+
+def _tables():
+    """Everything derived once: Huffman look-up lists (peek max-length bits -> length, x, y), the per-rate line -> band
+    maps, the IMDCT matrices with their windows folded in, the synthesis matrix and window."""
+    global _T
+    if _T is not None:
+        return _T
+    raw = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "mp3_tables.npz"))
+    t = {}
+    huff = {}
+    for tid in (1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 24):
+        lens, codes = raw[f"huff{tid}_len"], raw[f"huff{tid}_code"]
+        maxlen = int(lens.max())
+        lut = [0] * (1 << maxlen)                      # entry: len << 8 | x << 4 | y
+        for x in range(lens.shape[0]):
+            for y in range(lens.shape[1]):
+                n, c = int(lens[x, y]), int(codes[x, y])
+                lo = c << (maxlen - n)
+                lut[lo:lo + (1 << (maxlen - n))] = [n << 8 | x << 4 | y] * (1 << (maxlen - n))
+        huff[tid] = (maxlen, lut)
+    t["huff"] = huff
+    quad = []
+    for q in range(2):
+        lens, codes = raw["count1_len"][q], raw["count1_code"][q]
+        maxlen = int(lens.max())
+        lut = [0] * (1 << maxlen)
+        for v in range(16):
+            n, c = int(lens[v]), int(codes[v])
+            lo = c << (maxlen - n)
+            lut[lo:lo + (1 << (maxlen - n))] = [n << 8 | v] * (1 << (maxlen - n))
+        quad.append((maxlen, lut))
+    t["quad"] = quad
+    # scalefactor bands (Table B.8): boundaries in lines (long) / lines of one window (short)
+    t["long_idx"] = [np.concatenate([[0], np.cumsum(w)]).astype(int) for w in raw["sfb_long_width"]]
+    t["short_idx"] = [np.concatenate([[0], np.cumsum(w)]).astype(int) for w in raw["sfb_short_width"]]
+    t["long_of_line"], t["short_of_line"], t["short_win_of_line"], t["reorder"], t["reorder_mixed"] = [], [], [], [], []
+    for r in range(3):
+        li, si = t["long_idx"][r], t["short_idx"][r]
+        t["long_of_line"].append(np.repeat(np.arange(22), np.diff(li)))
+        # short blocks as transmitted: band by band, inside a band window 0's lines, then window 1's, window 2's
+        band = np.concatenate([np.full(3 * (si[b + 1] - si[b]), b) for b in range(13)])
+        win = np.concatenate([np.repeat(np.arange(3), si[b + 1] - si[b]) for b in range(13)])
+        t["short_of_line"].append(band)
+        t["short_win_of_line"].append(win)
+        # destination of transmitted line n for the IMDCT: 3 * (frequency line inside the window) + window
+        dst = np.concatenate([(3 * (si[b] + np.arange(si[b + 1] - si[b]))[None, :] + np.arange(3)[:, None]).reshape(-1)
+                              for b in range(13)])
+        t["reorder"].append(dst)
+        mixed = np.arange(576)
+        mixed[36:] = dst[36:]                          # the first two subbands (36 lines = short bands 0..2) stay long
+        t["reorder_mixed"].append(mixed)
+    t["pow43"] = np.arange(8207, dtype=np.float64) ** (4.0 / 3.0)
+    c = np.array(ALIAS_C)
+    t["cs"], t["ca"] = 1.0 / np.sqrt(1.0 + c * c), c / np.sqrt(1.0 + c * c)
+    # IMDCT, n = 36: x[i] = sum_k X[k] cos(pi / 72 (2 i + 1 + 18) (2 k + 1)), times the block-type window
+    i, k = np.arange(36)[:, None], np.arange(18)[None, :]
+    c36 = np.cos(np.pi / 72.0 * (2 * i + 1 + 18) * (2 * k + 1))
+    ii = np.arange(36)
+    w0 = np.sin(np.pi / 36.0 * (ii + 0.5))
+    w1 = np.where(ii < 18, w0, np.where(ii < 24, 1.0, np.where(ii < 30, np.sin(np.pi / 12.0 * (ii - 18 + 0.5)), 0.0)))
+    w3 = np.where(ii < 6, 0.0, np.where(ii < 12, np.sin(np.pi / 12.0 * (ii - 6 + 0.5)), np.where(ii < 18, 1.0, w0)))
+    t["imdct36"] = {0: (c36 * w0[:, None]).T, 1: (c36 * w1[:, None]).T, 3: (c36 * w3[:, None]).T}      # [18][36]
+    i, k = np.arange(12)[:, None], np.arange(6)[None, :]
+    c12 = np.cos(np.pi / 24.0 * (2 * i + 1 + 6) * (2 * k + 1)) * np.sin(np.pi / 12.0 * (np.arange(12) + 0.5))[:, None]
+    # three windows of a short block laid into the 36-sample frame at 6 + 6 w: lines 3 k + w of a subband -> 36 samples
+    short = np.zeros((18, 36))
+    for w in range(3):
+        for kk in range(6):
+            short[3 * kk + w, 6 + 6 * w:18 + 6 * w] = c12[:, kk]
+    t["imdct_short"] = short                                                                           # [18][36]
+    # polyphase synthesis: V[i] = sum_k cos((16 + i)(2 k + 1) pi / 64) S[k]; window D[i] = C[i] * 32
+    i, k = np.arange(64)[:, None], np.arange(32)[None, :]
+    t["synth"] = np.cos((16 + i) * (2 * k + 1) * np.pi / 64.0).T                                       # [32][64]
+    half = raw["window_half"].astype(np.float64) / 65536.0
+    d = np.zeros(512)
+    d[:257] = half                                   # (the table already alternates in sign from one 64-tap block to the next)
+    for n in range(1, 256):                          # second half: D[512 - n] = -D[n], except D[512 - 64 k] = D[64 k]
+        d[512 - n] = -half[n] if n % 64 else half[n]
+    t["window"] = d
+    _T = t
+    return t
+
+
+class _Bits:
+    """MSB-first bit reader over a bytes-like object."""
+    __slots__ = ("buf", "pos", "n")
+
+    def __init__(self, buf, pos=0):
+        self.buf, self.pos, self.n = buf, pos, len(buf) * 8
+
+    def get(self, n):
+        if n == 0:
+            return 0
+        p = self.pos
+        self.pos = p + n
+        b = p >> 3
+        chunk = int.from_bytes(self.buf[b:b + 5], "big") << (8 * (5 - len(self.buf[b:b + 5])))
+        return (chunk >> (40 - (p & 7) - n)) & ((1 << n) - 1)
+
+    def peek(self, n):
+        p = self.pos
+        b = p >> 3
+        piece = self.buf[b:b + 5]
+        chunk = int.from_bytes(piece, "big") << (8 * (5 - len(piece)))
+        return (chunk >> (40 - (p & 7) - n)) & ((1 << n) - 1)
+
+
+def _skip_id3v2(data):
+    pos = 0
+    while data[pos:pos + 3] == b"ID3" and len(data) >= pos + 10:
+        size = (data[pos + 6] & 0x7F) << 21 | (data[pos + 7] & 0x7F) << 14 | (data[pos + 8] & 0x7F) << 7 | (data[pos + 9] & 0x7F)
+        pos += 10 + size + (10 if data[pos + 5] & 0x10 else 0)
+    return pos
+
+
+def _header(data, pos):
+    """Parsed frame header at ``pos`` or None."""
+    if pos + 4 > len(data):
+        return None
+    h = int.from_bytes(data[pos:pos + 4], "big")
+    if (h >> 21) != 0x7FF:
+        return None
+    version, layer, prot = (h >> 19) & 3, (h >> 17) & 3, (h >> 16) & 1
+    bri, sri, pad = (h >> 12) & 15, (h >> 10) & 3, (h >> 9) & 1
+    if version == 1 or layer == 0 or bri == 15 or sri == 3:
+        return None
+    return dict(version=version, layer=layer, crc=prot == 0, bitrate_index=bri, rate_index=sri, padding=pad,
+                mode=(h >> 6) & 3, mode_ext=(h >> 4) & 3)
+
+
+def _frame_length(hd):
+    return 144000 * BITRATES[hd["bitrate_index"]] // RATES[hd["rate_index"]] + hd["padding"]
+
+
+def _first_frame(data):
+    pos = _skip_id3v2(data)
+    while pos + 4 <= len(data):
+        hd = _header(data, pos)
+        if hd is not None and hd["bitrate_index"] != 0:
+            if hd["version"] != 3 or hd["layer"] != 1:
+                raise Mp3Error("only MPEG-1 Layer III is built (this stream is MPEG-2 / 2.5 (LSF) or another layer)")
+            nxt = _header(data, pos + _frame_length(hd))
+            if nxt is not None or pos + _frame_length(hd) >= len(data) - 4:
+                return pos, hd
+        pos += 1
+    raise Mp3Error("no MPEG audio frame found")
+
+
+def probe(data):
+    """Sampling rate, channel count and the gapless fields of the Xing / Info + LAME header (if any)."""
+    pos, hd = _first_frame(data)
+    info = dict(sample_rate=RATES[hd["rate_index"]], channels=1 if hd["mode"] == 3 else 2, first_frame=pos, xing=False,
+                frames=None, start_pad=0, end_pad=0)
+    side = 17 if hd["mode"] == 3 else 32
+    tag = pos + 4 + side                              # (the header frame carries no CRC in practice; FFmpeg assumes so too)
+    if data[tag:tag + 4] in (b"Xing", b"Info"):
+        info["xing"] = True
+        flags = int.from_bytes(data[tag + 4:tag + 8], "big")
+        p = tag + 8
+        if flags & 1:
+            info["frames"] = int.from_bytes(data[p:p + 4], "big")
+            p += 4
+        if flags & 2:
+            p += 4
+        if flags & 4:
+            p += 100
+        if flags & 8:
+            p += 4
+        # LAME extension: 9-byte encoder string, 12 bytes of settings, then delay (12 bits) | padding (12 bits)
+        if p + 24 <= len(data) and data[p:p + 4] in (b"LAME", b"Lavc", b"Lavf", b"L3.9"):
+            v = int.from_bytes(data[p + 21:p + 24], "big")
+            info["start_pad"], info["end_pad"] = v >> 12, v & 0xFFF
+    return info
+
+
+def _side_info(br, nch):
+    si = dict(main_data_begin=br.get(9))
+    br.get(5 if nch == 1 else 3)
+    si["scfsi"] = [[br.get(1) for _ in range(4)] for _ in range(nch)]
+    si["gr"] = []
+    for _ in range(2):
+        chans = []
+        for _ in range(nch):
+            g = dict(part2_3_length=br.get(12), big_values=br.get(9), global_gain=br.get(8), scalefac_compress=br.get(4),
+                     window_switching=br.get(1))
+            if g["window_switching"]:
+                g["block_type"], g["mixed"] = br.get(2), br.get(1)
+                g["table_select"] = [br.get(5), br.get(5), 0]
+                g["subblock_gain"] = [br.get(3), br.get(3), br.get(3)]
+                if g["block_type"] == 0:
+                    raise Mp3Error("invalid stream: window switching with block type 0")
+                g["region0_count"], g["region1_count"] = (8 if g["block_type"] == 2 and not g["mixed"] else 7), 36
+            else:
+                g["block_type"], g["mixed"] = 0, 0
+                g["table_select"] = [br.get(5), br.get(5), br.get(5)]
+                g["subblock_gain"] = [0, 0, 0]
+                g["region0_count"], g["region1_count"] = br.get(4), br.get(3)
+            g["preflag"], g["scalefac_scale"], g["count1table_select"] = br.get(1), br.get(1), br.get(1)
+            chans.append(g)
+        si["gr"].append(chans)
+    return si
+
+
+def _scalefactors(br, g, scfsi, prev_long):
+    """Scale factors of one (granule, channel): (long [22], short [13][3]); ``prev_long`` = granule 0's long factors of
+    this channel when scfsi may reuse them (granule 1), else None.  ISO 11172-3 2.4.2.7 / 2.4.3.4.5."""
+    slen1, slen2 = SLEN[0][g["scalefac_compress"]], SLEN[1][g["scalefac_compress"]]
+    long_sf, short_sf = [0] * 22, [[0, 0, 0] for _ in range(13)]
+    if g["block_type"] == 2:
+        if g["mixed"]:
+            for sfb in range(8):
+                long_sf[sfb] = br.get(slen1)
+            for sfb in range(3, 6):
+                for w in range(3):
+                    short_sf[sfb][w] = br.get(slen1)
+        else:
+            for sfb in range(6):
+                for w in range(3):
+                    short_sf[sfb][w] = br.get(slen1)
+        for sfb in range(6, 12):
+            for w in range(3):
+                short_sf[sfb][w] = br.get(slen2)
+    else:
+        for grp, (lo, hi) in enumerate(((0, 6), (6, 11), (11, 16), (16, 21))):
+            n = slen1 if grp < 2 else slen2
+            if prev_long is not None and scfsi[grp]:
+                long_sf[lo:hi] = prev_long[lo:hi]
+            else:
+                for sfb in range(lo, hi):
+                    long_sf[sfb] = br.get(n)
+    return long_sf, short_sf
+
+
+def _huffman(br, g, end, rate_index, t):
+    """576 quantised lines of one (granule, channel); the reader ends at bit ``end`` (= part 2 start + part2_3_length)."""
+    out = [0] * 578
+    big = min(g["big_values"] * 2, 576)
+    li = t["long_idx"][rate_index]
+    if g["window_switching"]:
+        r1, r2 = 36, 576
+    else:
+        r1 = int(li[min(g["region0_count"] + 1, 22)])
+        r2 = int(li[min(g["region0_count"] + g["region1_count"] + 2, 22)])
+    bounds = (min(r1, big), min(r2, big), big)
+    buf, pos = br.buf, br.pos
+    i = 0
+    for region in range(3):
+        sel = g["table_select"][region]
+        tid, linbits, stop = TABLE_OF[sel], LINBITS[sel], bounds[region]
+        if tid == 0:
+            i = max(i, stop)                           # table 0: all zeros, no bits
+            continue
+        maxlen, lut = t["huff"][tid]
+        shift, mask = 40 - maxlen, (1 << maxlen) - 1
+        while i < stop:
+            b = pos >> 3
+            piece = buf[b:b + 5]
+            word = int.from_bytes(piece, "big") << (8 * (5 - len(piece)))
+            e = lut[(word >> (shift - (pos & 7))) & mask]
+            pos += e >> 8
+            x, y = (e >> 4) & 15, e & 15
+            if linbits and x == 15:
+                br.pos = pos
+                x += br.get(linbits)
+                pos = br.pos
+            if x:
+                if (buf[pos >> 3] >> (7 - (pos & 7))) & 1:
+                    x = -x
+                pos += 1
+            if linbits and y == 15:
+                br.pos = pos
+                y += br.get(linbits)
+                pos = br.pos
+            if y:
+                if (buf[pos >> 3] >> (7 - (pos & 7))) & 1:
+                    y = -y
+                pos += 1
+            out[i], out[i + 1] = x, y
+            i += 2
+    # count1 region: quadruples of magnitude <= 1 until the granule's bits run out
+    maxlen, lut = t["quad"][g["count1table_select"]]
+    while pos < end and i <= 572:
+        b = pos >> 3
+        piece = buf[b:b + 5]
+        word = int.from_bytes(piece, "big") << (8 * (5 - len(piece)))
+        e = lut[(word >> (40 - maxlen - (pos & 7))) & ((1 << maxlen) - 1)]
+        pos += e >> 8
+        v = e & 15
+        vals = [0, 0, 0, 0]
+        for n, bit in enumerate((8, 4, 2, 1)):
+            if v & bit:
+                vals[n] = -1 if (buf[pos >> 3] >> (7 - (pos & 7))) & 1 else 1
+                pos += 1
+        if pos > end:                                  # ran past the granule: the last quadruple is stuffing, not data
+            break
+        out[i:i + 4] = vals
+        i += 4
+    br.pos = end
+    return out[:576]
+
+
+def _requantise(isamp, g, long_sf, short_sf, rate_index, t):
+    """xr = sign(is) |is|^(4/3) 2^((global_gain - 210) / 4) x the scale-factor term (2.4.3.4.7.1), as transmitted
+    (short blocks not yet reordered)."""
+    isamp = np.asarray(isamp, dtype=np.int64)
+    mag = t["pow43"][np.minimum(np.abs(isamp), 8206)] * np.sign(isamp)
+    mult = 1.0 if g["scalefac_scale"] else 0.5
+    gain = (g["global_gain"] - 210) / 4.0
+    lsf = np.asarray(long_sf, dtype=np.float64)
+    exp_long = gain - mult * (lsf + (np.asarray(PRETAB) if g["preflag"] else 0))[t["long_of_line"][rate_index]]
+    if g["block_type"] != 2:
+        return mag * np.exp2(exp_long)
+    ssf = np.asarray(short_sf, dtype=np.float64)
+    band, win = t["short_of_line"][rate_index], t["short_win_of_line"][rate_index]
+    exp_short = gain - 2.0 * np.asarray(g["subblock_gain"], dtype=np.float64)[win] - mult * ssf[band, win]
+    if g["mixed"]:
+        exp_short[:36] = exp_long[:36]
+    return mag * np.exp2(exp_short)
+
+
+def decode(data, trim_gapless=True, clip=True):
+    """``(pcm float32 [channels, samples], sampling rate)`` of an MPEG-1 Layer III stream held in ``data`` (bytes).
+    ``trim_gapless``: drop the encoder delay / padding announced in a LAME header the way FFmpeg does; ``clip``: saturate
+    at +-1 like the 16-bit PCM the reference's decode chain goes through (librosa -> audioread -> FFmpeg; Chromium's
+    FFmpeg, the pin of this decoder, saturates the same way -- demo_speaker1.mp3 peaks at 1.22 unclipped)."""
+    t = _tables()
+    data = bytes(data)
+    info = probe(data)
+    pos, nch, rate = info["first_frame"], info["channels"], info["sample_rate"]
+    reservoir = b""
+    prev = np.zeros((nch, 32, 18))                     # IMDCT overlap per channel and subband
+    subband_slots = [[] for _ in range(nch)]           # hybrid outputs, 18 time slots x 32 subbands per granule
+    first = True
+    frames = 0
+    while True:
+        hd = _header(data, pos)
+        if hd is None or hd["bitrate_index"] == 0:
+            # resynchronise (a few junk bytes, an ID3v1 tag at the end); stop when nothing follows
+            nxt = data.find(b"\xff", pos + 1)
+            while nxt >= 0 and (_header(data, nxt) is None or _header(data, nxt)["bitrate_index"] == 0):
+                nxt = data.find(b"\xff", nxt + 1)
+            if nxt < 0:
+                break
+            pos = nxt
+            continue
+        if hd["version"] != 3 or hd["layer"] != 1:
+            raise Mp3Error("only MPEG-1 Layer III is built (this stream is MPEG-2 / 2.5 (LSF) or another layer)")
+        flen = _frame_length(hd)
+        if pos + flen > len(data):
+            break
+        frame_nch = 1 if hd["mode"] == 3 else 2
+        if frame_nch != nch or RATES[hd["rate_index"]] != rate:
+            raise Mp3Error("channel count / sampling rate changes inside the stream")
+        side_len = 17 if nch == 1 else 32
+        body = pos + 4 + (2 if hd["crc"] else 0)
+        if first and info["xing"]:
+            first = False                              # the Xing / Info frame carries the header, not audio
+            pos += flen
+            continue
+        first = False
+        si = _side_info(_Bits(data, body * 8), nch)
+        main = data[body + side_len:pos + flen]
+        if si["main_data_begin"] > len(reservoir):
+            # the stream was cut before this frame's reservoir: its granules cannot be decoded -> silence (as FFmpeg)
+            reservoir = (reservoir + main)[-511:]
+            for ch in range(nch):
+                subband_slots[ch].append(np.zeros((36, 32)))
+            pos += flen
+            frames += 1
+            continue
+        buf = reservoir[len(reservoir) - si["main_data_begin"]:] + main
+        reservoir = (reservoir + main)[-511:]
+        br = _Bits(buf + bytes(8))                     # (zero tail: peeks near the end stay in range)
+        if hd["mode"] == 1 and hd["mode_ext"] & 1:
+            raise Mp3Error("intensity stereo is not built")
+        ms = hd["mode"] == 1 and bool(hd["mode_ext"] & 2)
+        sf0 = [None] * nch
+        for gr in range(2):
+            xr = np.zeros((nch, 576))
+            for ch in range(nch):
+                g = si["gr"][gr][ch]
+                start = br.pos
+                long_sf, short_sf = _scalefactors(br, g, si["scfsi"][ch], sf0[ch] if gr == 1 else None)
+                if gr == 0:
+                    sf0[ch] = long_sf
+                isamp = _huffman(br, g, start + g["part2_3_length"], hd["rate_index"], t)
+                xr[ch] = _requantise(isamp, g, long_sf, short_sf, hd["rate_index"], t)
+            if ms:
+                m, s = xr[0].copy(), xr[1].copy()
+                xr[0], xr[1] = (m + s) / np.sqrt(2.0), (m - s) / np.sqrt(2.0)
+            for ch in range(nch):
+                g = si["gr"][gr][ch]
+                x = xr[ch]
+                if g["block_type"] == 2:               # short blocks: band-by-band order -> 3 k + window inside a subband
+                    y = np.zeros(576)
+                    y[t["reorder_mixed" if g["mixed"] else "reorder"][hd["rate_index"]]] = x
+                    x = y
+                x = x.reshape(32, 18).copy()
+                nlong = 32 if g["block_type"] != 2 else (2 if g["mixed"] else 0)
+                for sb in range(1, nlong):             # alias reduction across the boundaries between LONG subbands
+                    a, b = x[sb - 1, 17:9:-1].copy(), x[sb, :8].copy()
+                    x[sb - 1, 17:9:-1] = a * t["cs"] - b * t["ca"]
+                    x[sb, :8] = b * t["cs"] + a * t["ca"]
+                out = np.empty((32, 36))
+                if nlong:
+                    bt = 0 if (g["block_type"] == 2 and g["mixed"]) else g["block_type"]
+                    out[:nlong] = x[:nlong] @ t["imdct36"][bt]
+                if nlong < 32:
+                    out[nlong:] = x[nlong:] @ t["imdct_short"]
+                hyb = out[:, :18] + prev[ch]
+                prev[ch] = out[:, 18:]
+                hyb[1::2, 1::2] *= -1.0                # frequency inversion: odd time samples of odd subbands
+                subband_slots[ch].append(hyb.T)        # [18 slots][32 subbands]
+        pos += flen
+        frames += 1
+    if not frames:
+        raise Mp3Error("no decodable frame")
+    # ---- polyphase synthesis, all time slots at once: V = S N, out[t][j] = sum_i D[64 i + j] V[t - 2 i][j] + D[64 i + 32 + j] V[t - 2 i - 1][32 + j]
+    win = t["window"]
+    pcm = np.empty((nch, frames * 1152), dtype=np.float32)
+    for ch in range(nch):
+        s = np.concatenate(subband_slots[ch], axis=0)                       # [slots][32]
+        v = np.concatenate([np.zeros((16, 64)), s @ t["synth"]], axis=0)    # 16 slots of history
+        n = s.shape[0]
+        out = np.zeros((n, 32))
+        for i in range(8):
+            out += win[64 * i:64 * i + 32] * v[16 - 2 * i:16 - 2 * i + n, :32]
+            out += win[64 * i + 32:64 * i + 64] * v[15 - 2 * i:15 - 2 * i + n, 32:]
+        pcm[ch] = out.reshape(-1)
+    if trim_gapless and info["xing"] and (info["start_pad"] or info["end_pad"]):
+        # what FFmpeg's demuxer does with the LAME fields: skip start_pad + 528 + 1 samples, end at
+        # frames * 1152 - end_pad + 528 + 1 (the decoder itself delays the signal by 528 + 1 samples)
+        total = (info["frames"] if info["frames"] else frames) * 1152
+        a = info["start_pad"] + 529
+        b = min(pcm.shape[1], max(a, total - info["end_pad"] + 529))
+        pcm = pcm[:, a:b]
+    if clip:
+        pcm = np.clip(pcm, -1.0, 1.0)
+    return pcm, rate

@@ -26,7 +26,7 @@ def hash_numpy_array(audio_path):
         import librosa
         array, _ = librosa.load(audio_path, sr=None, mono=True)
     except ImportError:
-        array, _ = audio_io._read_wav(audio_path)
+        array, _ = audio_io.read_native(audio_path)
     array = np.asarray(array, dtype=np.float32)
     if array.ndim > 1:
         array = array.mean(axis=1)

@@ -440,3 +440,38 @@ def test_non_released_config_matches_oracle():
     from openvoice_amd._lib import OvError
     with pytest.raises(OvError, match="resblock"):
         SynthesizerTrn(0, 513, n_speakers=0, **dict(cfg, resblock="2"))
+
+
+def test_convert_and_extract_se_from_an_mp3_file(tmp_path, synth_sd):
+    """BASELINE.json configs[0] AS WRITTEN -- ``ToneColorConverter.convert`` / ``extract_se`` on an MP3 file (reference:
+    openvoice/api.py:123,144 ``librosa.load``): the MP3 that ships inside the image (kaleido's invalid_keypress.mp3, 0.52 s
+    of joint stereo at 44.1 kHz) goes through ``openvoice_amd.mp3`` (pinned against FFmpeg, tests/test_mp3_cpu.py), the
+    channel mean and the kaiser_best resampler to the model rate, then through the HIP path; checked against the CPU
+    oracle on the same decoded samples."""
+    import json
+    import numpy as np
+    from openvoice_amd import api, audio_io
+    from openvoice_amd.utils import default_converter_hparams
+    from oracle import vc_oracle
+    mp3_path = "/usr/local/lib/python3.10/dist-packages/kaleido/executable/etc/mathjax/extensions/a11y/invalid_keypress.mp3"
+    if not os.path.exists(mp3_path):
+        pytest.skip("the image's bundled MP3 is not on this machine")
+    hps = default_converter_hparams("v2")
+    cfg = {"_version_": "v2", "data": dict(hps.data.items()), "model": dict(hps.model.items())}
+    (tmp_path / "config.json").write_text(json.dumps(cfg))
+    torch.save({"model": synth_sd}, tmp_path / "checkpoint.pth")
+    tcc = api.ToneColorConverter(str(tmp_path / "config.json"), device=DEV, enable_watermark=False)
+    tcc.load_ckpt(str(tmp_path / "checkpoint.pth"))
+    wave, sr = audio_io.load(mp3_path, 22050)
+    assert sr == 22050 and 0.4 < len(wave) / sr < 0.6 and np.abs(wave).max() > 0.1
+    se = tcc.extract_se(mp3_path)
+    assert se.shape == (1, 256, 1) and torch.isfinite(se).all()
+    tgt = 0.3 * torch.randn(1, 256, 1, generator=torch.Generator().manual_seed(3))
+    audio = tcc.convert(mp3_path, se, tgt.to(DEV), output_path=None, tau=0.0)
+    with torch.no_grad():
+        spec = vc_oracle.spectrogram(torch.from_numpy(wave)[None])
+        se_ref = vc_oracle.reference_encoder(synth_sd, spec.transpose(1, 2)).unsqueeze(-1)
+        o_ref = vc_oracle.voice_conversion(synth_sd, dict(hps.model.items()), spec, torch.tensor([spec.shape[2]]), se.cpu(),
+                                           tgt, 0.0, torch.zeros(1, 192, spec.shape[2]), zero_g=True)[0]
+    assert (se.cpu() - se_ref).abs().max().item() <= 1e-4
+    assert audio.shape == (spec.shape[2] * 256,) and np.abs(audio - o_ref[0, 0].numpy()).max() <= 1e-3
