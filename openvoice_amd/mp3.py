@@ -434,10 +434,11 @@ def decode(data, trim_gapless=True, clip=True):
                     x = y
                 x = x.reshape(32, 18).copy()
                 nlong = 32 if g["block_type"] != 2 else (2 if g["mixed"] else 0)
-                for sb in range(1, nlong):             # alias reduction across the boundaries between LONG subbands
-                    a, b = x[sb - 1, 17:9:-1].copy(), x[sb, :8].copy()
-                    x[sb - 1, 17:9:-1] = a * t["cs"] - b * t["ca"]
-                    x[sb, :8] = b * t["cs"] + a * t["ca"]
+                if nlong > 1:                          # alias reduction across the boundaries between LONG subbands: the
+                    # butterflies of different boundaries touch disjoint lines (top 8 of sb - 1, bottom 8 of sb): all at once
+                    a, b = x[:nlong - 1, 17:9:-1].copy(), x[1:nlong, :8].copy()
+                    x[:nlong - 1, 17:9:-1] = a * t["cs"] - b * t["ca"]
+                    x[1:nlong, :8] = b * t["cs"] + a * t["ca"]
                 out = np.empty((32, 36))
                 if nlong:
                     bt = 0 if (g["block_type"] == 2 and g["mixed"]) else g["block_type"]
