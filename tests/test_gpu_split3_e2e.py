@@ -76,3 +76,20 @@ def test_benchmark_shape_items_match_the_oracle_at_the_fp32_bar(synth_sd):
               f"split vs fp32 kernels {(o_split[item] - o_fp32[item]).abs().max().item():.2e}; |o|max {want.abs().max().item():.3f}")
         assert e_split <= SPLIT_O_HAT_TOL and e_fp32 <= SPLIT_O_HAT_TOL
         assert e_three <= 1e-3             # the 16-bit-operand mode is held to BASELINE.json's 1e-3, not to the fp32 bar
+
+
+import test_gpu_fuzz as fuzz_tests  # noqa: E402
+
+
+@pytest.mark.parametrize("case", fuzz_tests._cases(24, 7)[::3],
+                         ids=lambda c: f"B{c['B']}_T{c['T']}_{'skip' if c['skip'] else 'full'}")
+def test_random_shapes_with_the_split_path(synth_sd, case):
+    """Every third case of tests/test_gpu_fuzz.py (random batch / frames / ragged lengths / zero_g / tau, half of them with the
+    length-aware work lists) through engines built with the split path on.  Under ``skip_padding`` the split stages compute
+    the whole tensors (a superset), the fp32 stage and conv_post still honour the limits: the valid samples match the oracle
+    and the padded tail is exact silence."""
+    fuzz_tests._models.clear()                       # (models cached by the fp32 fuzz run were built without the split path)
+    try:
+        fuzz_tests.test_random_shape_matches_oracle(synth_sd, case)
+    finally:
+        fuzz_tests._models.clear()
