@@ -35,6 +35,8 @@ def main():
     model = SynthesizerTrn(68, 513, n_speakers=10, **CFG)
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
+    if args.split_bf16x3:
+        model.engine().core.use_split_bf16x3(True, products=args.split_bf16x3)
     gen = torch.Generator().manual_seed(0)
     B, Tx = args.batch, args.tokens
     tokens = torch.randint(0, 68, (B, Tx), generator=gen).to(dev)
