@@ -26,6 +26,9 @@ def main():
                     help="compute the generator on the whole padded batch, as the reference does (round-2 figure); "
                          "default: length-aware work lists (infer(skip_padding=True): length + 16 frames per "
                          "utterance, valid samples bit-identical -- tests/test_gpu_limits.py)")
+    ap.add_argument("--split-bf16x3", type=int, default=0, choices=(0, 6, 3),
+                    help="opt-in: the generator's MRF stages on the split-precision kernels with 6 or 3 plane products "
+                         "(ConverterEngine.use_split_bf16x3; those stages compute the padded batch: no length-aware lists)")
     args = ap.parse_args()
     from openvoice_amd.models import SynthesizerTrn
     from openvoice_amd.params import synthetic_tts_state_dict
