@@ -465,7 +465,8 @@ int ov_resblock_pair2_bf16_supported(int C, int K, int dil);
  * x is read as stored (the producer stores it activated); res~ = res for res_slope = 1, else the inverse leaky ReLU of
  * res (res >= 0 ? res : res / res_slope: the residual tensor is the conv input of the pair, stored activated).
  * reference: openvoice/modules.py:296-306 (xt = c1(lrelu(x)); xt = c2(lrelu(xt)); x = xt + x).
- * Cin = Cout in {64, 128, 256}, K in {3, 7, 11}, dil in {1, 3, 5} (with res: dil = 1); out must alias neither x nor res. */
+ * Cin = Cout in {64, 128, 256}, K in {3, 7, 11}, dil in {1, 3, 5} (with res: dil = 1); out must alias neither x nor res.
+ * What a launch computes is bit-identical with and without col_limit. */
 typedef struct ov_conv1d_split3_params {
   const uint16_t* x;     /* [3][B][L][Cin] bf16 planes */
   const uint16_t* w;     /* ov_conv1d_split3_pack(Cout, Cin, K) */
@@ -479,8 +480,11 @@ typedef struct ov_conv1d_split3_params {
   float res_slope;       /* 0 < res_slope <= 1 */
   float out_slope;       /* 0 < out_slope <= 1; 1 = store the raw result */
   float scale;
-  int32_t reserved0;
+  int32_t col_limit_scale; /* with col_limit: output columns per unit of col_limit (>= 1) */
   unsigned long long* dbg; /* measurement only, NULL in production: [workgroups][4 matrix waves][8] ticks per phase */
+  const int32_t* col_limit; /* DEVICE int32 [B] or NULL: columns of each utterance that matter = col_limit[b] *
+                             * col_limit_scale; 128-row time tiles that start at or beyond them are neither computed nor
+                             * written (length-aware work lists, as ov_conv1d_params.col_limit; B <= 256, else ignored) */
 } ov_conv1d_split3_params;
 int ov_conv1d_split3(const ov_conv1d_split3_params* p, ov_stream_t stream);
 /* Elements (uint16) of the packed three-plane weight stream; 0 when Cout or Cin is not a multiple of 32. */
@@ -500,7 +504,8 @@ int ov_split3_to_f32(const uint16_t* a, const uint16_t* b, const uint16_t* c, in
 
 /* Library/ABI version (major*100 + minor).  2.01: ov_conv1d_params.col_limit, ov_conv_post_tanh_limited_f32,
  * ov_frame_limits_i32.  2.02: ov_unpad_rows_f32, ov_conv1d_bf16_pack16, ov_resblock_pair2_bf16cl (+ _supported).
- * 2.03: ov_conv1d_split3 (+ _pack_size, _pack, _supported), ov_split3_from_f32, ov_split3_to_f32.  The Python binding
+ * 2.03: ov_conv1d_split3 (+ _pack_size, _pack, _supported), ov_split3_from_f32, ov_split3_to_f32.  2.04:
+ * ov_conv1d_split3_params.col_limit / col_limit_scale.  The Python binding
  * refuses a library older than the entry points it calls (openvoice_amd/_lib.py MIN_VERSION). */
 int ov_version(void);
 /* 0 for a production build; non-zero = a measurement build with parts of the kernels compiled out (results are

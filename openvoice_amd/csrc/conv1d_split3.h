@@ -80,13 +80,28 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // (utterance, time tile, output-channel block) of a flattened step index; the channel block runs fastest, so the two
 // blocks of a 256-channel layer read the same input tile back to back (the second one from L2)
+// With per-utterance column limits (ov_conv1d_split3_params.col_limit: length-aware work lists, as ov_conv1d_params has
+// them) the list stays DENSE: `pref` (LDS, B + 1 entries) holds the prefix sums of the utterances' tile counts and the
+// utterance of a step is found by bisection -- tiles at or beyond an utterance's limit simply do not exist.
+constexpr int LIMIT_MAX_BATCH = 256;
 struct Step {
   int b, tile, mb;
-  __device__ __forceinline__ Step(long s, int ntiles, int nmb) {
+  __device__ __forceinline__ Step(long s, int ntiles, int nmb, const int* pref, int B) {
     const long bt = s / nmb;
     mb = (int)(s - bt * nmb);
-    b = (int)(bt / ntiles);
-    tile = (int)(bt - (long)b * ntiles);
+    if (!pref) {
+      b = (int)(bt / ntiles);
+      tile = (int)(bt - (long)b * ntiles);
+    } else {                                           // largest b with pref[b] <= bt  (pref[0] = 0, pref[B] > bt)
+      int lo = 0, hi = B;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (pref[mid] <= (int)bt) lo = mid;
+        else hi = mid;
+      }
+      b = lo;
+      tile = (int)bt - pref[lo];
+    }
   }
 };
 
@@ -112,7 +127,8 @@ struct Geo {
   static constexpr int NBUF = 3 * XB + NOH * OH + COT * 4 <= 160 * 1024 ? 3 : 2;
   static constexpr int OOFF = NBUF * XB;
   static constexpr int BOFF = OOFF + NOH * OH;
-  static constexpr int SMEM = BOFF + COT * 4;
+  static constexpr int POFF = BOFF + COT * 4;        // prefix sums of the utterances' tile counts (length-aware lists)
+  static constexpr int SMEM = POFF + (LIMIT_MAX_BATCH + 4) * 4;
   static constexpr int NPAIR = NCH * K;              // (chunk, tap) pairs of one step = 6 weight records each
   static_assert(NCH % 2 == 0, "the chunk loop is unrolled by two (static weight-ring slots for odd K)");
   static_assert(COT == 128 || COT == 64, "4 matrix waves: 1 x 4 or 2 x 2");
@@ -139,7 +155,39 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
   const int L = p.L;
   const int ntiles = (L + TT - 1) / TT;
   const int nmb = p.Cout / COT;
-  const long SS = (long)p.B * ntiles * nmb;
+  // length-aware work list: tiles per utterance from its column limit, exclusive prefix sums in LDS (one wave: up to four
+  // utterances per lane, a shuffle scan across the lanes); every role then maps step -> (utterance, tile) through it
+  int* const pref_lds = reinterpret_cast<int*>(smem + G::POFF);
+  const int* const pref = p.col_limit ? pref_lds : nullptr;
+  long SS = (long)p.B * ntiles * nmb;
+  if (pref) {
+    if (wave == 0) {
+      int cnt[4], sum = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int b = 4 * lane + i;
+        long cols = b < p.B ? (long)p.col_limit[b] * p.col_limit_scale : 0;
+        cols = cols < 0 ? 0 : (cols > L ? L : cols);
+        cnt[i] = (int)((cols + TT - 1) / TT);
+        sum += cnt[i];
+      }
+      int incl = sum;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+      }
+      int run = incl - sum;                            // exclusive prefix of this lane's first utterance
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (4 * lane + i <= p.B) pref_lds[4 * lane + i] = run;
+        run += cnt[i];
+      }
+      if (lane == 63 && p.B == 4 * 64) pref_lds[256] = run;
+    }
+    __syncthreads();
+    SS = (long)pref_lds[p.B] * nmb;
+  }
   const long g0 = SS * blockIdx.x / gridDim.x, g1 = SS * (blockIdx.x + 1) / gridDim.x;
   if (g0 >= g1) return;
   typedef const __attribute__((address_space(1))) unsigned char* gc_ptr;
@@ -231,7 +279,7 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
     const long total = (g1 - g0) * NCH;
     auto request = [&](long n) {
       if (n < total) {
-        const Step st(g0 + n / NCH, ntiles, nmb);
+        const Step st(g0 + n / NCH, ntiles, nmb, pref, p.B);
         dma_chunk((int)(n % NBUF), st, (int)(n % NCH));
       }
     };
@@ -247,7 +295,7 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
       }
       __builtin_amdgcn_s_barrier();                          // A(n): chunk n (and, from c = 1 on, the residual tile) landed
       // the output buffers are free from A(s, 0) on: the output waves fetched step s - 1's last round before it
-      if (c == 0) dma_residual(Step(g0 + n / NCH, ntiles, nmb));
+      if (c == 0) dma_residual(Step(g0 + n / NCH, ntiles, nmb, pref, p.B));
       request(n + NBUF - 1);
       if (c == NCH - 1) {
         __builtin_amdgcn_s_barrier();                          // E0
@@ -303,7 +351,7 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
     };
     __builtin_amdgcn_s_barrier();                            // (init)
     for (long s = g0; s < g1; ++s) {
-      const Step st(s, ntiles, nmb);
+      const Step st(s, ntiles, nmb, pref, p.B);
 #pragma unroll
       for (int c = 0; c < NCH; ++c) __builtin_amdgcn_s_barrier();   // A(s, c)
       __builtin_amdgcn_s_barrier();                            // E0: round 0 is complete in its buffer
@@ -375,14 +423,14 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
   if (dbg) tlast = __builtin_readcyclecounter();
   int n = 0, nstep = 0;
   {                                                   // first pair of the first step
-    const Step st(g0, ntiles, nmb);
+    const Step st(g0, ntiles, nmb, pref, p.B);
     wp = wall + (size_t)(NCT * st.mb + ct) * G::NPAIR * 6 * 64;
     static_for<0, 6>([&](auto rc) { wrequest(0, decltype(rc)::value); });
     wp += 6 * 64;
   }
   for (long s = g0; s < g1; ++s, ++nstep) {
-    const Step st(s, ntiles, nmb);
-    const Step nx(s + 1 < g1 ? s + 1 : s, ntiles, nmb);
+    const Step st(s, ntiles, nmb, pref, p.B);
+    const Step nx(s + 1 < g1 ? s + 1 : s, ntiles, nmb, pref, p.B);
     if (tid < COT) bsm[tid] = p.bias[COT * st.mb + tid];   // (read after barrier A(s, 0); last read before E0 of s - 1)
     f32x4 acc[2][JW];
     // ---- k-loops: two chunks per iteration (static ring parity: 2 K pairs) ------------------------------------------

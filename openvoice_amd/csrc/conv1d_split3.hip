@@ -131,8 +131,13 @@ int ov_conv1d_split3_supported(int Cin, int Cout, int K, int dil) {
   return kd && (Cin == 64 || Cin == 128 || Cin == 256) && Cout == Cin ? 1 : 0;
 }
 
-int ov_conv1d_split3(const ov_conv1d_split3_params* p, ov_stream_t stream) {
-  if (!p || !p->x || !p->w || !p->bias || !p->out) return OV_E_BADARG;
+int ov_conv1d_split3(const ov_conv1d_split3_params* pin, ov_stream_t stream) {
+  if (!pin) return OV_E_BADARG;
+  ov_conv1d_split3_params q = *pin;                  // (normalised copy: the limit is dropped where the table cannot hold it)
+  const ov_conv1d_split3_params* p = &q;
+  if (!p->x || !p->w || !p->bias || !p->out) return OV_E_BADARG;
+  if (p->col_limit && (p->col_limit_scale <= 0 || (reinterpret_cast<uintptr_t>(p->col_limit) & 3))) return OV_E_BADARG;
+  if (p->col_limit && p->B > ovks3::LIMIT_MAX_BATCH) q.col_limit = nullptr;   // documented: whole tensors
   if (p->B <= 0 || p->L <= 0 || p->nwg < 0 || p->x_plane <= 0 || p->out_plane <= 0) return OV_E_BADARG;
   if (p->res && p->res_plane <= 0) return OV_E_BADARG;
   if (p->out == p->x || p->out == p->res) return OV_E_BADARG;

@@ -330,18 +330,20 @@ void resblock_pair2_bf16cl(const OptTensor& x, const OptTensor& w1, const OptTen
   finish(ov_resblock_pair2_bf16cl(&p, c.stream()), "ov_resblock_pair2_bf16cl");
 }
 
-// ip = [B, L, Cin, Cout, K, dil, nwg, products, x_plane, out_plane, res_plane];  fp = [res_slope, out_slope, scale]
+// ip = [B, L, Cin, Cout, K, dil, nwg, products, x_plane, out_plane, res_plane, col_limit_scale];
+// fp = [res_slope, out_slope, scale]
 void conv1d_split3(const OptTensor& x, const OptTensor& w, const OptTensor& bias, const OptTensor& out, const OptTensor& res,
-                   const OptTensor& dbg, at::IntArrayRef ip, at::ArrayRef<double> fp) {
-  TORCH_CHECK(ip.size() == 11 && fp.size() == 3, "openvoice_amd::conv1d_split3: 11 integer and 3 float parameters");
+                   const OptTensor& dbg, const OptTensor& col_limit, at::IntArrayRef ip, at::ArrayRef<double> fp) {
+  TORCH_CHECK(ip.size() == 12 && fp.size() == 3, "openvoice_amd::conv1d_split3: 12 integer and 3 float parameters");
   Ctx c{"conv1d_split3", false};
   ov_conv1d_split3_params p{};
   p.x = sptr<uint16_t>(x, c, 0); p.w = sptr<uint16_t>(w, c, 1); p.bias = sptr<float>(bias, c, 2);
   p.out = sptr<uint16_t>(out, c, 3); p.res = sptr<uint16_t>(res, c, 4);
   p.dbg = sptr<unsigned long long>(dbg, c, 5);
+  p.col_limit = sptr<int32_t>(col_limit, c, 6);
   p.B = (int32_t)ip[0]; p.L = (int32_t)ip[1]; p.Cin = (int32_t)ip[2]; p.Cout = (int32_t)ip[3]; p.K = (int32_t)ip[4];
   p.dil = (int32_t)ip[5]; p.nwg = (int32_t)ip[6]; p.products = (int32_t)ip[7];
-  p.x_plane = ip[8]; p.out_plane = ip[9]; p.res_plane = ip[10];
+  p.x_plane = ip[8]; p.out_plane = ip[9]; p.res_plane = ip[10]; p.col_limit_scale = (int32_t)ip[11];
   p.res_slope = (float)fp[0]; p.out_slope = (float)fp[1]; p.scale = (float)fp[2];
   DeviceScope scope(c);
   finish(ov_conv1d_split3(&p, c.stream()), "ov_conv1d_split3");
@@ -363,8 +365,8 @@ TORCH_LIBRARY(openvoice_amd, m) {
         "Tensor(b!)? dbg, int[] ip, float[] fp) -> ()", &resblock_pair_bf16cl);
   m.def("resblock_pair2_bf16cl(Tensor? x, Tensor? w1, Tensor? b1, Tensor? w2, Tensor? b2, Tensor(a!)? out, Tensor? add, "
         "Tensor(b!)? dbg, int[] ip, float[] fp) -> ()", &resblock_pair2_bf16cl);
-  m.def("conv1d_split3(Tensor? x, Tensor? w, Tensor? bias, Tensor(a!)? out, Tensor? res, Tensor(b!)? dbg, int[] ip, "
-        "float[] fp) -> ()", &conv1d_split3);
+  m.def("conv1d_split3(Tensor? x, Tensor? w, Tensor? bias, Tensor(a!)? out, Tensor? res, Tensor(b!)? dbg, "
+        "Tensor? col_limit, int[] ip, float[] fp) -> ()", &conv1d_split3);
   // ---- device entry points with flat argument lists (schema derived from the C prototype)
   bind_device<&ov_frame_hops_f32>(m, "frame_hops_f32");
   bind_device<&ov_conv_post_tanh_f32>(m, "conv_post_tanh_f32");

@@ -793,7 +793,7 @@ class ConverterEngine:
             bufs = ws["split3"] = [torch.empty(need, dtype=torch.bfloat16, device=self.device) for _ in range(4 + nk)]
         return [b[:need].view(3, B, L, ch) for b in bufs]
 
-    def _mrf_split(self, stage, u, acc, ws, B, ch, L):
+    def _mrf_split(self, stage, u, acc, ws, B, ch, L, limits=None, rate=1):
         """One MRF stage on the split-precision kernels: u (B, ch, L) fp32 raw -> acc (B, ch, L) fp32 = mean of the
         ResBlock1 outputs.  Tensors between the launches are plane tensors stored ACTIVATED (the producer applies the
         next conv's leaky ReLU before it splits); conv2 reads its residual from the pair's activated input and inverts
@@ -803,6 +803,9 @@ class ConverterEngine:
         bufs = self._split_buffers(ws, B, ch, L)
         xa, t, ping, pong, results = bufs[0], bufs[1], bufs[2], bufs[3], bufs[4:]
         prod = self.split3_products
+        # length-aware work lists (skip_padding): 128-column tiles beyond an utterance's limit are dropped from every
+        # conv's (dense) work list; the two layout kernels stream whole tensors
+        lim = dict(col_limit=limits, col_limit_scale=rate) if limits is not None else {}
 
         def timed(tag, flops, fn):
             if self.profile is None:
@@ -821,10 +824,11 @@ class ConverterEngine:
             for n, (c1, c2) in enumerate(pairs):
                 last = n == len(pairs) - 1
                 flops = 2.0 * ch * ch * c1.K * L * B
-                timed("mrf_split", flops, lambda: split3.launch_conv_split3(c1, cur, t, out_slope=LRELU_SLOPE, products=prod))
+                timed("mrf_split", flops, lambda: split3.launch_conv_split3(c1, cur, t, out_slope=LRELU_SLOPE, products=prod, **lim))
                 dst = results[j] if last else (pong if cur is ping else ping)
                 timed("mrf_split", flops, lambda: split3.launch_conv_split3(c2, t, dst, res=cur, res_slope=LRELU_SLOPE,
-                                                                       out_slope=1.0 if last else LRELU_SLOPE, products=prod))
+                                                                             out_slope=1.0 if last else LRELU_SLOPE,
+                                                                             products=prod, **lim))
                 cur = dst
         ops = list(results[:nk]) + [None] * (3 - nk)
         if nk > 3:
@@ -885,9 +889,9 @@ class ConverterEngine:
             L *= s
             x_ld = L
             if self._split3_on and self.split_resblocks[i] is not None:
-                # split-precision stage (opt-in): computes whole tensors (no length-aware work lists: a superset)
+                # split-precision stage (opt-in); with limits its convs carry the same length-aware work lists
                 acc = free.pop()
-                self._mrf_split(self.split_resblocks[i], u, acc, ws, B, ch, L)
+                self._mrf_split(self.split_resblocks[i], u, acc, ws, B, ch, L, limits=limits, rate=rate)
                 free.append(u)
                 x = acc
                 continue

@@ -35,10 +35,12 @@ def supported(cin, cout, K, dil):
     return bool(_lib.call("ov_conv1d_split3_supported", cin, cout, K, dil))
 
 
-def launch_conv_split3(layer, x, out, res=None, res_slope=1.0, out_slope=1.0, scale=1.0, products=6, nwg=0, dbg=None):
+def launch_conv_split3(layer, x, out, res=None, res_slope=1.0, out_slope=1.0, scale=1.0, products=6, nwg=0, dbg=None,
+                       col_limit=None, col_limit_scale=1):
     """out = split3(lrelu((conv1d(x) + bias [+ res~]) * scale, out_slope)) on torch's current stream.  x (3, B, L, Cin),
     out / res (3, B, L, Cout): contiguous bfloat16 plane tensors; ``x`` is read as stored (activated by its producer),
-    res~ = the inverse leaky ReLU of ``res`` with ``res_slope``."""
+    res~ = the inverse leaky ReLU of ``res`` with ``res_slope``.  ``col_limit`` (int32 [B] on the device) x
+    ``col_limit_scale`` = columns of each utterance that matter: time tiles beyond are neither computed nor written."""
     _, B, L, cin = x.shape
     assert x.shape[0] == 3 and cin == layer.cin and out.shape == (3, B, L, layer.cout)
     for t in (x, out, res):
@@ -46,8 +48,8 @@ def launch_conv_split3(layer, x, out, res=None, res_slope=1.0, out_slope=1.0, sc
     xp, op = B * L * cin, B * L * layer.cout
     if _lib.use_torch_binding():
         _lib.torch_op("conv1d_split3", x, layer.w, layer.bias, out, res, dbg,
-                      [B, L, cin, layer.cout, layer.K, layer.dil, nwg, products, xp, op, op if res is not None else 0],
-                      [res_slope, out_slope, scale])
+                      col_limit, [B, L, cin, layer.cout, layer.K, layer.dil, nwg, products, xp, op,
+                                  op if res is not None else 0, col_limit_scale], [res_slope, out_slope, scale])
         return
     p = _lib.ConvSplit3Params()
     vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
@@ -55,7 +57,7 @@ def launch_conv_split3(layer, x, out, res=None, res_slope=1.0, out_slope=1.0, sc
     p.x_plane, p.out_plane, p.res_plane = xp, op, op if res is not None else 0
     p.B, p.L, p.Cin, p.Cout, p.K, p.dil, p.nwg, p.products = B, L, cin, layer.cout, layer.K, layer.dil, nwg, products
     p.res_slope, p.out_slope, p.scale = res_slope, out_slope, scale
-    p.dbg = vp(dbg)
+    p.dbg, p.col_limit, p.col_limit_scale = vp(dbg), vp(col_limit), col_limit_scale
     stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(_lib.load().ov_conv1d_split3(ctypes.byref(p), stream), "ov_conv1d_split3")
 

@@ -147,3 +147,30 @@ def test_split3_rejects_what_it_has_no_instance_for():
         launch_conv_split3(layer, x, out, products=4)
     with pytest.raises(OvError):
         PackedConvSplit3(_rand(32, 32, 3), None, DEV)
+
+
+@pytest.mark.parametrize("c,k,d,res", [(128, 7, 3, False), (256, 3, 1, True), (64, 11, 1, True)])
+def test_split3_length_aware_work_list(c, k, d, res):
+    """``col_limit``: 128-row time tiles that start at or beyond an utterance's limit are neither computed nor written (the
+    output stays NaN-poisoned there); everything that IS computed is bit-identical to the launch without limits; the dense
+    work list is re-dealt over the workgroups whatever the lengths are (limits 0, 1, mid-tile, a tile boundary, > L)."""
+    B, L = 6, 700
+    w, b, layer = _layer(c, k, d, seed=3)
+    x = _rand(B, c, L, seed=4)
+    xp = to_planes(x.to(DEV), SLOPE)
+    resp = to_planes(_rand(B, c, L, seed=5).to(DEV), SLOPE) if res else None
+    kw = dict(res=resp, res_slope=SLOPE) if res else {}
+    full = torch.empty_like(xp)
+    launch_conv_split3(layer, xp, full, **kw)
+    limits = torch.tensor([0, 1, 300, 128, 9999, 513], dtype=torch.int32, device=DEV)
+    for scale, nwg in ((1, 0), (1, 3), (2, 0)):
+        out = torch.full_like(xp, float("nan"))
+        launch_conv_split3(layer, xp, out, col_limit=limits, col_limit_scale=scale, nwg=nwg, **kw)
+        torch.cuda.synchronize()
+        for bi, lim in enumerate(limits.tolist()):
+            cols = min(L, lim * scale)
+            kept = min(L, (cols + 127) // 128 * 128)              # whole tiles up to the limit
+            assert torch.equal(out[:, bi, :kept], full[:, bi, :kept]), (bi, scale, nwg)
+            assert torch.isnan(out[:, bi, kept:].float()).all(), (bi, scale, nwg)
+    with pytest.raises(Exception):
+        launch_conv_split3(layer, xp, full, col_limit=limits, col_limit_scale=0, **kw)

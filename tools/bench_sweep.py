@@ -112,6 +112,14 @@ def main():
     for skip in (False, True):
         fn = lambda: model.voice_conversion(spec, lengths, se[0], se[1], tau=0.3, noise=noise, skip_padding=skip)[0]
         out[skip] = (timeit(fn), fn().clone())
+    split = {}
+    if args.split_ab:
+        eng = model.engine()
+        eng.use_split_bf16x3(True)
+        for skip in (False, True):
+            fn = lambda: model.voice_conversion(spec, lengths, se[0], se[1], tau=0.3, noise=noise, skip_padding=skip)[0]
+            split[skip] = (timeit(fn), fn().clone())
+        eng.use_split_bf16x3(False)
     same = all(torch.equal(out[True][1][b, :, :256 * int(n)], out[False][1][b, :, :256 * int(n)])
                for b, n in enumerate(lengths.tolist()))
     audio_s = float(lengths.sum()) * 256 / SAMPLE_RATE
@@ -119,7 +127,14 @@ def main():
                       "ms_full_padding": round(out[False][0] * 1e3, 3), "ms_skip_padding": round(out[True][0] * 1e3, 3),
                       "real_time_factor_on_real_audio_full": round(audio_s / out[False][0], 1),
                       "real_time_factor_on_real_audio_skip": round(audio_s / out[True][0], 1),
-                      "valid_samples_bit_identical": same}), flush=True)
+                      "valid_samples_bit_identical": same,
+                      **({"ms_split6_full_padding": round(split[False][0] * 1e3, 3), "ms_split6_skip_padding": round(split[True][0] * 1e3, 3),
+                          "split6_valid_samples_bit_identical": all(
+                              torch.equal(split[True][1][b, :, :256 * int(n)], split[False][1][b, :, :256 * int(n)])
+                              for b, n in enumerate(lengths.tolist())),
+                          "split6_vs_fp32_max_abs_on_valid": max(
+                              float((split[True][1][b, :, :256 * int(n)] - out[True][1][b, :, :256 * int(n)]).abs().max())
+                              for b, n in enumerate(lengths.tolist()))} if split else {})}), flush=True)
 
 
 if __name__ == "__main__":
