@@ -475,3 +475,7 @@ def test_convert_and_extract_se_from_an_mp3_file(tmp_path, synth_sd):
                                            tgt, 0.0, torch.zeros(1, 192, spec.shape[2]), zero_g=True)[0]
     assert (se.cpu() - se_ref).abs().max().item() <= 1e-4
     assert audio.shape == (spec.shape[2] * 256,) and np.abs(audio - o_ref[0, 0].numpy()).max() <= 1e-3
+    # the same call with the opt-in split-precision generator stages (API switch): fp32-level agreement
+    audio_split = tcc.enable_split_bf16x3().convert(mp3_path, se, tgt.to(DEV), output_path=None, tau=0.0)
+    tcc.enable_split_bf16x3(False)
+    assert np.abs(audio_split - o_ref[0, 0].numpy()).max() <= 1e-4 and np.abs(audio_split - audio).max() <= 1e-4
