@@ -96,3 +96,20 @@ def test_configs0_input_decodes_to_the_model_rate():
     y, sr = audio_io.load(CASES["example_reference"], 22050)
     assert sr == 22050 and abs(len(y) / sr - int(g["samples"]) / 44100) < 1e-3
     assert 0.3 < np.abs(y).max() <= 1.0 and np.isfinite(y).all()
+
+
+def test_truncated_prefixed_and_corrupted_streams_decode_without_surprises():
+    """A stream cut mid-frame decodes its whole frames (bit-identical to the full decode there); junk before the first frame
+    and an ID3v1 tag after the last are skipped; corrupted bytes yield finite, clipped samples, not an exception."""
+    data, _ = _load("invalid_keypress")
+    full, _ = mp3.decode(data)
+    for cut in (len(data) - 100, len(data) // 2, 3000):
+        part, _ = mp3.decode(data[:cut])
+        assert 0 < part.shape[1] < full.shape[1] and np.array_equal(part, full[:, :part.shape[1]])
+    wrapped, _ = mp3.decode(b"\x00\x12junk" + data + b"TAG" + bytes(125))
+    assert np.array_equal(wrapped, full)
+    broken = bytearray(data)
+    broken[4000] ^= 0xFF
+    broken[4001] ^= 0x55
+    pcm, _ = mp3.decode(bytes(broken))
+    assert pcm.shape == full.shape and np.isfinite(pcm).all() and np.abs(pcm).max() <= 1.0
