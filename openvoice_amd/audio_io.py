@@ -10,7 +10,7 @@ mean for mono (``librosa.to_mono``), ``resample_kaiser_best`` for rate conversio
 with resampy's own output is NOT pinned (neither package is in this image): it
 follows the published algorithm and filter constants and is tested against closed-form band-limited
 interpolation; the parity boundary of this repo starts at the float32 waveform at the model rate.
-MP3 (MPEG-1 Layer III: what resources/*.mp3 are) is decoded by ``openvoice_amd.mp3``, a decoder written from the
+MP3 (MPEG-1 / 2 / 2.5 Layer III; resources/*.mp3 are MPEG-1) is decoded by ``openvoice_amd.mp3``, a decoder written from the
 standard's decoding process and PINNED against FFmpeg's output (Chromium's build of it: oracle/make_mp3_golden.py,
 tests/test_mp3_cpu.py: identical sample counts, max-abs 5e-5 = 1.5 LSB of 16-bit PCM on the reference's four files).
 """

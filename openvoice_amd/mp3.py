@@ -5,10 +5,11 @@ hot path (it happens once per utterance, before the waveform reaches the GPU).
 
     pcm, rate = decode(open(path, "rb").read())        # float32 [channels, samples], the file's own sampling rate
 
-Scope: MPEG-1 Layer III (32 / 44.1 / 48 kHz), mono / stereo / joint stereo with MS coding, long / short / mixed blocks,
-bit reservoir, CRC-protected frames (the CRC is skipped, not checked), ID3v2 tags, the Xing / Info header frame with LAME's
-gapless fields (encoder delay and padding are trimmed the way FFmpeg trims them).  NOT built: MPEG-2 / 2.5 (LSF) frames
-and intensity stereo -- both raise ``Mp3Error`` naming the feature (none of the reference's resources uses them).
+Scope: Layer III of MPEG-1 (32 / 44.1 / 48 kHz), MPEG-2 (16 / 22.05 / 24 kHz: the LSF extension of ISO/IEC 13818-3 -- what
+24 kHz text-to-speech services return) and MPEG-2.5 (8 / 11.025 / 12 kHz); mono / stereo / joint stereo with MS coding, long /
+short / mixed blocks, bit reservoir, CRC-protected frames (the CRC is skipped, not checked), ID3v2 tags, the Xing / Info header
+frame with LAME's gapless fields (encoder delay and padding are trimmed the way FFmpeg trims them).  NOT built: intensity
+stereo, mixed blocks at 8 kHz -- both raise ``Mp3Error`` naming the feature.
 
 Tables: the standard's Huffman code tables (Annex B, Table B.7), synthesis window (Table B.3) and scalefactor-band
 partitions (Table B.8) are normative data that no formula produces; ``mp3_tables.npz`` holds them, read out of the image's
@@ -28,7 +29,14 @@ class Mp3Error(ValueError):
 
 _T = None                       # tables, loaded on first use
 BITRATES = (0, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320)          # kbit/s, MPEG-1 Layer III
-RATES = (44100, 48000, 32000)
+BITRATES_LSF = (0, 8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160)           # MPEG-2 / 2.5 Layer III
+RATES = (44100, 48000, 32000, 22050, 24000, 16000, 11025, 12000, 8000)                  # table row = 3 * family + index
+FAMILY = {3: 0, 2: 1, 0: 2}        # header version bits -> MPEG-1, MPEG-2 (LSF), MPEG-2.5 (LSF at a quarter of the rates)
+# MPEG-2 LSF scale factors (ISO/IEC 13818-3, 2.4.3.2): bands per partition, by scalefac_compress range and block kind
+# (long, short, mixed); partition i is coded with slen[i] bits per factor
+NR_OF_SFB = (((6, 5, 5, 5), (9, 9, 9, 9), (6, 9, 9, 9)),
+             ((6, 5, 7, 3), (9, 9, 12, 6), (6, 9, 12, 6)),
+             ((11, 10, 0, 0), (18, 18, 0, 0), (15, 18, 0, 0)))
 LINBITS = (0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 2, 3, 4, 6, 8, 10, 13, 4, 5, 6, 7, 8, 9, 11, 13)
 TABLE_OF = (0, 1, 2, 3, 0, 5, 6, 7, 8, 9, 10, 11, 12, 13, 0, 15) + (16,) * 8 + (24,) * 8   # table_select -> code table
 SLEN = ((0, 0, 0, 0, 3, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4), (0, 1, 2, 3, 0, 1, 2, 3, 1, 2, 3, 1, 2, 3, 2, 3))
@@ -71,7 +79,7 @@ def _tables():
     t["long_idx"] = [np.concatenate([[0], np.cumsum(w)]).astype(int) for w in raw["sfb_long_width"]]
     t["short_idx"] = [np.concatenate([[0], np.cumsum(w)]).astype(int) for w in raw["sfb_short_width"]]
     t["long_of_line"], t["short_of_line"], t["short_win_of_line"], t["reorder"], t["reorder_mixed"] = [], [], [], [], []
-    for r in range(3):
+    for r in range(9):
         li, si = t["long_idx"][r], t["short_idx"][r]
         t["long_of_line"].append(np.repeat(np.arange(22), np.diff(li)))
         # short blocks as transmitted: band by band, inside a band window 0's lines, then window 1's, window 2's
@@ -85,6 +93,7 @@ def _tables():
         t["reorder"].append(dst)
         mixed = np.arange(576)
         mixed[36:] = dst[36:]                          # the first two subbands (36 lines = short bands 0..2) stay long
+        # (8 kHz: short bands 0..2 are 72 lines wide; mixed blocks there are not decoded, see decode())
         t["reorder_mixed"].append(mixed)
     t["pow43"] = np.arange(8207, dtype=np.float64) ** (4.0 / 3.0)
     c = np.array(ALIAS_C)
@@ -161,12 +170,21 @@ def _header(data, pos):
     bri, sri, pad = (h >> 12) & 15, (h >> 10) & 3, (h >> 9) & 1
     if version == 1 or layer == 0 or bri == 15 or sri == 3:
         return None
+    fam = FAMILY[version]
     return dict(version=version, layer=layer, crc=prot == 0, bitrate_index=bri, rate_index=sri, padding=pad,
-                mode=(h >> 6) & 3, mode_ext=(h >> 4) & 3)
+                mode=(h >> 6) & 3, mode_ext=(h >> 4) & 3, lsf=fam > 0, row=3 * fam + sri)
 
 
 def _frame_length(hd):
-    return 144000 * BITRATES[hd["bitrate_index"]] // RATES[hd["rate_index"]] + hd["padding"]
+    """Bytes of the frame: 1152 samples per frame for MPEG-1, 576 (one granule) for the LSF families."""
+    if hd["lsf"]:
+        return 72000 * BITRATES_LSF[hd["bitrate_index"]] // RATES[hd["row"]] + hd["padding"]
+    return 144000 * BITRATES[hd["bitrate_index"]] // RATES[hd["row"]] + hd["padding"]
+
+
+def _side_len(hd):
+    mono = hd["mode"] == 3
+    return (9 if mono else 17) if hd["lsf"] else (17 if mono else 32)
 
 
 def _first_frame(data):
@@ -174,8 +192,8 @@ def _first_frame(data):
     while pos + 4 <= len(data):
         hd = _header(data, pos)
         if hd is not None and hd["bitrate_index"] != 0:
-            if hd["version"] != 3 or hd["layer"] != 1:
-                raise Mp3Error("only MPEG-1 Layer III is built (this stream is MPEG-2 / 2.5 (LSF) or another layer)")
+            if hd["layer"] != 1:
+                raise Mp3Error("only Layer III is built (this stream is MPEG audio Layer I or II)")
             nxt = _header(data, pos + _frame_length(hd))
             if nxt is not None or pos + _frame_length(hd) >= len(data) - 4:
                 return pos, hd
@@ -186,9 +204,9 @@ def _first_frame(data):
 def probe(data):
     """Sampling rate, channel count and the gapless fields of the Xing / Info + LAME header (if any)."""
     pos, hd = _first_frame(data)
-    info = dict(sample_rate=RATES[hd["rate_index"]], channels=1 if hd["mode"] == 3 else 2, first_frame=pos, xing=False,
-                frames=None, start_pad=0, end_pad=0)
-    side = 17 if hd["mode"] == 3 else 32
+    info = dict(sample_rate=RATES[hd["row"]], channels=1 if hd["mode"] == 3 else 2, first_frame=pos, xing=False,
+                frames=None, start_pad=0, end_pad=0, lsf=hd["lsf"])
+    side = _side_len(hd)
     tag = pos + 4 + side                              # (the header frame carries no CRC in practice; FFmpeg assumes so too)
     if data[tag:tag + 4] in (b"Xing", b"Info"):
         info["xing"] = True
@@ -238,6 +256,64 @@ def _side_info(br, nch):
     return si
 
 
+def _side_info_lsf(br, nch):
+    """MPEG-2 / 2.5 side information (ISO/IEC 13818-3, 2.4.1.7): one granule per frame, no scfsi, 9-bit
+    scalefac_compress, no preflag bit (it follows from scalefac_compress)."""
+    si = dict(main_data_begin=br.get(8))
+    br.get(1 if nch == 1 else 2)
+    chans = []
+    for _ in range(nch):
+        g = dict(part2_3_length=br.get(12), big_values=br.get(9), global_gain=br.get(8), scalefac_compress=br.get(9),
+                 window_switching=br.get(1))
+        if g["window_switching"]:
+            g["block_type"], g["mixed"] = br.get(2), br.get(1)
+            g["table_select"] = [br.get(5), br.get(5), 0]
+            g["subblock_gain"] = [br.get(3), br.get(3), br.get(3)]
+            if g["block_type"] == 0:
+                raise Mp3Error("invalid stream: window switching with block type 0")
+            g["region0_count"], g["region1_count"] = (8 if g["block_type"] == 2 and not g["mixed"] else 7), 36
+        else:
+            g["block_type"], g["mixed"] = 0, 0
+            g["table_select"] = [br.get(5), br.get(5), br.get(5)]
+            g["subblock_gain"] = [0, 0, 0]
+            g["region0_count"], g["region1_count"] = br.get(4), br.get(3)
+        g["scalefac_scale"], g["count1table_select"] = br.get(1), br.get(1)
+        g["preflag"] = 1 if g["scalefac_compress"] >= 500 else 0
+        chans.append(g)
+    si["scfsi"] = [[0, 0, 0, 0] for _ in range(nch)]
+    si["gr"] = [chans]
+    return si
+
+
+def _scalefactors_lsf(br, g):
+    """LSF scale factors: scalefac_compress selects four bit widths and, with the block kind, how many bands each
+    partition holds (NR_OF_SFB); the factors follow band by band (short blocks: the three windows of a band in turn)."""
+    sfc = g["scalefac_compress"]
+    if sfc < 400:
+        slen, row = ((sfc >> 4) // 5, (sfc >> 4) % 5, (sfc % 16) >> 2, sfc % 4), 0
+    elif sfc < 500:
+        sfc -= 400
+        slen, row = ((sfc >> 2) // 5, (sfc >> 2) % 5, sfc % 4, 0), 1
+    else:
+        sfc -= 500
+        slen, row = (sfc // 3, sfc % 3, 0, 0), 2
+    kind = 0 if g["block_type"] != 2 else (2 if g["mixed"] else 1)
+    vals = []
+    for n, bits in zip(NR_OF_SFB[row][kind], slen):
+        vals += [br.get(bits) for _ in range(n)]
+    long_sf, short_sf = [0] * 22, [[0, 0, 0] for _ in range(13)]
+    if kind == 0:
+        long_sf[:len(vals)] = vals
+    else:
+        first = 0
+        if kind == 2:                                   # mixed: 6 long bands, then the short bands from band 3 on
+            long_sf[:6] = vals[:6]
+            vals, first = vals[6:], 3
+        for i, v in enumerate(vals):
+            short_sf[first + i // 3][i % 3] = v
+    return long_sf, short_sf
+
+
 def _scalefactors(br, g, scfsi, prev_long):
     """Scale factors of one (granule, channel): (long [22], short [13][3]); ``prev_long`` = granule 0's long factors of
     this channel when scfsi may reuse them (granule 1), else None.  ISO 11172-3 2.4.2.7 / 2.4.3.4.5."""
@@ -274,7 +350,9 @@ def _huffman(br, g, end, rate_index, t):
     big = min(g["big_values"] * 2, 576)
     li = t["long_idx"][rate_index]
     if g["window_switching"]:
-        r1, r2 = 36, 576
+        # region 0 ends after short band 2 (3 x 12 lines) / long band 7 -- both 36 lines at the MPEG-1 rates, 54 / 36 at the
+        # LSF rates' band tables (and 108 / 72 at 8 kHz); region 1 takes the rest
+        r1, r2 = (3 * int(t["short_idx"][rate_index][3]) if g["block_type"] == 2 else int(li[8])), 576
     else:
         r1 = int(li[min(g["region0_count"] + 1, 22)])
         r2 = int(li[min(g["region0_count"] + g["region1_count"] + 2, 22)])
@@ -380,28 +458,29 @@ def decode(data, trim_gapless=True, clip=True):
                 break
             pos = nxt
             continue
-        if hd["version"] != 3 or hd["layer"] != 1:
-            raise Mp3Error("only MPEG-1 Layer III is built (this stream is MPEG-2 / 2.5 (LSF) or another layer)")
+        if hd["layer"] != 1:
+            raise Mp3Error("only Layer III is built (this stream is MPEG audio Layer I or II)")
         flen = _frame_length(hd)
         if pos + flen > len(data):
             break
         frame_nch = 1 if hd["mode"] == 3 else 2
-        if frame_nch != nch or RATES[hd["rate_index"]] != rate:
+        if frame_nch != nch or RATES[hd["row"]] != rate:
             raise Mp3Error("channel count / sampling rate changes inside the stream")
-        side_len = 17 if nch == 1 else 32
+        side_len = _side_len(hd)
+        ngr, row = (1 if hd["lsf"] else 2), hd["row"]
         body = pos + 4 + (2 if hd["crc"] else 0)
         if first and info["xing"]:
             first = False                              # the Xing / Info frame carries the header, not audio
             pos += flen
             continue
         first = False
-        si = _side_info(_Bits(data, body * 8), nch)
+        si = (_side_info_lsf if hd["lsf"] else _side_info)(_Bits(data, body * 8), nch)
         main = data[body + side_len:pos + flen]
         if si["main_data_begin"] > len(reservoir):
             # the stream was cut before this frame's reservoir: its granules cannot be decoded -> silence (as FFmpeg)
             reservoir = (reservoir + main)[-511:]
             for ch in range(nch):
-                subband_slots[ch].append(np.zeros((36, 32)))
+                subband_slots[ch].append(np.zeros((18 * ngr, 32)))
             pos += flen
             frames += 1
             continue
@@ -412,16 +491,21 @@ def decode(data, trim_gapless=True, clip=True):
             raise Mp3Error("intensity stereo is not built")
         ms = hd["mode"] == 1 and bool(hd["mode_ext"] & 2)
         sf0 = [None] * nch
-        for gr in range(2):
+        for gr in range(ngr):
             xr = np.zeros((nch, 576))
             for ch in range(nch):
                 g = si["gr"][gr][ch]
                 start = br.pos
-                long_sf, short_sf = _scalefactors(br, g, si["scfsi"][ch], sf0[ch] if gr == 1 else None)
+                if g["block_type"] == 2 and g["mixed"] and row == 8:
+                    raise Mp3Error("mixed blocks at 8 kHz (MPEG-2.5) are not built")
+                if hd["lsf"]:
+                    long_sf, short_sf = _scalefactors_lsf(br, g)
+                else:
+                    long_sf, short_sf = _scalefactors(br, g, si["scfsi"][ch], sf0[ch] if gr == 1 else None)
                 if gr == 0:
                     sf0[ch] = long_sf
-                isamp = _huffman(br, g, start + g["part2_3_length"], hd["rate_index"], t)
-                xr[ch] = _requantise(isamp, g, long_sf, short_sf, hd["rate_index"], t)
+                isamp = _huffman(br, g, start + g["part2_3_length"], row, t)
+                xr[ch] = _requantise(isamp, g, long_sf, short_sf, row, t)
             if ms:
                 m, s = xr[0].copy(), xr[1].copy()
                 xr[0], xr[1] = (m + s) / np.sqrt(2.0), (m - s) / np.sqrt(2.0)
@@ -430,7 +514,7 @@ def decode(data, trim_gapless=True, clip=True):
                 x = xr[ch]
                 if g["block_type"] == 2:               # short blocks: band-by-band order -> 3 k + window inside a subband
                     y = np.zeros(576)
-                    y[t["reorder_mixed" if g["mixed"] else "reorder"][hd["rate_index"]]] = x
+                    y[t["reorder_mixed" if g["mixed"] else "reorder"][row]] = x
                     x = y
                 x = x.reshape(32, 18).copy()
                 nlong = 32 if g["block_type"] != 2 else (2 if g["mixed"] else 0)
@@ -455,7 +539,8 @@ def decode(data, trim_gapless=True, clip=True):
         raise Mp3Error("no decodable frame")
     # ---- polyphase synthesis, all time slots at once: V = S N, out[t][j] = sum_i D[64 i + j] V[t - 2 i][j] + D[64 i + 32 + j] V[t - 2 i - 1][32 + j]
     win = t["window"]
-    pcm = np.empty((nch, frames * 1152), dtype=np.float32)
+    spf = 576 if info["lsf"] else 1152
+    pcm = np.empty((nch, frames * spf), dtype=np.float32)
     for ch in range(nch):
         s = np.concatenate(subband_slots[ch], axis=0)                       # [slots][32]
         v = np.concatenate([np.zeros((16, 64)), s @ t["synth"]], axis=0)    # 16 slots of history
@@ -468,7 +553,7 @@ def decode(data, trim_gapless=True, clip=True):
     if trim_gapless and info["xing"] and (info["start_pad"] or info["end_pad"]):
         # what FFmpeg's demuxer does with the LAME fields: skip start_pad + 528 + 1 samples, end at
         # frames * 1152 - end_pad + 528 + 1 (the decoder itself delays the signal by 528 + 1 samples)
-        total = (info["frames"] if info["frames"] else frames) * 1152
+        total = (info["frames"] if info["frames"] else frames) * spf
         a = info["start_pad"] + 529
         b = min(pcm.shape[1], max(a, total - info["end_pad"] + 529))
         pcm = pcm[:, a:b]

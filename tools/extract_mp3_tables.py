@@ -68,14 +68,15 @@ def main():
         kraft_and_prefix(quad[1, t], quad[0, t])
     out["count1_len"], out["count1_code"] = quad[0], quad[1]
     print("count1 tables A, B: complete prefix codes")
-    # ---- scalefactor-band widths: long[9][22], short[9][13] (uint8); rows 0..2 = 44100, 48000, 32000 Hz (MPEG-1)
+    # ---- scalefactor-band widths: long[9][22], short[9][13] (uint8), one row per sampling rate
     long_w = np.frombuffer(mm[sfb:sfb + 9 * 22], dtype=np.uint8).copy().reshape(9, 22)
     sfs = mm.find(bytes([4, 4, 4, 4, 6, 8, 10, 12, 14, 18, 22, 30, 56]))       # short-block widths at 44.1 kHz
     assert sfs > 0, "short scalefactor-band widths not found"
     short_w = np.frombuffer(mm[sfs:sfs + 9 * 13], dtype=np.uint8).copy().reshape(9, 13)
     assert (long_w.sum(1) == 576).all() and (short_w.sum(1) == 192).all(), (long_w.sum(1), short_w.sum(1))
-    out["sfb_long_width"], out["sfb_short_width"] = long_w[:3], short_w[:3]
-    print("scalefactor bands: long", long_w[:3].tolist(), "short", short_w[:3].tolist())
+    # rows: 44100, 48000, 32000 (MPEG-1), 22050, 24000, 16000 (MPEG-2), 11025, 12000, 8000 Hz (MPEG-2.5)
+    out["sfb_long_width"], out["sfb_short_width"] = long_w, short_w
+    print("scalefactor bands: long", long_w.tolist(), "short", short_w.tolist())
     # ---- synthesis window: first half (257 int32) of C[i] * 2^21 = D[i] * 65536
     w = mm.find(struct.pack("<16i", 0, -1, -1, -1, -1, -1, -1, -2, -2, -2, -2, -3, -3, -4, -4, -5))
     assert w > 0, "Table B.3 not found"
