@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
-"""Golden vectors for the MPEG-2 / 2.5 (LSF) half of openvoice_amd/mp3.py.
+"""Synthetic-bitstream golden vectors for openvoice_amd/mp3.py: the MPEG-2 / 2.5 (LSF) half, and the corners of MPEG-1 the
+five real files do not reach (mixed blocks, scfsi patterns, the preflag bit, a 511-byte-deep bit reservoir, 32 / 48 kHz).
 
 No LSF stream exists in this image (the reference's resources are MPEG-1), and nothing here can encode audio to MP3.  What
 a decoder test needs, though, is not audio but VALID BITSTREAMS with known decodes: this script writes Layer III frames
 directly -- random quantised spectra, scale factors, block types (long / start / short / stop / mixed), table selections,
-region splits, MS stereo -- with its own bit packer (header, LSF side information, LSF scale-factor partitions, Huffman
-coding of the big-values and count1 regions from the standard's tables), one stream per sampling-rate family, and has the
-image's Chromium (FFmpeg) decode them through oracle/make_mp3_golden.chromium_decode.  The streams and their decodes are
-committed as tests/golden/mp3_lsf_*.npz; tests/test_mp3_cpu.py decodes the stream with openvoice_amd.mp3 and compares.
+region splits, MS stereo -- with its own bit packer (header, MPEG-1 or LSF side information, their scale-factor codings,
+Huffman coding of the big-values and count1 regions from the standard's tables; for MPEG-1 the main data of all frames laid
+out as one continuous stream so that granules start in earlier frames), and has the image's Chromium (FFmpeg) decode them
+through oracle/make_mp3_golden.chromium_decode.  The streams and their decodes are committed as tests/golden/mp3_lsf_*.npz /
+mp3_syn_*.npz; tests/test_mp3_cpu.py decodes the stream with openvoice_amd.mp3 and compares.
 Test infrastructure, build container only.
 
-    python oracle/make_mp3_lsf_golden.py"""
+    python oracle/make_mp3_synthetic_golden.py"""
 import os
 import sys
 
@@ -118,14 +120,42 @@ def encode_granule(rng, raw, row, force_kind=None, force=None):
         assert sfc < 512
     g["scalefac_compress"] = sfc
     bk = 0 if g["block_type"] != 2 else (2 if g["mixed"] else 1)
+    if force.get("mpeg1"):
+        # MPEG-1 scale factors (ISO 11172-3 2.4.2.7): 4-bit scalefac_compress -> (slen1, slen2); long blocks in four band
+        # groups that granule 1 may inherit from granule 0 (scfsi); a preflag BIT
+        sfc = int(rng.integers(0, 16))
+        g["scalefac_compress"] = sfc
+        g["preflag"] = int(rng.integers(0, 2)) if g["block_type"] != 2 else 0
+        slen1, slen2 = mp3.SLEN[0][sfc], mp3.SLEN[1][sfc]
+        bw = BitWriter()
+        rnd = lambda bits: bw.put(int(rng.integers(0, 1 << bits)) if bits else 0, bits)
+        if g["block_type"] == 2:
+            if g["mixed"]:
+                for _ in range(8):
+                    rnd(slen1)
+                for _ in range(3 * 3):
+                    rnd(slen1)
+            else:
+                for _ in range(6 * 3):
+                    rnd(slen1)
+            for _ in range(6 * 3):
+                rnd(slen2)
+        else:
+            scfsi = force.get("scfsi", [0, 0, 0, 0])
+            for grp, cnt in enumerate((6, 5, 5, 5)):
+                if not scfsi[grp]:
+                    for _ in range(cnt):
+                        rnd(slen1 if grp < 2 else slen2)
+        sl = None
     if "sl" in force:
         sl = list(force["sl"])
         sfc = {0: ((sl[0] * 5 + sl[1]) << 4) | (sl[2] << 2) | sl[3], 1: 400 + (((sl[0] * 5 + sl[1]) << 2) | sl[2]), 2: 500 + sl[0] * 3 + sl[1]}[rng_range]
         g["scalefac_compress"] = sfc
-    bw = BitWriter()
-    for n, bits in zip(mp3.NR_OF_SFB[rng_range][bk], sl):
-        for _ in range(n):
-            bw.put(int(rng.integers(0, 1 << bits)) if bits else 0, bits)
+    if sl is not None:
+        bw = BitWriter()
+        for n, bits in zip(mp3.NR_OF_SFB[rng_range][bk], sl):
+            for _ in range(n):
+                bw.put(int(rng.integers(0, 1 << bits)) if bits else 0, bits)
     # ---- Huffman: big values per region, then count1
     lo = 0
     for region, hi in enumerate(bounds):
@@ -230,6 +260,105 @@ def make_stream(seed, version_bits, sr_index, stereo, frames=60, force=None, kin
     return bytes(out), rate, nch
 
 
+def make_stream_v1(seed, sr_index, stereo, frames=50):
+    """MPEG-1 frames: two granules, scfsi, 4-bit scalefac_compress, preflag bit -- and a REAL bit reservoir: the main data
+    of all frames is one continuous bit stream laid into the frames' data areas back to back, so that a frame's granules
+    may start in earlier frames (main_data_begin > 0) exactly as encoders do it."""
+    raw = np.load(os.path.join(REPO, "openvoice_amd", "mp3_tables.npz"))
+    rng = np.random.default_rng(seed)
+    rate = mp3.RATES[sr_index]
+    nch = 2 if stereo else 1
+    bri = 13                                             # 256 kbit/s
+    side_len = 17 if nch == 1 else 32
+    first_ms = bool(seed % 2)
+    state = [0] * nch
+    frames_side, frames_main, lens = [], [], []
+    for f in range(frames):
+        ms = stereo and (rng.random() < 0.5 if f >= 6 else first_ms)
+        mode, mode_ext = (3, 0) if not stereo else ((1, 2) if ms else (0, 0))
+        pad = int(rng.integers(0, 2)) if rate == 44100 else 0
+        hdr = (0x7FF << 21) | (3 << 19) | (1 << 17) | (1 << 16) | (bri << 12) | (sr_index << 10) | (pad << 9) | (mode << 6) | (mode_ext << 4)
+        grs = [[None] * nch for _ in range(2)]
+        scfsi = [[0, 0, 0, 0] for _ in range(nch)]
+        for ch in range(nch):
+            kinds = []
+            for gr in range(2):
+                prev = state[ch]
+                if prev in (0, 1, 4):
+                    k = int(rng.choice([0, 1, 2, 2]))
+                elif prev == 2:
+                    k = int(rng.choice([3, 5]))
+                else:
+                    k = int(rng.choice([prev, 4, 4]))
+                state[ch] = k
+                kinds.append(k)
+            if kinds[0] not in (3, 5) and kinds[1] not in (3, 5):     # scfsi only between two long-type granules
+                scfsi[ch] = [int(v) for v in rng.integers(0, 2, 4)]
+            grs[0][ch] = encode_granule(rng, raw, sr_index, kinds[0], dict(mpeg1=True))
+            grs[1][ch] = encode_granule(rng, raw, sr_index, kinds[1], dict(mpeg1=True, scfsi=scfsi[ch]))
+        main = BitWriter()
+        for gr in range(2):
+            for ch in range(nch):
+                main.bits += grs[gr][ch][1].bits
+        while len(main) % 8:
+            main.bits.append(0)
+        frames_main.append(main)
+        frames_side.append((hdr, pad, scfsi, grs))
+        lens.append(144000 * mp3.BITRATES[bri] // rate + pad)
+    # lay the main data out: frame f's bytes go as early as possible, at most 511 bytes before its own data area and never
+    # before the end of frame f - 1's
+    out = bytearray()
+    pool = bytearray()                                   # all data areas so far, concatenated
+    cursor = 0                                           # first free byte of the pool
+    starts = []
+    area_start = []
+    for f in range(frames):
+        area_start.append(len(pool))
+        pool += bytes(lens[f] - 4 - side_len)
+        mbytes = frames_main[f].tobytes(len(frames_main[f]) // 8)
+        begin = max(cursor, area_start[f] - 511)
+        assert begin + len(mbytes) <= len(pool), "granules do not fit: lower the spectra or raise the bit rate"
+        pool[begin:begin + len(mbytes)] = mbytes
+        starts.append(area_start[f] - begin)             # main_data_begin of frame f
+        cursor = begin + len(mbytes)
+    for f in range(frames):
+        hdr, pad, scfsi, grs = frames_side[f]
+        side = BitWriter()
+        side.put(starts[f], 9)
+        side.put(0, 5 if nch == 1 else 3)
+        for ch in range(nch):
+            for v in scfsi[ch]:
+                side.put(v, 1)
+        for gr in range(2):
+            for ch in range(nch):
+                g = grs[gr][ch][0]
+                side.put(g["part2_3_length"], 12)
+                side.put(g["big_values"], 9)
+                side.put(g["global_gain"], 8)
+                side.put(g["scalefac_compress"], 4)
+                side.put(g["window_switching"], 1)
+                if g["window_switching"]:
+                    side.put(g["block_type"], 2)
+                    side.put(g["mixed"], 1)
+                    side.put(g["table_select"][0], 5)
+                    side.put(g["table_select"][1], 5)
+                    for v in g["subblock_gain"]:
+                        side.put(v, 3)
+                else:
+                    for v in g["table_select"]:
+                        side.put(v, 5)
+                    side.put(g["region0_count"], 4)
+                    side.put(g["region1_count"], 3)
+                side.put(g["preflag"], 1)
+                side.put(g["scalefac_scale"], 1)
+                side.put(g["count1table_select"], 1)
+        assert len(side) == side_len * 8
+        a = area_start[f]
+        out += hdr.to_bytes(4, "big") + side.tobytes(side_len) + bytes(pool[a:a + lens[f] - 4 - side_len])
+    return bytes(out), rate, nch, max(starts)
+
+
+CASES_V1 = [("mpeg1_44100_mono_reservoir", 21, 0, False), ("mpeg1_48000_stereo_ms", 22, 1, True), ("mpeg1_32000_mono", 23, 2, False)]
 CASES = [("mpeg2_22050_mono", 11, 2, 0, False), ("mpeg2_24000_stereo_ms", 12, 2, 1, True), ("mpeg2_16000_mono", 13, 2, 2, False),
          ("mpeg25_11025_stereo", 14, 0, 0, True), ("mpeg25_12000_mono", 15, 0, 1, False)]
 
@@ -241,6 +370,15 @@ def main():
     with open(js, "w") as fh:
         fh.write(FAKE_PLOTLY)
     scope = PlotlyScope(plotlyjs=js)
+    for name, seed, sri, stereo in CASES_V1:
+        data, rate, nch, deepest = make_stream_v1(seed, sri, stereo)
+        pcm = chromium_decode(data, nch, rate, scope)
+        mine, _ = mp3.decode(data)
+        n = min(pcm.shape[1], mine.shape[1])
+        print(name, "stream", len(data), "bytes, reservoir up to", deepest, "bytes; chromium", pcm.shape, "peak",
+              float(np.abs(pcm).max()), "| this decoder", mine.shape, "max-abs difference", float(np.abs(pcm[:, :n] - mine[:, :n]).max()))
+        np.savez_compressed(os.path.join(REPO, "tests", "golden", f"mp3_syn_{name}.npz"), stream=np.frombuffer(data, dtype=np.uint8),
+                            pcm=pcm, rate=rate, channels=nch)
     for name, seed, vbits, sri, stereo in CASES:
         data, rate, nch = make_stream(seed, vbits, sri, stereo)
         pcm = chromium_decode(data, nch, rate, scope)

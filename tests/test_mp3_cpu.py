@@ -75,6 +75,21 @@ def test_unsupported_streams_are_named():
         mp3.decode(bytes(layer2))
 
 
+SYN_CASES = ["mpeg1_44100_mono_reservoir", "mpeg1_48000_stereo_ms", "mpeg1_32000_mono"]
+
+
+@pytest.mark.parametrize("name", SYN_CASES)
+def test_synthetic_mpeg1_streams_match_ffmpeg_golden(name):
+    """MPEG-1 corners the real files do not reach -- mixed blocks, random scfsi patterns, the preflag bit, both count1
+    tables, a bit reservoir used to its 511-byte limit, the padding bit, 32 and 48 kHz -- on synthetic bitstreams written by
+    oracle/make_mp3_synthetic_golden.py and decoded by FFmpeg (Chromium); stream + decode are in the fixture."""
+    g = np.load(os.path.join(GOLDEN, f"mp3_syn_{name}.npz"))
+    data, want = bytes(g["stream"]), g["pcm"]
+    pcm, rate = mp3.decode(data)
+    assert rate == int(g["rate"]) and pcm.shape == want.shape == (int(g["channels"]), 50 * 1152)
+    assert np.abs(want).max() > 0.02 and np.abs(pcm - want).max() <= 1e-4
+
+
 LSF_CASES = ["mpeg2_22050_mono", "mpeg2_24000_stereo_ms", "mpeg2_16000_mono", "mpeg25_11025_stereo", "mpeg25_12000_mono"]
 
 
@@ -83,7 +98,7 @@ def test_lsf_streams_match_ffmpeg_golden(name):
     """MPEG-2 (16 / 22.05 / 24 kHz) and MPEG-2.5 (11.025 / 12 kHz) Layer III -- the LSF syntax of ISO/IEC 13818-3: one granule
     per frame, 9-bit scalefac_compress with its three ranges and the bands-per-partition table, no scfsi, its own band
     tables.  No LSF file exists in the image and nothing here encodes audio, so the vectors are SYNTHETIC BITSTREAMS written
-    frame by frame by oracle/make_mp3_lsf_golden.py (random spectra incl. escape values and count1 quadruples, scale
+    frame by frame by oracle/make_mp3_synthetic_golden.py (random spectra incl. escape values and count1 quadruples, scale
     factors, every block kind in legal window sequences, random region splits and table selections, MS stereo) and decoded
     by FFmpeg inside the image's Chromium; stream and decode are both in the fixture, so this runs everywhere.  Bar: 1e-4
     (FFmpeg's decoder there is the fixed-point one: 1 LSB of 16-bit PCM = 3.05e-5)."""
