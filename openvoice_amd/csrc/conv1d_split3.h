@@ -399,8 +399,15 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
   typedef const __attribute__((address_space(1))) u32x4* gw_ptr;
   const gw_ptr wall = (gw_ptr)(p.w);
   gw_ptr wp = wall;
-  u32x4 wq[2][3][2];                       // [pair parity][plane][f]: the pair in use + the pair being requested
-  auto wrequest = [&](int par, int r) {    // record r (= 2 plane + f) of the next pair; r, par compile-time
+  // Weight ring: WR sets of a pair's six records.  Wave tiles of 128 rows (JW = 8): two sets, the next pair (96 MFMAs =
+  // 1 540 cycles away) is requested while the current one runs; slot = pair parity, static because the chunk loop is
+  // unrolled by two (2 K pairs).  Wave tiles of 64 rows (JW = 4, C = 64): a pair is only 48 MFMAs (770 cycles, about one L2
+  // round trip under load: the k-loops ran at 1.30x their MFMA issue time, profiles/r05_s6), so FOUR sets and requests TWO
+  // pairs ahead; slot = tap % 4 -- any three consecutive pairs then sit in distinct slots for K in {3, 7, 11} (K % 4 = 3:
+  // ... K-2 -> 1, K-1 -> 2, next chunk's 0 -> 0, 1 -> 1), static without any unrolling.
+  constexpr int WR = JW == 4 ? 4 : 2, WAHEAD = WR == 4 ? 2 : 1;
+  u32x4 wq[WR][3][2];                      // [ring slot][plane][f]
+  auto wrequest = [&](int par, int r) {    // record r (= 2 plane + f) of the pair being requested; r, par compile-time
     asm volatile("" : "+s"(wp));           // opaque: scalar base + lane offset, not hoisted out of the step loop
     if (NPL == 3 || r < 4) wq[par][r >> 1][r & 1] = wp[lane + 64 * r];
   };
@@ -422,11 +429,13 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
   __syncthreads();                                    // (init; the helper waves' matching s_barrier)
   if (dbg) tlast = __builtin_readcyclecounter();
   int n = 0, nstep = 0;
-  {                                                   // first pair of the first step
+  {                                                   // first pair(s) of the first step
     const Step st(g0, ntiles, nmb, pref, p.B);
     wp = wall + (size_t)(NCT * st.mb + ct) * G::NPAIR * 6 * 64;
-    static_for<0, 6>([&](auto rc) { wrequest(0, decltype(rc)::value); });
-    wp += 6 * 64;
+    static_for<0, WAHEAD>([&](auto qc) {
+      static_for<0, 6>([&](auto rc) { wrequest(decltype(qc)::value, decltype(rc)::value); });
+      wp += 6 * 64;
+    });
   }
   for (long s = g0; s < g1; ++s, ++nstep) {
     const Step st(s, ntiles, nmb, pref, p.B);
@@ -469,9 +478,11 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
           for (int jj = 0; jj < 2; ++jj) xq[0][pl][jj] = oread(xlb[0], pl, jj);
         static_for<0, K>([&](auto tc) {
           constexpr int tap = decltype(tc)::value;
-          constexpr int par = (ci * K + tap) & 1;     // weight-ring parity of this pair (2 K pairs per iteration: static)
-          if constexpr (ci == 1 && tap == K - 1) {
-            // the next pair is chunk pair 0 of the next iteration -- or of the next step (whose output tile may differ)
+          constexpr int par = WR == 4 ? tap % 4 : (ci * K + tap) & 1;      // ring slot of this pair
+          constexpr int rtap = (tap + WAHEAD) % K;                           // tap of the pair requested during this one
+          constexpr int rpar = WR == 4 ? rtap % 4 : par ^ 1;                 // ... and its slot
+          if constexpr (ci == 1 && tap == K - WAHEAD) {
+            // the pair requested now is pair 0 of the next iteration -- or of the next step (whose output tile may differ)
             if (it + 1 == NCH / 2) wp = wall + (size_t)(NCT * nx.mb + ct) * G::NPAIR * 6 * 64;
           }
           constexpr int JB = JW / 2;                  // blocks per pair
@@ -500,7 +511,7 @@ __global__ __launch_bounds__(64 * (NMW + NIN + NOUT)) void conv1d_split3_kernel(
                 if constexpr (m < 2 * NPL) {
                   if constexpr (more) xq[nb][m >> 1][m & 1] = oread(xlb[ntap < K ? ntap : 0], m >> 1, 2 * njh + (m & 1));
                 } else if constexpr (jh == 0 && m >= RQ0 && (m - RQ0) % 2 == 0 && (m - RQ0) / 2 < 2 * NPL) {
-                  wrequest(par ^ 1, (m - RQ0) / 2);   // all of the next pair's records in the first block: earliest possible
+                  wrequest(rpar, (m - RQ0) / 2);      // all of that pair's records in the first block: earliest possible
                 } else if constexpr (m == MPB - 1 && jh == JB - 1) {
                   wp += 6 * 64;
                 }
