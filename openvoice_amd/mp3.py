@@ -6,10 +6,12 @@ hot path (it happens once per utterance, before the waveform reaches the GPU).
     pcm, rate = decode(open(path, "rb").read())        # float32 [channels, samples], the file's own sampling rate
 
 Scope: Layer III of MPEG-1 (32 / 44.1 / 48 kHz), MPEG-2 (16 / 22.05 / 24 kHz: the LSF extension of ISO/IEC 13818-3 -- what
-24 kHz text-to-speech services return) and MPEG-2.5 (8 / 11.025 / 12 kHz); mono / stereo / joint stereo with MS coding, long /
-short / mixed blocks, bit reservoir, CRC-protected frames (the CRC is skipped, not checked), ID3v2 tags, the Xing / Info header
-frame with LAME's gapless fields (encoder delay and padding are trimmed the way FFmpeg trims them).  NOT built: intensity
-stereo, mixed blocks at 8 kHz -- both raise ``Mp3Error`` naming the feature.
+24 kHz text-to-speech services return) and MPEG-2.5 (8 / 11.025 / 12 kHz); mono / stereo / joint stereo with MS and
+intensity coding, long / short / mixed blocks, bit reservoir, CRC-protected frames (the CRC is skipped, not checked), ID3v2
+tags, the Xing / Info header frame with LAME's gapless fields (encoder delay and padding are trimmed the way FFmpeg trims
+them).  NOT built: mixed blocks at 8 kHz (``Mp3Error`` names them) -- the one place where the standard's two rules
+disagree (long bands 0..5 are 72 lines there, the long-windowed part of a mixed block 36) and FFmpeg, the decoder of the
+reference's chain, has no defined behaviour either (it asks for a sample file).
 
 Tables: the standard's Huffman code tables (Annex B, Table B.7), synthesis window (Table B.3) and scalefactor-band
 partitions (Table B.8) are normative data that no formula produces; ``mp3_tables.npz`` holds them, read out of the image's
@@ -36,7 +38,11 @@ FAMILY = {3: 0, 2: 1, 0: 2}        # header version bits -> MPEG-1, MPEG-2 (LSF)
 # (long, short, mixed); partition i is coded with slen[i] bits per factor
 NR_OF_SFB = (((6, 5, 5, 5), (9, 9, 9, 9), (6, 9, 9, 9)),
              ((6, 5, 7, 3), (9, 9, 12, 6), (6, 9, 12, 6)),
-             ((11, 10, 0, 0), (18, 18, 0, 0), (15, 18, 0, 0)))
+             ((11, 10, 0, 0), (18, 18, 0, 0), (15, 18, 0, 0)),
+             # the right channel of an intensity-stereo frame (its factors are intensity positions above the bound):
+             ((7, 7, 7, 0), (12, 12, 12, 0), (6, 15, 12, 0)),
+             ((6, 6, 6, 3), (12, 9, 9, 6), (6, 12, 9, 6)),
+             ((8, 8, 5, 0), (15, 12, 9, 0), (6, 18, 9, 0)))
 LINBITS = (0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 2, 3, 4, 6, 8, 10, 13, 4, 5, 6, 7, 8, 9, 11, 13)
 TABLE_OF = (0, 1, 2, 3, 0, 5, 6, 7, 8, 9, 10, 11, 12, 13, 0, 15) + (16,) * 8 + (24,) * 8   # table_select -> code table
 SLEN = ((0, 0, 0, 0, 3, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4), (0, 1, 2, 3, 0, 1, 2, 3, 1, 2, 3, 1, 2, 3, 2, 3))
@@ -285,11 +291,24 @@ def _side_info_lsf(br, nch):
     return si
 
 
-def _scalefactors_lsf(br, g):
+def _scalefactors_lsf(br, g, intensity_right=False):
     """LSF scale factors: scalefac_compress selects four bit widths and, with the block kind, how many bands each
-    partition holds (NR_OF_SFB); the factors follow band by band (short blocks: the three windows of a band in turn)."""
+    partition holds (NR_OF_SFB); the factors follow band by band (short blocks: the three windows of a band in turn).
+    ``intensity_right``: the right channel of an intensity-stereo frame -- bit 0 of scalefac_compress is the intensity
+    scale, the rest selects among three other partitions (ISO/IEC 13818-3, 2.4.3.2), and there is no preflag."""
     sfc = g["scalefac_compress"]
-    if sfc < 400:
+    if intensity_right:
+        sfc >>= 1
+        g["preflag"] = 0
+        if sfc < 180:
+            slen, row = (sfc // 36, (sfc % 36) // 6, (sfc % 36) % 6, 0), 3
+        elif sfc < 244:
+            sfc -= 180
+            slen, row = ((sfc & 63) >> 4, (sfc & 15) >> 2, sfc & 3, 0), 4
+        else:
+            sfc -= 244
+            slen, row = (sfc // 3, sfc % 3, 0, 0), 5
+    elif sfc < 400:
         slen, row = ((sfc >> 4) // 5, (sfc >> 4) % 5, (sfc % 16) >> 2, sfc % 4), 0
     elif sfc < 500:
         sfc -= 400
@@ -433,6 +452,63 @@ def _requantise(isamp, g, long_sf, short_sf, rate_index, t):
     return mag * np.exp2(exp_short)
 
 
+def _joint_stereo(xr, nonzero_right, g1, long_sf1, short_sf1, row, t, ms, lsf):
+    """Intensity stereo (ISO/IEC 11172-3, 2.4.3.4.9.3; LSF: 13818-3, 2.4.3.2) with MS stereo below the bound, on the two
+    channels' lines as transmitted.  The right channel's block type ``g1`` gives the band partition; in every window the
+    bands ABOVE the last band in which the right channel transmitted a non-zero line carry, in the left channel, the sum
+    signal, and in the right channel's scale factors the intensity position.  A band with an illegal position (>= 7;
+    LSF: >= 16, FFmpeg's reading -- the decoder of the reference's chain) is not intensity coded: MS if the frame says
+    MS, else as transmitted.  The last band (long 21, short 12) has no factor of its own and takes the one below."""
+    nz = np.asarray(nonzero_right, dtype=bool)
+    region = np.zeros(576, dtype=bool)                  # lines coded in intensity stereo
+    pos = np.zeros(576, dtype=np.int64)
+    lband = t["long_of_line"][row]
+    lsf1 = np.asarray(long_sf1, dtype=np.int64)
+    if g1["block_type"] == 2:
+        sband, swin = t["short_of_line"][row], t["short_win_of_line"][row]
+        first = 36 if g1["mixed"] else 0                # mixed: the lines below are long bands
+        ssf = np.asarray(short_sf1, dtype=np.int64)
+        found_any = False
+        for w in range(3):
+            sel = (swin == w) & (np.arange(576) >= first)
+            hit = sband[sel & nz]
+            top = int(hit.max()) if hit.size else -1
+            found_any |= hit.size > 0
+            region |= sel & (sband > top)
+        short_lines = np.arange(576) >= first
+        pos[short_lines] = ssf[np.minimum(sband, 11), swin][short_lines]
+        if g1["mixed"]:
+            low = np.arange(576) < 36
+            if not found_any:
+                hit = lband[low & nz]
+                top = int(hit.max()) if hit.size else -1
+                region |= low & (lband > top)
+            pos[low] = lsf1[lband][low]
+    else:
+        hit = lband[nz]
+        top = int(hit.max()) if hit.size else -1
+        region = lband > top
+        pos = lsf1[np.minimum(lband, 20)]
+    if lsf:
+        # position p: the channel (left for odd p, right for even p) is scaled by 2^(-(scale + 1) ((p + 1) >> 1) / 4)
+        scale = g1["scalefac_compress"] & 1
+        legal = pos < 16
+        p = np.minimum(pos, 15)
+        f = np.exp2(-(scale + 1) * ((p + 1) >> 1) / 4.0)
+        left, right = np.where(p & 1, f, 1.0), np.where(p & 1, 1.0, f)
+    else:
+        legal = pos < 7
+        ratio = np.tan(np.minimum(pos, 5) * np.pi / 12.0)
+        left = np.where(pos == 6, 1.0, ratio / (1.0 + ratio))
+        right = np.where(pos == 6, 0.0, 1.0 / (1.0 + ratio))
+    intensity = region & legal
+    x0, x1 = xr[0].copy(), xr[1].copy()
+    if ms:
+        xr[0], xr[1] = (x0 + x1) / np.sqrt(2.0), (x0 - x1) / np.sqrt(2.0)
+    xr[0][intensity] = (x0 * left)[intensity]
+    xr[1][intensity] = (x0 * right)[intensity]
+
+
 def decode(data, trim_gapless=True, clip=True):
     """``(pcm float32 [channels, samples], sampling rate)`` of an MPEG-1 Layer III stream held in ``data`` (bytes).
     ``trim_gapless``: drop the encoder delay / padding announced in a LAME header the way FFmpeg does; ``clip``: saturate
@@ -487,8 +563,7 @@ def decode(data, trim_gapless=True, clip=True):
         buf = reservoir[len(reservoir) - si["main_data_begin"]:] + main
         reservoir = (reservoir + main)[-511:]
         br = _Bits(buf + bytes(8))                     # (zero tail: peeks near the end stay in range)
-        if hd["mode"] == 1 and hd["mode_ext"] & 1:
-            raise Mp3Error("intensity stereo is not built")
+        intensity = hd["mode"] == 1 and bool(hd["mode_ext"] & 1)
         ms = hd["mode"] == 1 and bool(hd["mode_ext"] & 2)
         sf0 = [None] * nch
         for gr in range(ngr):
@@ -499,14 +574,16 @@ def decode(data, trim_gapless=True, clip=True):
                 if g["block_type"] == 2 and g["mixed"] and row == 8:
                     raise Mp3Error("mixed blocks at 8 kHz (MPEG-2.5) are not built")
                 if hd["lsf"]:
-                    long_sf, short_sf = _scalefactors_lsf(br, g)
+                    long_sf, short_sf = _scalefactors_lsf(br, g, intensity and ch == 1)
                 else:
                     long_sf, short_sf = _scalefactors(br, g, si["scfsi"][ch], sf0[ch] if gr == 1 else None)
                 if gr == 0:
                     sf0[ch] = long_sf
                 isamp = _huffman(br, g, start + g["part2_3_length"], row, t)
                 xr[ch] = _requantise(isamp, g, long_sf, short_sf, row, t)
-            if ms:
+            if intensity:
+                _joint_stereo(xr, np.asarray(isamp) != 0, si["gr"][gr][1], long_sf, short_sf, row, t, ms, hd["lsf"])
+            elif ms:
                 m, s = xr[0].copy(), xr[1].copy()
                 xr[0], xr[1] = (m + s) / np.sqrt(2.0), (m - s) / np.sqrt(2.0)
             for ch in range(nch):

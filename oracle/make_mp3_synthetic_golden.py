@@ -69,10 +69,10 @@ def encode_granule(rng, raw, row, force_kind=None, force=None):
     g["block_type"] = {0: 0, 1: 0, 2: 1, 3: 2, 4: 3, 5: 2}[kind]
     g["mixed"] = int(kind == 5)
     # ---- quantised spectrum: big-values pairs decaying with frequency, then +-1 quadruples, then zeros
-    nbig = int(rng.integers(20, 140))                   # pairs
+    nbig = int(rng.integers(*force.get("nbig", (20, 140))))              # pairs
     ncount1 = int(rng.integers(0, 30))                  # quadruples
     isamp = np.zeros(576, dtype=np.int64)
-    env = np.maximum(1.0, 40.0 * np.exp(-np.arange(2 * nbig) / (10.0 + 60.0 * rng.random())))
+    env = np.maximum(force.get("floor", 1.0), 40.0 * np.exp(-np.arange(2 * nbig) / (10.0 + 60.0 * rng.random())))
     mags = np.floor(rng.random(2 * nbig) * env).astype(np.int64)
     if rng.random() < force.get("escape_p", 0.3):
         mags[int(rng.integers(0, 8))] = int(rng.integers(16, 400))       # an escape (linbits) value now and then
@@ -120,6 +120,24 @@ def encode_granule(rng, raw, row, force_kind=None, force=None):
         assert sfc < 512
     g["scalefac_compress"] = sfc
     bk = 0 if g["block_type"] != 2 else (2 if g["mixed"] else 1)
+    if force.get("lsf_intensity_right"):
+        # the right channel of an LSF intensity-stereo frame: bit 0 = intensity scale, the rest picks one of three other
+        # partitions (ISO/IEC 13818-3 2.4.3.2); widths mostly <= 3 bits so that legal positions (< 16) are the rule
+        small = lambda hi: int(rng.integers(1, min(hi, 4))) if rng.random() < 0.8 else int(rng.integers(0, hi))
+        rng_range = 3 + int(rng.integers(0, 3))
+        if rng_range == 3:
+            sl = [small(5), small(6), small(6), 0]
+            isfc = sl[0] * 36 + sl[1] * 6 + sl[2]
+            assert isfc < 180
+        elif rng_range == 4:
+            sl = [small(4), small(4), small(4), 0]
+            isfc = 180 + ((sl[0] << 4) | (sl[1] << 2) | sl[2])
+            assert isfc < 244
+        else:
+            sl = [small(4), int(rng.integers(0, 3)), 0, 0]
+            isfc = 244 + sl[0] * 3 + sl[1]
+            assert isfc < 256
+        g["scalefac_compress"] = (isfc << 1) | int(rng.integers(0, 2))
     if force.get("mpeg1"):
         # MPEG-1 scale factors (ISO 11172-3 2.4.2.7): 4-bit scalefac_compress -> (slen1, slen2); long blocks in four band
         # groups that granule 1 may inherit from granule 0 (scfsi); a preflag BIT
@@ -190,7 +208,7 @@ def encode_granule(rng, raw, row, force_kind=None, force=None):
     return g, bw
 
 
-def make_stream(seed, version_bits, sr_index, stereo, frames=60, force=None, kinds=None):
+def make_stream(seed, version_bits, sr_index, stereo, frames=60, force=None, kinds=None, intensity=False):
     raw = np.load(os.path.join(REPO, "openvoice_amd", "mp3_tables.npz"))
     rng = np.random.default_rng(seed)
     fam = {2: 1, 0: 2}[version_bits]
@@ -207,6 +225,9 @@ def make_stream(seed, version_bits, sr_index, stereo, frames=60, force=None, kin
         # the header changes right at the start of a stream -- a property of its stream detection, not of Layer III decoding)
         ms = stereo and (rng.random() < 0.5 if f >= 6 else first_ms)
         mode, mode_ext = (3, 0) if not stereo else ((1, 2) if ms else (0, 0))
+        if intensity:
+            # joint stereo with intensity coding (mode_extension bit 0), with and without MS; a plain / MS frame now and then
+            mode, mode_ext = [(1, 1), (1, 3), (1, 1), (1, 3), (1, 2), (0, 0)][int(rng.integers(0, 6)) if f >= 6 else int(first_ms)]
         hdr = (0x7FF << 21) | (version_bits << 19) | (1 << 17) | (1 << 16) | (bri << 12) | (sr_index << 10) | (mode << 6) | (mode_ext << 4)
         # block kinds follow the LEGAL window sequence of the standard (long / stop -> long or start; start -> short or mixed;
         # short / mixed -> short, mixed or stop), per channel: decoders are free to assume it -- FFmpeg's short-block
@@ -225,7 +246,16 @@ def make_stream(seed, version_bits, sr_index, stereo, frames=60, force=None, kin
                     k = int(rng.choice([prev, 4, 4]))    # subbands of a mixed block are long ones and follow the same rule
                 state[ch] = k
                 ks.append(k)
-        grs = [encode_granule(rng, raw, row, ks[ch], force) for ch in range(nch)]
+        forces = [force] * nch
+        if intensity:
+            # both channels in the same block type (the standard requires it of intensity-coded frames); the left channel's
+            # spectrum reaches far up (it carries the sum signal), the right channel's ends early: the bands above are the
+            # intensity region, the right channel's factors there the positions
+            ks[1] = ks[0]
+            state[1] = state[0]
+            forces = [dict(force or {}, nbig=(120, 220), floor=2.5, escape_p=0.0),
+                      dict(force or {}, nbig=(10, 100), lsf_intensity_right=bool(mode_ext & 1))]
+        grs = [encode_granule(rng, raw, row, ks[ch], forces[ch]) for ch in range(nch)]
         side = BitWriter()
         side.put(0, 8)                                   # main_data_begin: no reservoir
         side.put(0, 1 if nch == 1 else 2)
@@ -260,7 +290,7 @@ def make_stream(seed, version_bits, sr_index, stereo, frames=60, force=None, kin
     return bytes(out), rate, nch
 
 
-def make_stream_v1(seed, sr_index, stereo, frames=50):
+def make_stream_v1(seed, sr_index, stereo, frames=50, intensity=False):
     """MPEG-1 frames: two granules, scfsi, 4-bit scalefac_compress, preflag bit -- and a REAL bit reservoir: the main data
     of all frames is one continuous bit stream laid into the frames' data areas back to back, so that a frame's granules
     may start in earlier frames (main_data_begin > 0) exactly as encoders do it."""
@@ -268,7 +298,7 @@ def make_stream_v1(seed, sr_index, stereo, frames=50):
     rng = np.random.default_rng(seed)
     rate = mp3.RATES[sr_index]
     nch = 2 if stereo else 1
-    bri = 13                                             # 256 kbit/s
+    bri = 14 if intensity else 13                        # 256 kbit/s (320 where the left channel carries wide spectra)
     side_len = 17 if nch == 1 else 32
     first_ms = bool(seed % 2)
     state = [0] * nch
@@ -276,6 +306,8 @@ def make_stream_v1(seed, sr_index, stereo, frames=50):
     for f in range(frames):
         ms = stereo and (rng.random() < 0.5 if f >= 6 else first_ms)
         mode, mode_ext = (3, 0) if not stereo else ((1, 2) if ms else (0, 0))
+        if intensity:
+            mode, mode_ext = [(1, 1), (1, 3), (1, 1), (1, 3), (1, 2), (0, 0)][int(rng.integers(0, 6)) if f >= 6 else int(first_ms)]
         pad = int(rng.integers(0, 2)) if rate == 44100 else 0
         hdr = (0x7FF << 21) | (3 << 19) | (1 << 17) | (1 << 16) | (bri << 12) | (sr_index << 10) | (pad << 9) | (mode << 6) | (mode_ext << 4)
         grs = [[None] * nch for _ in range(2)]
@@ -283,6 +315,10 @@ def make_stream_v1(seed, sr_index, stereo, frames=50):
         for ch in range(nch):
             kinds = []
             for gr in range(2):
+                if intensity and ch == 1:                # intensity-coded frames: both channels in the same block type
+                    kinds = list(left_kinds)
+                    state[1] = state[0]
+                    break
                 prev = state[ch]
                 if prev in (0, 1, 4):
                     k = int(rng.choice([0, 1, 2, 2]))
@@ -294,8 +330,12 @@ def make_stream_v1(seed, sr_index, stereo, frames=50):
                 kinds.append(k)
             if kinds[0] not in (3, 5) and kinds[1] not in (3, 5):     # scfsi only between two long-type granules
                 scfsi[ch] = [int(v) for v in rng.integers(0, 2, 4)]
-            grs[0][ch] = encode_granule(rng, raw, sr_index, kinds[0], dict(mpeg1=True))
-            grs[1][ch] = encode_granule(rng, raw, sr_index, kinds[1], dict(mpeg1=True, scfsi=scfsi[ch]))
+            left_kinds = kinds if ch == 0 else left_kinds
+            extra = {}
+            if intensity:
+                extra = dict(nbig=(100, 180), floor=2.5, escape_p=0.0) if ch == 0 else dict(nbig=(10, 90))
+            grs[0][ch] = encode_granule(rng, raw, sr_index, kinds[0], dict(mpeg1=True, **extra))
+            grs[1][ch] = encode_granule(rng, raw, sr_index, kinds[1], dict(mpeg1=True, scfsi=scfsi[ch], **extra))
         main = BitWriter()
         for gr in range(2):
             for ch in range(nch):
@@ -363,6 +403,10 @@ CASES = [("mpeg2_22050_mono", 11, 2, 0, False), ("mpeg2_24000_stereo_ms", 12, 2,
          ("mpeg25_11025_stereo", 14, 0, 0, True), ("mpeg25_12000_mono", 15, 0, 1, False)]
 
 
+CASES_INTENSITY = [("mpeg1_44100_intensity", 31, "v1", 0), ("mpeg1_32000_intensity", 32, "v1", 2),
+                   ("mpeg2_22050_intensity", 41, 2, 0), ("mpeg2_16000_intensity", 42, 2, 2), ("mpeg25_11025_intensity", 43, 0, 0)]
+
+
 def main():
     from kaleido.scopes.plotly import PlotlyScope
     from make_mp3_golden import FAKE_PLOTLY, chromium_decode
@@ -370,7 +414,24 @@ def main():
     with open(js, "w") as fh:
         fh.write(FAKE_PLOTLY)
     scope = PlotlyScope(plotlyjs=js)
+    only = sys.argv[1] if len(sys.argv) > 1 else ""      # e.g. "intensity": regenerate only the files whose name holds it
+    for name, seed, vbits, sri in CASES_INTENSITY:
+        if only not in name:
+            continue
+        if vbits == "v1":
+            data, rate, nch, _ = make_stream_v1(seed, sri, True, intensity=True)
+        else:
+            data, rate, nch = make_stream(seed, vbits, sri, True, intensity=True)
+        pcm = chromium_decode(data, nch, rate, scope)
+        mine, _ = mp3.decode(data)
+        n = min(pcm.shape[1], mine.shape[1])
+        print(name, "stream", len(data), "bytes; chromium", pcm.shape, "peak", float(np.abs(pcm).max()), "| this decoder",
+              mine.shape, "max-abs difference", float(np.abs(pcm[:, :n] - mine[:, :n]).max()))
+        np.savez_compressed(os.path.join(REPO, "tests", "golden", f"mp3_syn_{name}.npz"), stream=np.frombuffer(data, dtype=np.uint8),
+                            pcm=pcm, rate=rate, channels=nch)
     for name, seed, sri, stereo in CASES_V1:
+        if only not in name:
+            continue
         data, rate, nch, deepest = make_stream_v1(seed, sri, stereo)
         pcm = chromium_decode(data, nch, rate, scope)
         mine, _ = mp3.decode(data)
@@ -380,6 +441,8 @@ def main():
         np.savez_compressed(os.path.join(REPO, "tests", "golden", f"mp3_syn_{name}.npz"), stream=np.frombuffer(data, dtype=np.uint8),
                             pcm=pcm, rate=rate, channels=nch)
     for name, seed, vbits, sri, stereo in CASES:
+        if only not in name:
+            continue
         data, rate, nch = make_stream(seed, vbits, sri, stereo)
         pcm = chromium_decode(data, nch, rate, scope)
         mine, r2 = mp3.decode(data)
