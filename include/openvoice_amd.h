@@ -221,10 +221,14 @@ typedef struct ov_wn_layer_params {
   int32_t last;          /* 1: the layer has no residual rows; out is not written */
   int32_t width;         /* tile width in columns: 0 = chosen by the launcher (ov_wn_layer_tile), else 16 .. 128 step 16 */
   int32_t ntile;         /* filled in by the launcher */
-  int32_t reserved;
+  int32_t row_split;     /* 0: the launcher decides; 1: always the fused launch; 3: always the row-split pair (needs acts) */
   unsigned long long* dbg; /* measurement only, NULL in production: [workgroups][8 matrix waves][8] shader-clock ticks
                           * per phase (first chunk wait, gate-conv k-steps, chunk waits, gate, operand issue + acts
                           * barrier, res/skip k-steps, epilogue) and the wave's start tick */
+  float* acts;           /* ABI 2.05; or NULL: scratch [B][H][ld] (batch stride = bstride, 16-byte aligned, not x / out /
+                          * skip).  With it the launcher may run the layer as TWO launches whose workgroups each own a
+                          * third of the rows -- gate rows -> acts, then res/skip rows -- when B * ceil(T / 16) tiles would
+                          * leave most compute units idle (one utterance at frame rate); results bit-identical */
 } ov_wn_layer_params;
 int ov_wn_layer_f32(const ov_wn_layer_params* p, ov_stream_t stream);
 /* 1 when (hidden channels, taps) has a fused instance (192, 5: every WN of the converter and of the V1 speaker). */
@@ -505,7 +509,8 @@ int ov_split3_to_f32(const uint16_t* a, const uint16_t* b, const uint16_t* c, in
 /* Library/ABI version (major*100 + minor).  2.01: ov_conv1d_params.col_limit, ov_conv_post_tanh_limited_f32,
  * ov_frame_limits_i32.  2.02: ov_unpad_rows_f32, ov_conv1d_bf16_pack16, ov_resblock_pair2_bf16cl (+ _supported).
  * 2.03: ov_conv1d_split3 (+ _pack_size, _pack, _supported), ov_split3_from_f32, ov_split3_to_f32.  2.04:
- * ov_conv1d_split3_params.col_limit / col_limit_scale.  The Python binding
+ * ov_conv1d_split3_params.col_limit / col_limit_scale.  2.05: ov_wn_layer_params.acts / row_split (the field that
+ * was `reserved`; the struct grew by one pointer at its end).  The Python binding
  * refuses a library older than the entry points it calls (openvoice_amd/_lib.py MIN_VERSION). */
 int ov_version(void);
 /* 0 for a production build; non-zero = a measurement build with parts of the kernels compiled out (results are

@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OPENVOICE_AMD_LIB") or os.path.join(_HERE, "libopenvoice_amd.so")
 
 OV_OK = 0
-MIN_VERSION = 204     # ov_version() of the newest entry point this package calls (include/openvoice_amd.h)
+MIN_VERSION = 205     # ov_version() of the newest entry point this package calls (include/openvoice_amd.h)
 OV_ERRORS = {-1: "OV_E_BADARG", -2: "OV_E_UNSUPPORTED", -3: "OV_E_ALIGN", -4: "OV_E_LAUNCH"}
 
 EPI_LINEAR, EPI_GATE, EPI_RESSKIP, EPI_COUPLE, EPI_POSTERIOR, EPI_CONVT, EPI_MAGNITUDE = range(7)
@@ -107,7 +107,7 @@ class WnLayerParams(ctypes.Structure):
                 ("bstride", ctypes.c_int64), ("cond_bstride", ctypes.c_int64), ("mask_bstride", ctypes.c_int64),
                 ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("T", ctypes.c_int32), ("ld", ctypes.c_int32),
                 ("K", ctypes.c_int32), ("first", ctypes.c_int32), ("last", ctypes.c_int32), ("width", ctypes.c_int32),
-                ("ntile", ctypes.c_int32), ("reserved", ctypes.c_int32), ("dbg", _fp)]
+                ("ntile", ctypes.c_int32), ("row_split", ctypes.c_int32), ("dbg", _fp), ("acts", _fp)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check every header symbol exists.

@@ -259,20 +259,21 @@ void resblock_pair_f32(const OptTensor& x, const OptTensor& w1, const OptTensor&
   finish(ov_resblock_pair_f32(&p, c.stream()), "ov_resblock_pair_f32");
 }
 
-// ip = [B, H, T, ld, K, first, last, width, bstride, cond_bstride, mask_bstride, cond_off]
+// ip = [B, H, T, ld, K, first, last, width, bstride, cond_bstride, mask_bstride, cond_off, row_split]
 void wn_layer_f32(const OptTensor& x, const OptTensor& out, const OptTensor& skip, const OptTensor& w_in,
                   const OptTensor& b_in, const OptTensor& cond, const OptTensor& w_rs, const OptTensor& b_rs,
-                  const OptTensor& mask, const OptTensor& dbg, at::IntArrayRef ip) {
-  TORCH_CHECK(ip.size() == 12, "openvoice_amd::wn_layer_f32: 12 integer parameters");
+                  const OptTensor& mask, const OptTensor& dbg, const OptTensor& acts, at::IntArrayRef ip) {
+  TORCH_CHECK(ip.size() == 13, "openvoice_amd::wn_layer_f32: 13 integer parameters");
   Ctx c{"wn_layer_f32", false};
   ov_wn_layer_params p{};
   p.x = sptr<float>(x, c, 0); p.out = sptr<float>(out, c, 1); p.skip = sptr<float>(skip, c, 2);
   p.w_in = sptr<float>(w_in, c, 3); p.b_in = sptr<float>(b_in, c, 4); p.cond = sptr<float>(cond, c, 5, ip[11]);
   p.w_rs = sptr<float>(w_rs, c, 6); p.b_rs = sptr<float>(b_rs, c, 7); p.mask = sptr<float>(mask, c, 8);
   p.dbg = sptr<unsigned long long>(dbg, c, 9);
+  p.acts = sptr<float>(acts, c, 10);
   p.B = (int32_t)ip[0]; p.H = (int32_t)ip[1]; p.T = (int32_t)ip[2]; p.ld = (int32_t)ip[3]; p.K = (int32_t)ip[4];
   p.first = (int32_t)ip[5]; p.last = (int32_t)ip[6]; p.width = (int32_t)ip[7];
-  p.bstride = ip[8]; p.cond_bstride = ip[9]; p.mask_bstride = ip[10];
+  p.bstride = ip[8]; p.cond_bstride = ip[9]; p.mask_bstride = ip[10]; p.row_split = (int32_t)ip[12];
   DeviceScope scope(c);
   finish(ov_wn_layer_f32(&p, c.stream()), "ov_wn_layer_f32");
 }
@@ -358,7 +359,7 @@ TORCH_LIBRARY(openvoice_amd, m) {
   m.def("resblock_pair_f32(Tensor? x, Tensor? w1, Tensor? b1, Tensor? w2, Tensor? b2, Tensor(a!)? out, Tensor? add, "
         "Tensor(b!)? dbg, Tensor? col_limit, int[] ip, float[] fp) -> ()", &resblock_pair_f32);
   m.def("wn_layer_f32(Tensor? x, Tensor(a!)? out, Tensor(b!)? skip, Tensor? w_in, Tensor? b_in, Tensor? cond, Tensor? w_rs, "
-        "Tensor? b_rs, Tensor? mask, Tensor(c!)? dbg, int[] ip) -> ()", &wn_layer_f32);
+        "Tensor? b_rs, Tensor? mask, Tensor(c!)? dbg, Tensor(d!)? acts, int[] ip) -> ()", &wn_layer_f32);
   m.def("conv1d_bf16cl(Tensor? x, Tensor? w, Tensor? bias, Tensor(a!)? out, Tensor? res, Tensor? add, Tensor(b!)? dbg, "
         "int[] ip, float[] fp) -> ()", &conv1d_bf16cl);
   m.def("resblock_pair_bf16cl(Tensor? x, Tensor? w1, Tensor? b1, Tensor? w2, Tensor? b2, Tensor(a!)? out, Tensor? add, "

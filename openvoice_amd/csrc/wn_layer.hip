@@ -28,6 +28,18 @@
 //   operand.  LDS: 2 x 18 KB chunk buffers + 108 KB acts = 144 KB.
 //
 // h is read with a (K-1)/2 halo from neighbouring tiles, so h' goes to a SECOND buffer (the caller ping-pongs).
+//
+// ROW-SPLIT FORM for a single utterance (MODE 1 + MODE 2, round 5).  One utterance of 861 frames is 54 tiles of 16
+// columns: 54 of 256 CUs, each of them matrix-bound on all 2H gate rows (23 us of MFMA issue per layer, 34 us measured,
+// 48 layers per conversion = a quarter of a batch-1 conversion).  There the launcher splits the ROWS three ways instead:
+// launch 1 (MODE 1) = phase 1 + gate with one 16-row fragment per wave, workgroup (tile, r) owning fragments 8r .. 8r+7 (64
+// gated channels) and writing them to the `acts` scratch in HBM; launch 2 (MODE 2) = `acts` tile -> LDS, phase 2 + epilogue,
+// again one fragment per wave.  3 x the workgroups, a third of the k-loop each, the same weight records (a wave reads its
+// fragment's 1 KiB out of the fused packing's 3 KiB record) and the same summation order per output element: the results
+// are bit-identical to the fused launch (tests/test_gpu_wn_layer.py).  No cross-workgroup wait anywhere.  Measured
+// (profiles/r05_s15): 16.7 + 7.2 us per layer against 34.4 fused.  (Keeping all six chunks of the 24-column tile resident so
+// that the k-loop waits for one global-memory latency instead of six was measured too: no change -- the gate launch is bound
+// by its one dependent MFMA chain per wave, two waves per SIMD, not by the staging.)
 #include <hip/hip_runtime.h>
 
 #include "openvoice_amd.h"
@@ -52,12 +64,15 @@ __device__ __forceinline__ float wn_gate(float t, float s) {
   return copysignf((1.f - a) * r, t);
 }
 
-template <int K, int H, int NB>
+// MODE 0: the fused layer.  MODE 1 / 2: the row-split form's gate launch / res-skip launch (blockIdx.y = row third).
+template <int K, int H, int NB, int MODE>
 __global__ __launch_bounds__(64 * (WNL_MW + WNL_NLD)) void wn_layer_kernel(const ov_wn_layer_params p) {
   static_assert((2 * H) % (16 * WNL_MW) == 0 && H % WNL_CH == 0, "H must be a multiple of 64");
   static_assert(K % 2 == 1 && (K - 1) / 2 <= WNL_PADA, "odd K <= 9");
   static_assert(NB >= 1 && NB <= 8, "tile width 16 .. 128 columns");
-  constexpr int RB = 2 * H / (16 * WNL_MW);   // 16-row fragments per wave
+  constexpr int RBP = 2 * H / (16 * WNL_MW);  // 16-row fragments per wave in the weight packing (and of the fused layer)
+  constexpr int RB = MODE == 0 ? RBP : 1;     // ... and per wave of this launch
+  static_assert(MODE == 0 || NB == 1, "the row-split form exists for 16-column tiles");
   constexpr int NCH = H / WNL_CH;
   constexpr int PAD = (K - 1) / 2, PADA = WNL_PADA;
   constexpr int W = 16 * NB;
@@ -69,8 +84,8 @@ __global__ __launch_bounds__(64 * (WNL_MW + WNL_NLD)) void wn_layer_kernel(const
   constexpr int RPC = 2 * K;                   // weight records (4 k-steps) per chunk
   constexpr int NR1 = NCH * RPC, NR2 = H / 16;
 
-  __shared__ __attribute__((aligned(16))) float xs[2 * BUF];
-  __shared__ __attribute__((aligned(16))) float acts[H * XS];
+  __shared__ __attribute__((aligned(16))) float xs[MODE == 2 ? 4 : 2 * BUF];
+  __shared__ __attribute__((aligned(16))) float acts[MODE == 1 ? 4 : H * XS];
   __shared__ __attribute__((aligned(16))) float msk[128];   // mask[b][t0 .. t0+W): read by the epilogue from LDS, so
                                                            // that no global load (vmcnt) sits between its stores
 
@@ -96,6 +111,26 @@ __global__ __launch_bounds__(64 * (WNL_MW + WNL_NLD)) void wn_layer_kernel(const
 #pragma unroll
       for (int r = 0; r < 4; ++r) m[r] = t + r < T ? m[r] : 0.f;
       *reinterpret_cast<f32x4*>(msk + 4 * llane) = m;
+    }
+    if constexpr (MODE == 2) {
+      // the gated tile [H][W] of launch 1 -> LDS; columns >= T as zeros (they feed only columns that are never written)
+      const float* __restrict__ ab = p.acts + (int64_t)b * p.bstride;
+      constexpr int AV = W / 4, NA = H * AV;
+#pragma unroll
+      for (int i = 0; i < (NA + 64 * WNL_NLD - 1) / (64 * WNL_NLD); ++i) {
+        const int idx = i * (64 * WNL_NLD) + llane;
+        if (idx < NA) {
+          const int row = idx / AV, c4 = idx - row * AV;
+          const int t = t0 + 4 * c4;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (t < T) v = *reinterpret_cast<const f32x4*>(ab + (uint32_t)row * ld + (uint32_t)t);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = t + r < T ? v[r] : 0.f;
+          *reinterpret_cast<f32x4*>(acts + row * XS + 4 * c4) = v;
+        }
+      }
+      __syncthreads();   // (acts in LDS)
+      return;
     }
 #pragma unroll 1
     for (int chunk = 0; chunk < NCH; ++chunk) {
@@ -128,7 +163,7 @@ __global__ __launch_bounds__(64 * (WNL_MW + WNL_NLD)) void wn_layer_kernel(const
       }
       __syncthreads();   // hand buffer (chunk & 1) to the matrix waves
     }
-    __syncthreads();     // (acts in LDS) -- the matrix waves' phase boundary
+    if constexpr (MODE == 0) __syncthreads();   // (acts in LDS) -- the matrix waves' phase boundary
     return;
   }
 
@@ -146,9 +181,13 @@ __global__ __launch_bounds__(64 * (WNL_MW + WNL_NLD)) void wn_layer_kernel(const
     }
   };
   const int g = lane >> 4, c = lane & 15;   // operand k-row / fragment column; accumulator rows 4g .. 4g+3
-  const int row0 = wave * (16 * RB);        // first of this wave's 16*RB rows (both phases)
+  // this wave's first 16-row fragment (both phases) and where its weight records start: the packing is
+  // [wave of the fused layer][record][RBP fragments][lane]
+  const int frag0 = MODE == 0 ? wave * RBP : WNL_MW * (int)blockIdx.y + wave;
+  const int row0 = 16 * frag0;
+  const int pw = frag0 / RBP, pi = frag0 - pw * RBP;
   f32x4 acc[RB][NB];
-  {
+  if constexpr (MODE != 2) {
     const float* __restrict__ cb = p.cond ? p.cond + (int64_t)b * p.cond_bstride : nullptr;
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
@@ -160,8 +199,10 @@ __global__ __launch_bounds__(64 * (WNL_MW + WNL_NLD)) void wn_layer_kernel(const
   }
 
   // ---- phase 1: gate rows = W_in * h ------------------------------------------------------------------------------
-  const f32x4* __restrict__ w1 = reinterpret_cast<const f32x4*>(p.w_in) + (size_t)wave * ((NR1 + 1) * RB * 64);
   f32x4 a_cur[RB], a_nxt[RB];
+  if constexpr (MODE != 2) {
+  const f32x4* __restrict__ w1 =
+      reinterpret_cast<const f32x4*>(p.w_in) + (size_t)pw * ((NR1 + 1) * RBP * 64) + (size_t)pi * 64;
 #pragma unroll
   for (int i = 0; i < RB; ++i) a_cur[i] = w1[i * 64 + lane];
   const int xl_off = g * XS + c + (PADA - PAD);
@@ -170,7 +211,7 @@ __global__ __launch_bounds__(64 * (WNL_MW + WNL_NLD)) void wn_layer_kernel(const
     __syncthreads();   // loaders finished buffer (chunk & 1); we finished reading the other one
     mark(chunk == 0 ? 0 : 2);
     const float* xl = xs + (chunk & 1) * BUF + xl_off;
-    const f32x4* __restrict__ wc = w1 + (size_t)chunk * (RPC * RB * 64);
+    const f32x4* __restrict__ wc = w1 + (size_t)chunk * (RPC * RBP * 64);
     float bcur[NB], bnxt[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) bcur[j] = xl[16 * j];
@@ -179,7 +220,7 @@ __global__ __launch_bounds__(64 * (WNL_MW + WNL_NLD)) void wn_layer_kernel(const
       const int u = m & 3;
       if (u == 0) {                         // the record after the last one of the last chunk is zero padding
 #pragma unroll
-        for (int i = 0; i < RB; ++i) a_nxt[i] = (wc + (size_t)(m / 4 + 1) * (RB * 64))[i * 64 + lane];
+        for (int i = 0; i < RB; ++i) a_nxt[i] = (wc + (size_t)(m / 4 + 1) * (RBP * 64))[i * 64 + lane];
       }
       if (m + 1 < STEPS1) {
         const int tap = (m + 1) / 8, s = (m + 1) % 8;
@@ -204,10 +245,23 @@ __global__ __launch_bounds__(64 * (WNL_MW + WNL_NLD)) void wn_layer_kernel(const
     }
     mark(1);
   }
+  }
 
   // ---- gate: rows 4g + {0, 1, 2, 3} of fragment q = tanh rows of channels 8q+g, 8q+g+4, then their sigmoid rows ---
-  const f32x4* __restrict__ w2 = reinterpret_cast<const f32x4*>(p.w_rs) + (size_t)wave * ((NR2 + 1) * RB * 64);
-  const bool skip_rows = wave >= WNL_MW / 2;        // rows >= H of the res/skip conv
+  if constexpr (MODE == 1) {
+    // row-split form, launch 1: the gated channels of this wave's fragment go to the `acts` scratch in HBM
+    float* __restrict__ ag = p.acts + (int64_t)b * p.bstride + (uint32_t)(8 * frag0 + g) * ld;
+    const int col = t0 + c;
+    const f32x4 v = acc[0][0];
+    if (col < T) {
+      ag[col] = wn_gate(v[0], v[2]);
+      ag[4 * ld + col] = wn_gate(v[1], v[3]);
+    }
+    return;
+  }
+  const f32x4* __restrict__ w2 =
+      reinterpret_cast<const f32x4*>(p.w_rs) + (size_t)pw * ((NR2 + 1) * RBP * 64) + (size_t)pi * 64;
+  const bool skip_rows = row0 >= H;                 // rows >= H of the res/skip conv
   const bool idle2 = p.last && !skip_rows;          // last layer: no residual rows (modules.py:203-207)
   if (!idle2) {
 #pragma unroll
@@ -224,12 +278,14 @@ __global__ __launch_bounds__(64 * (WNL_MW + WNL_NLD)) void wn_layer_kernel(const
   const bool zero_src = skip_rows && p.first;       // first layer initialises the skip accumulator
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
-    const int ch = 8 * (wave * RB + i) + g;
+    const int ch = 8 * (frag0 + i) + g;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      const f32x4 v = acc[i][j];
-      acts[ch * XS + 16 * j + c] = wn_gate(v[0], v[2]);
-      acts[(ch + 4) * XS + 16 * j + c] = wn_gate(v[1], v[3]);
+      if constexpr (MODE == 0) {
+        const f32x4 v = acc[i][j];
+        acts[ch * XS + 16 * j + c] = wn_gate(v[0], v[2]);
+        acts[(ch + 4) * XS + 16 * j + c] = wn_gate(v[1], v[3]);
+      }
       if (!idle2) {
         const int col = t0 + 16 * j + 4 * g;          // multiple of 4; col < T => col + 3 < ld (ld % 4 == 0)
         const uint32_t voff = (uint32_t)(16 * i) * ld + (uint32_t)(col < T ? col : 0);
@@ -258,13 +314,13 @@ __global__ __launch_bounds__(64 * (WNL_MW + WNL_NLD)) void wn_layer_kernel(const
 #pragma unroll 1
     for (int grp = 0; grp < NR2 / 4; ++grp) {       // 16 k-steps (64 channels) per iteration
       const float* ag = al + grp * 64 * XS;
-      const f32x4* __restrict__ wg = w2 + (size_t)grp * (4 * RB * 64);
+      const f32x4* __restrict__ wg = w2 + (size_t)grp * (4 * RBP * 64);
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
         const int u = m & 3;
         if (u == 0) {
 #pragma unroll
-          for (int i = 0; i < RB; ++i) a_nxt[i] = (wg + (size_t)(m / 4 + 1) * (RB * 64))[i * 64 + lane];
+          for (int i = 0; i < RB; ++i) a_nxt[i] = (wg + (size_t)(m / 4 + 1) * (RBP * 64))[i * 64 + lane];
         }
         // k-step m + 1 (the first of the next group when m = 15; past the end it re-reads row 4g of the last group)
         {
@@ -326,26 +382,28 @@ __global__ __launch_bounds__(64 * (WNL_MW + WNL_NLD)) void wn_layer_kernel(const
   if (dbg && lane == 0) {
     tph[7] = tstart;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) p.dbg[((size_t)blockIdx.x * WNL_MW + wave) * 8 + q] = tph[q];
+    for (int q = 0; q < 8; ++q) p.dbg[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * WNL_MW + wave) * 8 + q] = tph[q];
   }
 }
 
-#define OV_WN_INST(NB) template __global__ void wn_layer_kernel<5, 192, NB>(const ov_wn_layer_params);
+#define OV_WN_INST(NB) template __global__ void wn_layer_kernel<5, 192, NB, 0>(const ov_wn_layer_params);
 OV_WN_INST(1) OV_WN_INST(2) OV_WN_INST(3) OV_WN_INST(4) OV_WN_INST(5) OV_WN_INST(6) OV_WN_INST(7) OV_WN_INST(8)
+template __global__ void wn_layer_kernel<5, 192, 1, 1>(const ov_wn_layer_params);
+template __global__ void wn_layer_kernel<5, 192, 1, 2>(const ov_wn_layer_params);
 
 typedef void (*wn_kernel_fn)(const ov_wn_layer_params);
 
 template <int K, int H>
 static wn_kernel_fn wn_kernel_for(int nb) {
   switch (nb) {
-    case 1: return wn_layer_kernel<K, H, 1>;
-    case 2: return wn_layer_kernel<K, H, 2>;
-    case 3: return wn_layer_kernel<K, H, 3>;
-    case 4: return wn_layer_kernel<K, H, 4>;
-    case 5: return wn_layer_kernel<K, H, 5>;
-    case 6: return wn_layer_kernel<K, H, 6>;
-    case 7: return wn_layer_kernel<K, H, 7>;
-    case 8: return wn_layer_kernel<K, H, 8>;
+    case 1: return wn_layer_kernel<K, H, 1, 0>;
+    case 2: return wn_layer_kernel<K, H, 2, 0>;
+    case 3: return wn_layer_kernel<K, H, 3, 0>;
+    case 4: return wn_layer_kernel<K, H, 4, 0>;
+    case 5: return wn_layer_kernel<K, H, 5, 0>;
+    case 6: return wn_layer_kernel<K, H, 6, 0>;
+    case 7: return wn_layer_kernel<K, H, 7, 0>;
+    case 8: return wn_layer_kernel<K, H, 8, 0>;
   }
   return nullptr;
 }
@@ -438,6 +496,29 @@ int ov_wn_layer_f32(const ov_wn_layer_params* pin, ov_stream_t stream) {
   // 16-byte aligned and own the whole last vector (columns T .. round_up(T, 4) - 1 are read and discarded)
   if ((reinterpret_cast<uintptr_t>(q.mask) & 15) || (q.mask_bstride % 4)) return OV_E_ALIGN;
   if (q.mask_bstride < (int64_t)((q.T + 3) / 4) * 4) return OV_E_BADARG;
+  if (q.row_split != 0 && q.row_split != 1 && q.row_split != 3) return OV_E_BADARG;
+  if (q.acts) {
+    if (reinterpret_cast<uintptr_t>(q.acts) & 15) return OV_E_ALIGN;
+    if (q.acts == q.x || q.acts == q.out || q.acts == q.skip) return OV_E_BADARG;
+  } else if (q.row_split == 3) {
+    return OV_E_BADARG;
+  }
+  // Row-split pair (see the head of this file): worth it while three times the 16-column tiles still fit the compute
+  // units in one round -- ONE utterance at frame rate (measured, profiles/r05_s14: batch 1 7.9 -> 7.4 ms per conversion,
+  // batch 2 within the noise, batch 3+ slower).
+  const int64_t tiles16 = (int64_t)q.B * ((q.T + 15) / 16);
+  const bool split = q.row_split == 3 ||
+                     (q.row_split == 0 && q.acts && q.width == 0 && !q.dbg && 3 * tiles16 <= wn_compute_units());
+  if (split) {
+    if (q.width != 0 && q.width != 16) return OV_E_BADARG;
+    if (tiles16 > INT32_MAX) return OV_E_BADARG;
+    q.width = 16;
+    q.ntile = (q.T + 15) / 16;
+    const dim3 grid((unsigned)tiles16, 3), block(64 * (WNL_MW + WNL_NLD));
+    hipLaunchKernelGGL((wn_layer_kernel<5, 192, 1, 1>), grid, block, 0, static_cast<hipStream_t>(stream), q);
+    hipLaunchKernelGGL((wn_layer_kernel<5, 192, 1, 2>), grid, block, 0, static_cast<hipStream_t>(stream), q);
+    return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
+  }
   const int width = ov_wn_layer_tile(q.B, q.T, q.width);
   if (width == 0) return OV_E_BADARG;
   q.width = width;

@@ -322,14 +322,16 @@ def wn_pack(w_dense, device):
 
 
 def launch_wn_layer(layer, x, out, skip, mask, B, T, ld, cond=None, cond_off=0, cond_bs=0, first=False, last=False,
-                    width=0, mask_bs=0, dbg=None):
+                    width=0, mask_bs=0, dbg=None, acts=None, row_split=0):
     """One fused WaveNet layer (``ov_wn_layer_f32``): out = (x + res) * mask, skip (+)= rs; ``layer`` is a dict of
-    the packed tensors built by ``_WaveNet``; x / out / skip are [B][H][ld]."""
+    the packed tensors built by ``_WaveNet``; x / out / skip are [B][H][ld].  ``acts`` ([B][H][ld] scratch) lets the
+    launcher run a single utterance as the row-split launch pair (bit-identical results); ``row_split`` 1 / 3 force
+    the fused / the split form."""
     if _lib.use_torch_binding():
         H = layer["hidden"]
         _lib.torch_op("wn_layer_f32", x, out, skip, layer["w_in"], layer["b_in"], cond, layer["w_rs"], layer["b_rs"],
-                      mask, dbg, [B, H, T, ld, layer["K"], int(first), int(last), width, H * ld, cond_bs, mask_bs,
-                                  cond_off])
+                      mask, dbg, acts, [B, H, T, ld, layer["K"], int(first), int(last), width, H * ld, cond_bs, mask_bs,
+                                        cond_off, row_split])
         return
     p = _lib.WnLayerParams()
     p.x, p.out, p.skip = _ptr(x), _ptr(out), _ptr(skip)
@@ -339,8 +341,9 @@ def launch_wn_layer(layer, x, out, skip, mask, B, T, ld, cond=None, cond_off=0, 
     H = layer["hidden"]
     p.bstride, p.cond_bstride, p.mask_bstride = H * ld, cond_bs, mask_bs
     p.B, p.H, p.T, p.ld, p.K = B, H, T, ld, layer["K"]
-    p.first, p.last, p.width = int(first), int(last), width
+    p.first, p.last, p.width, p.row_split = int(first), int(last), width, row_split
     p.dbg = ctypes.c_void_p(dbg.data_ptr()) if dbg is not None else None
+    p.acts = _ptr(acts) if acts is not None else None
     stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(_lib.load().ov_wn_layer_f32(ctypes.byref(p), stream), "ov_wn_layer_f32")
 
@@ -485,6 +488,7 @@ class ConverterEngine:
         # silently corrupt the last samples with a hard-wired 16)
         self.generator_margin = max(GENERATOR_MARGIN, generator_margin_frames(self.cfg))
         self.fuse_wn = True      # WaveNet layers as one launch each (ov_wn_layer_f32) where the shape has an instance
+        self.wn_row_split = 0    # 0: the launcher splits a layer's rows over two launches for a single utterance; 1: never
         self.fuse_pairs = True   # ResBlock pairs of the HBM-bound stages as one launch each (PAIR_POLICY)
         # opt-in fast generator: bf16 activations, fp32 accumulation (waveform within
         # ~1e-2 of the fp32 path instead of ~1e-5).  Built lazily by use_bf16_generator().
@@ -596,7 +600,7 @@ class ConverterEngine:
             for i in range(wn.n_layers):
                 layer = wn.fused_layers[i]
                 args = dict(cond=cond, cond_off=2 * H * i, cond_bs=cbs, first=i == 0, last=i == wn.n_layers - 1,
-                            mask_bs=Tp)
+                            mask_bs=Tp, acts=ws["acts"], row_split=self.wn_row_split)
                 if self.profile is None:
                     launch_wn_layer(layer, src, dst, ws["skip"], mask, B, T, Tp, **args)
                 else:

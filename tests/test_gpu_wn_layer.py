@@ -53,7 +53,7 @@ def _reference(x, g, mask, skip0, w_in, b_in, w_rs, b_rs, first, last):
     return (x + rs[:, :H]) * mask[:, None], (0 if first else skip0) + rs[:, H:]
 
 
-def _run(B, T, lengths, width, first=False, last=False, per_item_cond=True, seed=10):
+def _run(B, T, lengths, width, first=False, last=False, per_item_cond=True, seed=10, row_split=1, with_acts=False):
     ld = (T + 3) // 4 * 4
     x, skip0 = _rand(B, H, T, seed=seed), _rand(B, H, T, seed=seed + 1)
     g = _rand(B if per_item_cond else 1, 2 * H, seed=seed + 2, scale=0.3)
@@ -65,14 +65,16 @@ def _run(B, T, lengths, width, first=False, last=False, per_item_cond=True, seed
     xd, skipd, maskd = pad(x), pad(skip0 if not first else torch.full_like(skip0, float("nan"))), pad(mask)
     outd = torch.full((B, H, ld), float("nan"), device=DEV)
     gd = g[:, wn_fused_row_order(H)].contiguous().to(DEV)
+    acts = torch.full((B, H, ld), float("nan"), device=DEV) if (with_acts or row_split == 3) else None
     launch_wn_layer(_packed(*lw), xd, outd, skipd, maskd, B, T, ld, cond=gd, cond_bs=2 * H if per_item_cond else 0,
-                    first=first, last=last, width=width, mask_bs=ld)
+                    first=first, last=last, width=width, mask_bs=ld, acts=acts, row_split=row_split)
     torch.cuda.synchronize()
     if not last:
         _close(outd[:, :, :T], x_ref, what=f"h' (T={T}, width={width})")
         assert torch.isnan(outd[:, :, T:]).all(), "columns >= T must not be written"
     _close(skipd[:, :, :T], skip_ref, what=f"skip (T={T}, width={width})")
     assert (skipd[:, :, T:].cpu() == 0).all()
+    return outd, skipd, acts
 
 
 @pytest.mark.parametrize("width", [16, 32, 48, 64, 80, 96, 112, 128])
@@ -98,6 +100,43 @@ def test_first_and_last_layer_forms():
 
 def test_broadcast_conditioning_row():
     _run(3, 77, [77, 50, 1], 0, per_item_cond=False)
+
+
+@pytest.mark.parametrize("B,T", [(1, 861), (2, 861), (1, 1), (1, 17), (3, 64), (1, 65), (2, 127), (1, 1000)])
+@pytest.mark.parametrize("form", ["middle", "first", "last"])
+def test_row_split_pair_is_bit_identical_to_the_fused_launch(B, T, form):
+    """The two-launch row-split form (gate rows -> ``acts`` scratch, then res/skip rows; three workgroups per 16-column
+    tile, one 16-row fragment per wave) against plain PyTorch AND bit for bit against the fused launch on the same tile
+    width: same weight records, same summation order per output element.  Ragged lengths, T = 1, T not a multiple of 4 /
+    16, the first layer (skip initialised over NaN) and the last (skip rows only, h' untouched)."""
+    lengths = [max(1, T - 7 * i) for i in range(B)]
+    kw = dict(first=form == "first", last=form == "last")
+    o3, s3, acts = _run(B, T, lengths, 0, row_split=3, **kw)
+    o1, s1, _ = _run(B, T, lengths, 16, row_split=1, **kw)
+    assert torch.equal(s3[:, :, :T], s1[:, :, :T])
+    if form != "last":
+        assert torch.equal(o3[:, :, :T], o1[:, :, :T])
+    assert torch.isfinite(acts[:, :, :T]).all() and torch.isnan(acts[:, :, T:]).all()   # scratch: columns < T only
+
+
+def test_row_split_is_the_launchers_choice_for_one_utterance_only():
+    """row_split = 0 with a scratch: one utterance at frame rate takes the split pair (the scratch is written), batches
+    whose 16-column tiles fill the compute units without it stay fused (the scratch is untouched); without a scratch, or
+    with a forced tile width, always fused.  Forcing the split without a scratch is an argument error."""
+    for B, T, expect in ((1, 861, True), (1, 1300, True), (2, 861, False), (8, 861, False), (32, 861, False)):
+        _, _, acts = _run(B, T, [T] * B, 0, row_split=0, with_acts=True)
+        assert bool(torch.isfinite(acts[:, :, :T]).all()) == expect and bool(torch.isnan(acts).all()) == (not expect)
+    _, _, acts = _run(1, 200, [200], 32, row_split=0, with_acts=True)
+    assert torch.isnan(acts).all()
+    layer = _packed(*_layer(1))
+    x = torch.zeros(1, H, 16, device=DEV)
+    mask = torch.ones(1, 16, device=DEV)
+    with pytest.raises(_lib.OvError, match="BADARG"):
+        launch_wn_layer(layer, x, torch.zeros_like(x), torch.zeros_like(x), mask, 1, 16, 16, row_split=3)
+    with pytest.raises(_lib.OvError, match="BADARG"):
+        launch_wn_layer(layer, x, torch.zeros_like(x), torch.zeros_like(x), mask, 1, 16, 16, row_split=2)
+    with pytest.raises(_lib.OvError, match="BADARG"):
+        launch_wn_layer(layer, x, torch.zeros_like(x), torch.zeros_like(x), mask, 1, 16, 16, acts=x, row_split=3)
 
 
 def test_tile_rule():

@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--split-ab", action="store_true",
                     help="every batch size also with the opt-in split-precision MRF stages (engine.use_split_bf16x3, 6 and "
                          "3 plane products); reports the two paths' waveforms' distance on a fixed noise tensor")
+    ap.add_argument("--wn-ab", action="store_true",
+                    help="the WaveNet layers' row-split launch pair (the launcher's choice for one or two utterances) "
+                         "against the fused launch (engine.wn_row_split = 1), same process, outputs compared bit for bit")
     ap.add_argument("--no-ragged", action="store_true")
     args = ap.parse_args()
     from bench import SAMPLE_RATE, synth_wave
@@ -82,6 +85,20 @@ def main():
             dtg = timeit(lambda: fixed(graph=True))
             rows[-1].update(ms_serial_order=round(dt1 * 1e3, 3), ms_graph_replay=round(dtg * 1e3, 3),
                             bit_identical_to_serial=bool(torch.equal(o3, o1)), graph_bit_identical=bool(torch.equal(og, o1)))
+        if args.wn_ab:
+            spec = spectrogram_torch(wave, d.filter_length, d.sampling_rate, d.hop_length, d.win_length, center=False)
+            lengths = torch.full((B,), spec.shape[2], dtype=torch.int64, device=dev)
+            noise = torch.randn(B, 192, spec.shape[2], generator=torch.Generator().manual_seed(B)).to(dev)
+            fixed = lambda: model.voice_conversion(spec, lengths, se[0], se[1], tau=0.3, noise=noise)[0]
+            res = {}
+            for mode, name in ((1, "fused"), (3, "row_split"), (0, "auto")):
+                eng.wn_row_split = mode
+                res[name] = (timeit(step), fixed().clone())
+            eng.wn_row_split = 0
+            rows[-1].update(ms_wn_fused=round(res["fused"][0] * 1e3, 3), ms_wn_row_split=round(res["row_split"][0] * 1e3, 3),
+                            ms_wn_auto=round(res["auto"][0] * 1e3, 3),
+                            wn_row_split_bit_identical=bool(torch.equal(res["fused"][1], res["row_split"][1])
+                                                            and torch.equal(res["fused"][1], res["auto"][1])))
         if args.split_ab:
             spec = spectrogram_torch(wave, d.filter_length, d.sampling_rate, d.hop_length, d.win_length, center=False)
             lengths = torch.full((B,), spec.shape[2], dtype=torch.int64, device=dev)
