@@ -228,7 +228,7 @@ typedef struct ov_wn_layer_params {
   float* acts;           /* ABI 2.05; or NULL: scratch [B][H][ld] (batch stride = bstride, 16-byte aligned, not x / out /
                           * skip).  With it the launcher may run the layer as TWO launches whose workgroups each own a
                           * third of the rows -- gate rows -> acts, then res/skip rows -- when B * ceil(T / 16) tiles would
-                          * leave most compute units idle (one utterance at frame rate); results bit-identical */
+                          * leave most compute units idle (one or two utterances at frame rate); results bit-identical */
 } ov_wn_layer_params;
 int ov_wn_layer_f32(const ov_wn_layer_params* p, ov_stream_t stream);
 /* 1 when (hidden channels, taps) has a fused instance (192, 5: every WN of the converter and of the V1 speaker). */

@@ -29,7 +29,7 @@
 //
 // h is read with a (K-1)/2 halo from neighbouring tiles, so h' goes to a SECOND buffer (the caller ping-pongs).
 //
-// ROW-SPLIT FORM for a single utterance (MODE 1 + MODE 2, round 5).  One utterance of 861 frames is 54 tiles of 16
+// ROW-SPLIT FORM for one or two utterances (MODE 1 + MODE 2, round 5).  One utterance of 861 frames is 54 tiles of 16
 // columns: 54 of 256 CUs, each of them matrix-bound on all 2H gate rows (23 us of MFMA issue per layer, 34 us measured,
 // 48 layers per conversion = a quarter of a batch-1 conversion).  There the launcher splits the ROWS three ways instead:
 // launch 1 (MODE 1) = phase 1 + gate with one 16-row fragment per wave, workgroup (tile, r) owning fragments 8r .. 8r+7 (64
@@ -37,9 +37,9 @@
 // again one fragment per wave.  3 x the workgroups, a third of the k-loop each, the same weight records (a wave reads its
 // fragment's 1 KiB out of the fused packing's 3 KiB record) and the same summation order per output element: the results
 // are bit-identical to the fused launch (tests/test_gpu_wn_layer.py).  No cross-workgroup wait anywhere.  Measured
-// (profiles/r05_s15): 16.7 + 7.2 us per layer against 34.4 fused.  (Keeping all six chunks of the 24-column tile resident so
+// (profiles/r05_s18): 11.4 + 7.2 us per layer against 34.4 fused (16.7 + 7.2 with the fused k-loop's prefetch distances).  (Keeping all six chunks of the 24-column tile resident so
 // that the k-loop waits for one global-memory latency instead of six was measured too: no change -- the gate launch is bound
-// by its one dependent MFMA chain per wave, two waves per SIMD, not by the staging.)
+// by its k-loop, not by the staging.)  The gate launch's k-loop has its own form with deeper operand rings (below).
 #include <hip/hip_runtime.h>
 
 #include "openvoice_amd.h"
@@ -203,9 +203,45 @@ __global__ __launch_bounds__(64 * (WNL_MW + WNL_NLD)) void wn_layer_kernel(const
   if constexpr (MODE != 2) {
   const f32x4* __restrict__ w1 =
       reinterpret_cast<const f32x4*>(p.w_in) + (size_t)pw * ((NR1 + 1) * RBP * 64) + (size_t)pi * 64;
+  if constexpr (MODE == 0) {
 #pragma unroll
-  for (int i = 0; i < RB; ++i) a_cur[i] = w1[i * 64 + lane];
+    for (int i = 0; i < RB; ++i) a_cur[i] = w1[i * 64 + lane];
+  }
   const int xl_off = g * XS + c + (PADA - PAD);
+  if constexpr (MODE == 1) {
+    // One MFMA per k-step and wave: the fused loop's prefetch distances (B operand one k-step, weights one record ahead) are
+    // a third of what they are with three row blocks -- too short for the LDS and L2 latencies.  Same k-step order (the
+    // summation order is what makes the pair bit-identical to the fused launch), deeper rings: the B operands of a whole
+    // tap (8 k-steps) are read one tap ahead, WD - 1 weight records (4 k-steps each) are in flight.  Fully unrolled: every
+    // ring slot is a compile-time register.
+    constexpr int WD = 6;
+    f32x4 wr[WD];
+#pragma unroll
+    for (int r = 0; r < WD - 1; ++r) wr[r] = w1[(size_t)r * (RBP * 64) + lane];
+#pragma unroll
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+      __syncthreads();   // loaders finished buffer (chunk & 1); we finished reading the other one
+      const float* xl = xs + (chunk & 1) * BUF + xl_off;
+      float bv[2][8];
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) bv[0][s8] = xl[4 * s8 * XS];
+#pragma unroll
+      for (int tap = 0; tap < K; ++tap) {
+        if (tap + 1 < K) {
+#pragma unroll
+          for (int s8 = 0; s8 < 8; ++s8) bv[(tap + 1) & 1][s8] = xl[4 * s8 * XS + tap + 1];
+        }
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+          const int m = 8 * tap + s8, R = chunk * RPC + m / 4, u = m & 3;
+          if (u == 0 && R + WD - 1 < NR1) wr[(R + WD - 1) % WD] = w1[(size_t)(R + WD - 1) * (RBP * 64) + lane];
+          __builtin_amdgcn_sched_barrier(0);
+          acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[R % WD][u], bv[tap & 1][s8], acc[0][0], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  } else {
 #pragma unroll 1
   for (int chunk = 0; chunk < NCH; ++chunk) {
     __syncthreads();   // loaders finished buffer (chunk & 1); we finished reading the other one
@@ -244,6 +280,7 @@ __global__ __launch_bounds__(64 * (WNL_MW + WNL_NLD)) void wn_layer_kernel(const
       }
     }
     mark(1);
+  }
   }
   }
 
@@ -503,12 +540,12 @@ int ov_wn_layer_f32(const ov_wn_layer_params* pin, ov_stream_t stream) {
   } else if (q.row_split == 3) {
     return OV_E_BADARG;
   }
-  // Row-split pair (see the head of this file): worth it while three times the 16-column tiles still fit the compute
-  // units in one round -- ONE utterance at frame rate (measured, profiles/r05_s14: batch 1 7.9 -> 7.4 ms per conversion,
-  // batch 2 within the noise, batch 3+ slower).
+  // Row-split pair (see the head of this file): worth it while three times the 16-column tiles fit the compute units in
+  // little more than one round -- one or two utterances at frame rate (measured, profiles/r05_s18: batch 1 7.90 -> 7.2 ms
+  // per conversion, batch 2 12.58 -> 12.42, batch 3 even, batch 4+ slower).
   const int64_t tiles16 = (int64_t)q.B * ((q.T + 15) / 16);
-  const bool split = q.row_split == 3 ||
-                     (q.row_split == 0 && q.acts && q.width == 0 && !q.dbg && 3 * tiles16 <= wn_compute_units());
+  const bool split = q.row_split == 3 || (q.row_split == 0 && q.acts && q.width == 0 && !q.dbg &&
+                                          3 * tiles16 <= wn_compute_units() + wn_compute_units() / 3);
   if (split) {
     if (q.width != 0 && q.width != 16) return OV_E_BADARG;
     if (tiles16 > INT32_MAX) return OV_E_BADARG;

@@ -325,7 +325,7 @@ def launch_wn_layer(layer, x, out, skip, mask, B, T, ld, cond=None, cond_off=0, 
                     width=0, mask_bs=0, dbg=None, acts=None, row_split=0):
     """One fused WaveNet layer (``ov_wn_layer_f32``): out = (x + res) * mask, skip (+)= rs; ``layer`` is a dict of
     the packed tensors built by ``_WaveNet``; x / out / skip are [B][H][ld].  ``acts`` ([B][H][ld] scratch) lets the
-    launcher run a single utterance as the row-split launch pair (bit-identical results); ``row_split`` 1 / 3 force
+    launcher run one or two utterances as the row-split launch pair (bit-identical results); ``row_split`` 1 / 3 force
     the fused / the split form."""
     if _lib.use_torch_binding():
         H = layer["hidden"]
@@ -488,7 +488,7 @@ class ConverterEngine:
         # silently corrupt the last samples with a hard-wired 16)
         self.generator_margin = max(GENERATOR_MARGIN, generator_margin_frames(self.cfg))
         self.fuse_wn = True      # WaveNet layers as one launch each (ov_wn_layer_f32) where the shape has an instance
-        self.wn_row_split = 0    # 0: the launcher splits a layer's rows over two launches for a single utterance; 1: never
+        self.wn_row_split = 0    # 0: the launcher splits a layer's rows over two launches for one or two utterances; 1: never
         self.fuse_pairs = True   # ResBlock pairs of the HBM-bound stages as one launch each (PAIR_POLICY)
         # opt-in fast generator: bf16 activations, fp32 accumulation (waveform within
         # ~1e-2 of the fp32 path instead of ~1e-5).  Built lazily by use_bf16_generator().

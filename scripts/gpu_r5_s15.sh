@@ -3,7 +3,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-O=gpurun_out/r5s15; mkdir -p $O
+O=gpurun_out/${OUT15:-r5s15}; mkdir -p $O
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof -o b1 --output-format csv -- python $GRAFT_REPO_ROOT/tools/bench_sweep.py --batches 1 --steps 20 --no-ragged > $GRAFT_REPO_ROOT/$O/sweep.log 2>&1
 cd $GRAFT_REPO_ROOT

@@ -174,3 +174,39 @@ def test_split3_length_aware_work_list(c, k, d, res):
             assert torch.isnan(out[:, bi, kept:].float()).all(), (bi, scale, nwg)
     with pytest.raises(Exception):
         launch_conv_split3(layer, xp, full, col_limit=limits, col_limit_scale=0, **kw)
+
+
+FULL = [(256, 11, 1, 6888), (128, 11, 5, 55104), (128, 3, 1, 55104), (64, 7, 3, 110208)]
+
+
+@pytest.mark.parametrize("c,k,d,L", FULL)
+def test_split3_full_size_properties(c, k, d, L):
+    """BASELINE's full sizes (32 utterances, the MRF stages' real lengths), where a float64 reference is out of reach: three
+    size-independent properties, each BIT-EXACT because an output element's summation order does not depend on where it sits.
+    (a) time-shift equivariance -- the input moved by 37 columns (not a multiple of any tile or chunk size) gives the output
+    moved by 37 columns away from the utterance edges: every tile's halo rows and every work-list boundary are read right;
+    (b) utterance independence -- a permuted batch gives the permuted output; (c) scaling by a power of two (bias-free,
+    linear epilogue) scales every plane exactly."""
+    B, s = 32, 37
+    w, _, _ = _layer(c, k, d, seed=c + k)
+    layer = PackedConvSplit3(w, None, DEV, dil=d)
+    gen = torch.Generator(device=DEV).manual_seed(L + k)
+    x = torch.randn(B, L + s, c, device=DEV, generator=gen) * torch.exp(torch.randn(B, 1, c, device=DEV, generator=gen))
+
+    def planes(v):                                           # (B, L, C) fp32 -> (3, B, L, C) bf16, exact split
+        return split3_reference(v.contiguous()).contiguous()
+
+    def run(xp):
+        out = torch.full((3, B, L, c), float("nan"), dtype=torch.bfloat16, device=DEV)
+        launch_conv_split3(layer, xp, out)
+        return out
+
+    base = run(planes(x[:, s:]))                             # columns s .. L + s
+    torch.cuda.synchronize()
+    assert torch.isfinite(base.float()).all()
+    moved = run(planes(x[:, :L]))                            # columns 0 .. L: the same signal s columns later
+    halo = (k - 1) * d // 2
+    assert torch.equal(moved[:, :, s + halo:L - halo], base[:, :, halo:L - s - halo])
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).to(DEV)
+    assert torch.equal(run(planes(x[perm, s:])), base[:, perm])
+    assert torch.equal(run(planes(4.0 * x[:, s:])).float(), 4.0 * base.float())

@@ -119,11 +119,11 @@ def test_row_split_pair_is_bit_identical_to_the_fused_launch(B, T, form):
     assert torch.isfinite(acts[:, :, :T]).all() and torch.isnan(acts[:, :, T:]).all()   # scratch: columns < T only
 
 
-def test_row_split_is_the_launchers_choice_for_one_utterance_only():
-    """row_split = 0 with a scratch: one utterance at frame rate takes the split pair (the scratch is written), batches
-    whose 16-column tiles fill the compute units without it stay fused (the scratch is untouched); without a scratch, or
-    with a forced tile width, always fused.  Forcing the split without a scratch is an argument error."""
-    for B, T, expect in ((1, 861, True), (1, 1300, True), (2, 861, False), (8, 861, False), (32, 861, False)):
+def test_row_split_is_the_launchers_choice_for_one_or_two_utterances_only():
+    """row_split = 0 with a scratch: one or two utterances at frame rate take the split pair (the scratch is written),
+    batches whose 16-column tiles fill the compute units without it stay fused (the scratch is untouched); without a
+    scratch, or with a forced tile width, always fused.  Forcing the split without a scratch is an argument error."""
+    for B, T, expect in ((1, 861, True), (1, 1300, True), (2, 861, True), (3, 861, False), (32, 861, False)):
         _, _, acts = _run(B, T, [T] * B, 0, row_split=0, with_acts=True)
         assert bool(torch.isfinite(acts[:, :, :T]).all()) == expect and bool(torch.isnan(acts).all()) == (not expect)
     _, _, acts = _run(1, 200, [200], 32, row_split=0, with_acts=True)
