@@ -221,7 +221,8 @@ typedef struct ov_wn_layer_params {
   int32_t last;          /* 1: the layer has no residual rows; out is not written */
   int32_t width;         /* tile width in columns: 0 = chosen by the launcher (ov_wn_layer_tile), else 16 .. 128 step 16 */
   int32_t ntile;         /* filled in by the launcher */
-  int32_t row_split;     /* 0: the launcher decides; 1: always the fused launch; 3: always the row-split pair (needs acts) */
+  int32_t row_split;     /* 0: the launcher decides; 1: always the fused launch; 3: always the row-split pair (needs acts,
+                          * dbg must be NULL) */
   unsigned long long* dbg; /* measurement only, NULL in production: [workgroups][8 matrix waves][8] shader-clock ticks
                           * per phase (first chunk wait, gate-conv k-steps, chunk waits, gate, operand issue + acts
                           * barrier, res/skip k-steps, epilogue) and the wave's start tick */

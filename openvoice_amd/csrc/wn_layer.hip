@@ -540,6 +540,7 @@ int ov_wn_layer_f32(const ov_wn_layer_params* pin, ov_stream_t stream) {
   } else if (q.row_split == 3) {
     return OV_E_BADARG;
   }
+  if (q.row_split == 3 && q.dbg) return OV_E_BADARG;   // the phase timers (and their buffer's size) belong to the fused launch
   // Row-split pair (see the head of this file): worth it while three times the 16-column tiles fit the compute units in
   // little more than one round -- one or two utterances at frame rate (measured, profiles/r05_s18: batch 1 7.90 -> 7.2 ms
   // per conversion, batch 2 12.58 -> 12.42, batch 3 even, batch 4+ slower).

@@ -754,9 +754,9 @@ class ConverterEngine:
         0-2 of the released configuration, 80 % of a conversion's FLOPs) on ``ov_conv1d_split3``: every fp32 operand
         carried as three bf16 planes (lossless), every product as the six plane products of weight >= 2^-18 on the bf16
         matrix pipe with fp32 accumulation -- fp32-level results (against float64 the error is BELOW the fp32 MFMA
-        kernels' on every shape, profiles/r05_s2_split3_table_all_shapes.txt) at 1.2-2.1x their speed: 106.4 instead of
-        139.8 ms per batch-32 conversion.  ``products=3`` uses the hi / mid planes only (16-bit operands, ~2e-5 per conv,
-        84.2 ms).  Off by default: the contract path is the fp32 kernels
+        kernels' on every shape, profiles/r05_s2_split3_table_all_shapes.txt) at 1.3-2.1x their speed: 103-104 instead of
+        139.5-140.5 ms per batch-32 conversion.  ``products=3`` uses the hi / mid planes only (16-bit operands, ~2e-5 per
+        conv, 80 ms).  Off by default: the contract path is the fp32 kernels
         (reference: openvoice/modules.py:296-309, models.py:280-286)."""
         if products not in (6, 3):
             raise _lib.OvError(f"use_split_bf16x3: products must be 6 or 3, got {products!r}")

@@ -137,6 +137,9 @@ def test_row_split_is_the_launchers_choice_for_one_or_two_utterances_only():
         launch_wn_layer(layer, x, torch.zeros_like(x), torch.zeros_like(x), mask, 1, 16, 16, row_split=2)
     with pytest.raises(_lib.OvError, match="BADARG"):
         launch_wn_layer(layer, x, torch.zeros_like(x), torch.zeros_like(x), mask, 1, 16, 16, acts=x, row_split=3)
+    with pytest.raises(_lib.OvError, match="BADARG"):                     # phase timers exist for the fused launch only
+        launch_wn_layer(layer, x, torch.zeros_like(x), torch.zeros_like(x), mask, 1, 16, 16, acts=torch.zeros_like(x),
+                        row_split=3, dbg=torch.zeros(8 * 8, dtype=torch.int64, device=DEV))
 
 
 def test_tile_rule():
