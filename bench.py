@@ -92,6 +92,27 @@ def bf16_counter_record(batch, frames):
     return rec, "rocprofv3 PMC passes, profiles/bf16_counters_latest.json (FETCH_SIZE x 2 + WRITE_SIZE, calibrated)"
 
 
+def split_traffic_record(batch, frames, products):
+    """The committed PMC traffic record of the split-precision conv launches (tools/pmc_traffic_split.py ->
+    profiles/split3_traffic_latest.json), returned only when it was taken on the running tree's split kernel sources at
+    this batch / frame count / product count."""
+    from openvoice_amd.hostinfo import split3_source_digest
+    path = os.path.join(REPO, "profiles", "split3_traffic_latest.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)
+    except (OSError, ValueError):
+        return None, "no split-conv traffic record committed"
+    if rec.get("split3_source_digest") != split3_source_digest():
+        return None, (f"profiles/split3_traffic_latest.json was measured on split kernel sources "
+                      f"{rec.get('split3_source_digest')}, this tree is {split3_source_digest()}")
+    if (rec.get("batch"), rec.get("frames")) != (batch, frames):
+        return None, f"profiles/split3_traffic_latest.json is for batch {rec.get('batch')} x {rec.get('frames')} frames"
+    if any(i.get("products") != products for i in rec.get("instances", [])):
+        return None, "profiles/split3_traffic_latest.json was measured with another product count"
+    return rec, "rocprofv3 PMC passes of bench.py --split-bf16x3, profiles/split3_traffic_latest.json"
+
+
 SAMPLE_RATE = 22050
 
 
@@ -362,6 +383,22 @@ def split_opt_in(engine, step, model, sd, cfg, wave, se, hop_cfg, B, seconds, no
                             "fp32_equivalent_tflops": round(f_s / t_s / 1e12, 2), "layout_kernels_ms": round(t_l * 1e3, 3)},
                "note": "opt-in (ConverterEngine.use_split_bf16x3 / bench.py --split-bf16x3); the contract line above is the "
                        "fp32 MFMA path"}
+        T = int(wave.shape[1]) // int(hop_cfg.hop_length)
+        rec, why = split_traffic_record(B, T, engine.split3_products)
+        roof = out["roofline"]
+        roof["traffic_source"] = why
+        if rec and rec.get("launches_per_step") == n_s:
+            # the HBM side of the same launches: PMC bytes per conversion against the 6-bytes-per-element streams
+            roof.update(traffic=rec["bytes_per_step"], traffic_unit="HBM bytes per conversion over the split-precision launches",
+                        alg_bytes_per_step=rec["algorithmic_bytes_per_step"],
+                        traffic_over_algorithmic=rec["traffic_over_algorithmic"],
+                        hbm_tb_per_s=round(rec["bytes_per_step"] / t_s / 1e12, 3),
+                        hbm_frac_of_8_tb_per_s=round(rec["bytes_per_step"] / t_s / 8e12, 4))
+        else:
+            roof["traffic"] = None
+            if rec:
+                roof["traffic_source"] = (f"profiles/split3_traffic_latest.json counted {rec.get('launches_per_step')} split "
+                                          f"launches per step, this run issues {n_s}")
         if not no_parity:
             par = parity_of_item(model, sd, cfg, wave, se, 0.3, hop_cfg)
             par["fp32_bar"] = 1e-4
@@ -652,6 +689,15 @@ def main():
                                "alg_tflop_per_step_split_stages": round(f_s / 1e12, 3),
                                "fp32_stage_launches": n_mrf, "fp32_stage_tflops": round(achieved, 2),
                                "layout_kernels_ms": round(by_tag.get("split_layout", [0, 0, 0.0])[2] * 1e3, 3)}
+            rec, why = split_traffic_record(B, frames, args.split_products)
+            out["roofline"]["traffic_source"] = why
+            if rec and rec.get("launches_per_step") == n_s:
+                out["roofline"].update(
+                    traffic=rec["bytes_per_step"], traffic_unit="HBM bytes per conversion over the split-precision launches",
+                    alg_bytes_per_step=rec["algorithmic_bytes_per_step"],
+                    traffic_over_algorithmic=rec["traffic_over_algorithmic"],
+                    hbm_tb_per_s=round(rec["bytes_per_step"] / t_s / 1e12, 3),
+                    hbm_frac_of_8_tb_per_s=round(rec["bytes_per_step"] / t_s / 8e12, 4))
             out["note"] = "opt-in configuration (--split-bf16x3), not the contract line"
         if args.bf16_generator:
             # this configuration is judged against BOTH roofs -- HBM bytes (PMC-measured where a

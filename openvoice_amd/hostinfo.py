@@ -85,3 +85,18 @@ def bf16_source_digest():
         with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def split3_source_digest():
+    """sha256 (16 hex digits) over the split-precision conv kernels and their host helpers.  The counter record
+    profiles/split3_traffic_latest.json carries it (tools/pmc_traffic_split.py)."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "csrc", "conv1d_split3*")) + [os.path.join(here, "split3.py")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
