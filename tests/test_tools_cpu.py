@@ -81,3 +81,41 @@ def test_bench_reports_pmc_traffic_only_for_the_same_launch_configuration(tmp_pa
         assert value is None and "this run" in why, args
     monkeypatch.setattr(bench, "PMC_TRAFFIC_FILE", str(tmp_path / "missing.json"))
     assert bench.pmc_traffic(32, 861, True, PAIR_POLICY, 63) == (None, "no PMC record committed")
+
+
+def test_split_conv_traffic_per_instance_and_its_gate_in_bench(tmp_path, monkeypatch):
+    """tools/pmc_traffic_split.py: per kernel instance, FETCH_SIZE x the factor measured on the pass's own 1 GiB copies and
+    WRITE_SIZE against the 6-bytes-per-element streams (residual form: two tensors read); bench.split_traffic_record hands
+    the record out only for the split kernel sources, shape and product count it was measured on."""
+    gib_kib = float(1 << 20)
+    s128 = "void ovks3::conv1d_split3_kernel<11, 1, 128, 128, true, 6>(ov_conv1d_split3_params)"
+    s256 = "void ovks3::conv1d_split3_kernel<3, 5, 256, 128, false, 6>(ov_conv1d_split3_params)"
+    tensor128 = 6 * 2 * 10 * 64 * 128            # batch 2, 10 frames, stage 1: 64 columns per frame, C = 128
+    tensor256 = 6 * 2 * 10 * 8 * 256
+    fetch = [[1, 256, s128, "FETCH_SIZE", 1.5 * 2 * tensor128 / 2 / 1024, 0, 1], [2, 256, s256, "FETCH_SIZE", 3.0 * tensor256 / 2 / 1024, 0, 1]]
+    write = [[1, 256, s128, "WRITE_SIZE", tensor128 / 1024, 0, 1], [2, 256, s256, "WRITE_SIZE", tensor256 / 1024, 0, 1]]
+    fetch += [[10 + i, 1, COPY, "FETCH_SIZE", gib_kib / 2, 0, 1] for i in range(3)]
+    write += [[10 + i, 1, COPY, "WRITE_SIZE", gib_kib, 0, 1] for i in range(3)]
+    _write(str(tmp_path / "f" / "r1_counter_collection.csv"), fetch)
+    _write(str(tmp_path / "w" / "r1_counter_collection.csv"), write)
+    rec = json.loads(_run("pmc_traffic_split.py", str(tmp_path / "f"), str(tmp_path / "w"), "1", "2", "10"))
+    by = {(i["C"], i["residual"]): i for i in rec["instances"]}
+    assert by[(128, True)]["read_over_algorithmic"] == 1.5 and by[(256, False)]["read_over_algorithmic"] == 3.0
+    assert all(i["write_over_algorithmic"] == 1.0 and i["products"] == 6 for i in rec["instances"])
+    assert rec["launches_per_step"] == 2 and rec["algorithmic_bytes_per_step"] == 3 * tensor128 + 2 * tensor256
+    assert rec["bytes_per_step"] == round(1.5 * 2 * tensor128 + tensor128 + 3.0 * tensor256 + tensor256)
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    os.makedirs(tmp_path / "profiles")
+    (tmp_path / "profiles" / "split3_traffic_latest.json").write_text(json.dumps(rec))
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    assert bench.split_traffic_record(2, 10, 6)[0]["bytes_per_step"] == rec["bytes_per_step"]
+    assert bench.split_traffic_record(2, 10, 3)[0] is None and bench.split_traffic_record(32, 10, 6)[0] is None
+    rec["split3_source_digest"] = "0" * 16
+    (tmp_path / "profiles" / "split3_traffic_latest.json").write_text(json.dumps(rec))
+    assert bench.split_traffic_record(2, 10, 6)[0] is None
+    # and the committed record belongs to the committed kernels
+    from openvoice_amd.hostinfo import split3_source_digest
+    with open(os.path.join(ROOT, "profiles", "split3_traffic_latest.json")) as fh:
+        assert json.load(fh)["split3_source_digest"] == split3_source_digest()
