@@ -300,9 +300,17 @@ __global__ __launch_bounds__(64 * (WNL_MW + WNL_NLD)) void wn_layer_kernel(const
       reinterpret_cast<const f32x4*>(p.w_rs) + (size_t)pw * ((NR2 + 1) * RBP * 64) + (size_t)pi * 64;
   const bool skip_rows = row0 >= H;                 // rows >= H of the res/skip conv
   const bool idle2 = p.last && !skip_rows;          // last layer: no residual rows (modules.py:203-207)
+  f32x4 wr2[MODE == 2 ? NR2 : 1];
   if (!idle2) {
+    if constexpr (MODE == 2) {
+      // row-split form, launch 2: all NR2 records of this wave's fragment (12 KiB) requested now, while the loader waves
+      // fetch the `acts` tile -- the k-loop below then waits for nothing
 #pragma unroll
-    for (int i = 0; i < RB; ++i) a_cur[i] = w2[i * 64 + lane];   // first res/skip record in flight during the gate
+      for (int r = 0; r < NR2; ++r) wr2[r] = w2[(size_t)r * (RBP * 64) + lane];
+    } else {
+#pragma unroll
+      for (int i = 0; i < RB; ++i) a_cur[i] = w2[i * 64 + lane];   // first res/skip record in flight during the gate
+    }
   }
   // Phase 2 runs TRANSPOSED (operands swapped: D = acts^T W^T, same LDS reads and the same weight records): a lane
   // then holds 4 consecutive time columns of ONE row per fragment, so h / skip / out are touched with 16-byte
@@ -343,7 +351,19 @@ __global__ __launch_bounds__(64 * (WNL_MW + WNL_NLD)) void wn_layer_kernel(const
   }
 
   // ---- phase 2: res/skip rows = W_rs * acts -----------------------------------------------------------------------
-  {
+  if constexpr (MODE == 2) {
+    // one MFMA per k-step and wave (see the gate launch): every B operand of the 48 k-steps read up front, the weight
+    // records already in registers; the same k-step order as the fused loop
+    const float* al = acts + g * XS + c;
+    float bv[4 * NR2];
+#pragma unroll
+    for (int q = 0; q < 4 * NR2; ++q) bv[q] = al[4 * q * XS];
+#pragma unroll
+    for (int q = 0; q < 4 * NR2; ++q) {
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[q], wr2[q / 4][q & 3], acc[0][0], 0, 0, 0);   // transposed
+    }
+  } else {
     const float* al = acts + g * XS + c;
     float bcur[NB], bnxt[NB];
 #pragma unroll
