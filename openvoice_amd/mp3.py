@@ -509,6 +509,52 @@ def _joint_stereo(xr, nonzero_right, g1, long_sf1, short_sf1, row, t, ms, lsf):
     xr[1][intensity] = (x0 * right)[intensity]
 
 
+HYBRID_BLOCK = 64
+
+
+def _hybrid(x, kind, tail, row, t):
+    """Hybrid synthesis of a block of granules of one channel: ``x`` [n][576] lines as transmitted, ``kind`` [n] (0 / 1 / 3
+    long with the normal / start / stop window, 2 short, 4 mixed, -1 undecodable = silence), ``tail`` [32][18] the overlap
+    left by the granule before.  Returns ([18 n slots][32 subbands], new tail)."""
+    n = x.shape[0]
+    for code, key in ((2, "reorder"), (4, "reorder_mixed")):                # short blocks: band-by-band order -> 3 k + window
+        sel = kind == code                                                  # inside a subband
+        if sel.any():
+            y = np.zeros((int(sel.sum()), 576))
+            y[:, t[key][row]] = x[sel]
+            x[sel] = y
+    x = x.reshape(n, 32, 18)
+    for sel, nlong in (((kind == 0) | (kind == 1) | (kind == 3), 32), (kind == 4, 2)):
+        if sel.any():                                  # alias reduction across the boundaries between LONG subbands: the
+            # butterflies of different boundaries touch disjoint lines (top 8 of sb - 1, bottom 8 of sb): all at once
+            xs = x[sel]
+            a, b = xs[:, :nlong - 1, 17:9:-1].copy(), xs[:, 1:nlong, :8].copy()
+            xs[:, :nlong - 1, 17:9:-1] = a * t["cs"] - b * t["ca"]
+            xs[:, 1:nlong, :8] = b * t["cs"] + a * t["ca"]
+            x[sel] = xs
+    out = np.zeros((n, 32, 36))
+    mm = lambda a, m: (np.ascontiguousarray(a).reshape(-1, 18) @ m).reshape(a.shape[0], -1, 36)   # one GEMM per window kind
+    for bt in (0, 1, 3):
+        sel = kind == bt
+        if sel.any():
+            out[sel] = mm(x[sel], t["imdct36"][bt])
+    sel = kind == 2
+    if sel.any():
+        out[sel] = mm(x[sel], t["imdct_short"])
+    sel = kind == 4
+    if sel.any():
+        xs = x[sel]
+        out[sel] = np.concatenate([mm(xs[:, :2], t["imdct36"][0]), mm(xs[:, 2:], t["imdct_short"])], axis=1)
+    tails = np.concatenate([tail[None], out[:, :, 18:]], axis=0)            # tails[i] = what granule i overlaps with
+    silent = np.flatnonzero(kind == -1)
+    for i in silent:                                   # an undecodable granule passes the overlap before it on
+        tails[i + 1] = tails[i]
+    hyb = out[:, :, :18] + tails[:-1]
+    hyb[silent] = 0.0
+    hyb[:, 1::2, 1::2] *= -1.0                         # frequency inversion: odd time samples of odd subbands
+    return hyb.transpose(0, 2, 1).reshape(-1, 32), tails[-1]
+
+
 def decode(data, trim_gapless=True, clip=True):
     """``(pcm float32 [channels, samples], sampling rate)`` of an MPEG-1 Layer III stream held in ``data`` (bytes).
     ``trim_gapless``: drop the encoder delay / padding announced in a LAME header the way FFmpeg does; ``clip``: saturate
@@ -519,8 +565,11 @@ def decode(data, trim_gapless=True, clip=True):
     info = probe(data)
     pos, nch, rate = info["first_frame"], info["channels"], info["sample_rate"]
     reservoir = b""
-    prev = np.zeros((nch, 32, 18))                     # IMDCT overlap per channel and subband
-    subband_slots = [[] for _ in range(nch)]           # hybrid outputs, 18 time slots x 32 subbands per granule
+    # per channel, one entry per granule: the 576 requantised (and stereo-processed) lines as transmitted, and what the
+    # hybrid filter bank has to do with them -- 0 / 1 / 3 long blocks (normal / start / stop window), 2 short, 4 mixed,
+    # -1 a granule that could not be decoded (silence).  The filter bank itself runs once, over all granules (below).
+    lines = [[] for _ in range(nch)]
+    kinds = [[] for _ in range(nch)]
     first = True
     frames = 0
     while True:
@@ -556,7 +605,9 @@ def decode(data, trim_gapless=True, clip=True):
             # the stream was cut before this frame's reservoir: its granules cannot be decoded -> silence (as FFmpeg)
             reservoir = (reservoir + main)[-511:]
             for ch in range(nch):
-                subband_slots[ch].append(np.zeros((18 * ngr, 32)))
+                for _ in range(ngr):
+                    lines[ch].append(np.zeros(576))
+                    kinds[ch].append(-1)
             pos += flen
             frames += 1
             continue
@@ -588,38 +639,27 @@ def decode(data, trim_gapless=True, clip=True):
                 xr[0], xr[1] = (m + s) / np.sqrt(2.0), (m - s) / np.sqrt(2.0)
             for ch in range(nch):
                 g = si["gr"][gr][ch]
-                x = xr[ch]
-                if g["block_type"] == 2:               # short blocks: band-by-band order -> 3 k + window inside a subband
-                    y = np.zeros(576)
-                    y[t["reorder_mixed" if g["mixed"] else "reorder"][row]] = x
-                    x = y
-                x = x.reshape(32, 18).copy()
-                nlong = 32 if g["block_type"] != 2 else (2 if g["mixed"] else 0)
-                if nlong > 1:                          # alias reduction across the boundaries between LONG subbands: the
-                    # butterflies of different boundaries touch disjoint lines (top 8 of sb - 1, bottom 8 of sb): all at once
-                    a, b = x[:nlong - 1, 17:9:-1].copy(), x[1:nlong, :8].copy()
-                    x[:nlong - 1, 17:9:-1] = a * t["cs"] - b * t["ca"]
-                    x[1:nlong, :8] = b * t["cs"] + a * t["ca"]
-                out = np.empty((32, 36))
-                if nlong:
-                    bt = 0 if (g["block_type"] == 2 and g["mixed"]) else g["block_type"]
-                    out[:nlong] = x[:nlong] @ t["imdct36"][bt]
-                if nlong < 32:
-                    out[nlong:] = x[nlong:] @ t["imdct_short"]
-                hyb = out[:, :18] + prev[ch]
-                prev[ch] = out[:, 18:]
-                hyb[1::2, 1::2] *= -1.0                # frequency inversion: odd time samples of odd subbands
-                subband_slots[ch].append(hyb.T)        # [18 slots][32 subbands]
+                lines[ch].append(xr[ch])
+                kinds[ch].append(g["block_type"] if g["block_type"] != 2 else (4 if g["mixed"] else 2))
         pos += flen
         frames += 1
     if not frames:
         raise Mp3Error("no decodable frame")
-    # ---- polyphase synthesis, all time slots at once: V = S N, out[t][j] = sum_i D[64 i + j] V[t - 2 i][j] + D[64 i + 32 + j] V[t - 2 i - 1][32 + j]
     win = t["window"]
     spf = 576 if info["lsf"] else 1152
+    row = RATES.index(rate)
     pcm = np.empty((nch, frames * spf), dtype=np.float32)
     for ch in range(nch):
-        s = np.concatenate(subband_slots[ch], axis=0)                       # [slots][32]
+        # ---- hybrid filter bank (2.4.3.4.9 / .10): reorder, alias reduction, IMDCT, overlap-add, frequency inversion -- over
+        # blocks of granules (one numpy call per step and block instead of per granule; blocks small enough to stay in cache)
+        tail = np.zeros((32, 18))                                           # second IMDCT half of the granule before
+        blocks = []
+        for g0 in range(0, len(lines[ch]), HYBRID_BLOCK):
+            sb, tail = _hybrid(np.stack(lines[ch][g0:g0 + HYBRID_BLOCK]), np.asarray(kinds[ch][g0:g0 + HYBRID_BLOCK]), tail,
+                               row, t)
+            blocks.append(sb)
+        s = np.concatenate(blocks, axis=0)                                  # [slots][32 subbands]
+        # ---- polyphase synthesis, all time slots at once: V = S N, out[t][j] = sum_i D[64 i + j] V[t - 2 i][j] + D[64 i + 32 + j] V[t - 2 i - 1][32 + j]
         v = np.concatenate([np.zeros((16, 64)), s @ t["synth"]], axis=0)    # 16 slots of history
         n = s.shape[0]
         out = np.zeros((n, 32))
