@@ -119,6 +119,13 @@ def test_row_split_pair_is_bit_identical_to_the_fused_launch(B, T, form):
     assert torch.isfinite(acts[:, :, :T]).all() and torch.isnan(acts[:, :, T:]).all()   # scratch: columns < T only
 
 
+def test_row_split_with_a_broadcast_conditioning_row():
+    """What a batch-1 ``convert`` issues: one conditioning row for the whole batch (cond_bstride = 0), split pair vs fused."""
+    o3, s3, _ = _run(2, 333, [333, 200], 0, per_item_cond=False, row_split=3)
+    o1, s1, _ = _run(2, 333, [333, 200], 16, per_item_cond=False, row_split=1)
+    assert torch.equal(o3[:, :, :333], o1[:, :, :333]) and torch.equal(s3[:, :, :333], s1[:, :, :333])
+
+
 def test_row_split_is_the_launchers_choice_for_one_or_two_utterances_only():
     """row_split = 0 with a scratch: one or two utterances at frame rate take the split pair (the scratch is written),
     batches whose 16-column tiles fill the compute units without it stay fused (the scratch is untouched); without a
