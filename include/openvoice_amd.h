@@ -250,6 +250,15 @@ int ov_wn_layer_tile(int B, int T, int width);
 int ov_frame_hops_f32(const float* wave, float* hops, int B, int N, int hop, int pad, int U, int ld,
                       ov_stream_t stream);
 
+/* Rate conversion at the audio boundary, reference openvoice/api.py:123,144 (``librosa.load(path, sr=...)`` = resampy's
+ * kaiser_best band-limited sinc interpolation): a polyphase FIR over a mono waveform,
+ *   y[t] = sum_{j < 2 taps} h[t % P][j] * x[(t * Q) / P - taps + 1 + j]        (x = 0 outside [0, n_in))
+ * with P / Q = output rate / input rate in lowest terms and h the [P][2 taps] float64 weights of the interpolation
+ * filter at each of the P fractional positions (openvoice_amd/audio_io.py: kaiser_best_phases, the same weights its host
+ * restatement applies); float64 accumulation.  All pointers DEVICE.  ABI 2.06. */
+int ov_polyphase_fir_f32(const float* x, const double* h, float* y, int64_t n_in, int64_t n_out, int P, int Q, int taps,
+                         ov_stream_t stream);
+
 /* conv_post + tanh, reference openvoice/models.py:287-289:
  * out[b][0][t] = tanh( sum_{c,j} w[c][j] * lrelu(x[b][c][t+j-(K-1)/2], in_slope) ), no bias.
  * w is the dense [C][K] DEVICE weight. */
@@ -511,7 +520,7 @@ int ov_split3_to_f32(const uint16_t* a, const uint16_t* b, const uint16_t* c, in
  * ov_frame_limits_i32.  2.02: ov_unpad_rows_f32, ov_conv1d_bf16_pack16, ov_resblock_pair2_bf16cl (+ _supported).
  * 2.03: ov_conv1d_split3 (+ _pack_size, _pack, _supported), ov_split3_from_f32, ov_split3_to_f32.  2.04:
  * ov_conv1d_split3_params.col_limit / col_limit_scale.  2.05: ov_wn_layer_params.acts / row_split (the field that
- * was `reserved`; the struct grew by one pointer at its end).  The Python binding
+ * was `reserved`; the struct grew by one pointer at its end).  2.06: ov_polyphase_fir_f32.  The Python binding
  * refuses a library older than the entry points it calls (openvoice_amd/_lib.py MIN_VERSION). */
 int ov_version(void);
 /* 0 for a production build; non-zero = a measurement build with parts of the kernels compiled out (results are

@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OPENVOICE_AMD_LIB") or os.path.join(_HERE, "libopenvoice_amd.so")
 
 OV_OK = 0
-MIN_VERSION = 205     # ov_version() of the newest entry point this package calls (include/openvoice_amd.h)
+MIN_VERSION = 206     # ov_version() of the newest entry point this package calls (include/openvoice_amd.h)
 OV_ERRORS = {-1: "OV_E_BADARG", -2: "OV_E_UNSUPPORTED", -3: "OV_E_ALIGN", -4: "OV_E_LAUNCH"}
 
 EPI_LINEAR, EPI_GATE, EPI_RESSKIP, EPI_COUPLE, EPI_POSTERIOR, EPI_CONVT, EPI_MAGNITUDE = range(7)
@@ -133,6 +133,7 @@ SIGNATURES = {
     "ov_linear_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
     "ov_sequence_mask_f32": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
     "ov_unpad_rows_f32": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]),
+    "ov_polyphase_fir_f32": (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_int64, ctypes.c_int64, _i, _i, _i, _fp]),
     "ov_layernorm_freq_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_float, _fp]),
     "ov_conv2d_s2_relu_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -219,8 +219,8 @@ class ToneColorConverter(OpenVoiceBaseClass):
         other lengths keep the per-file path.  The mean runs over files in the caller's order either way."""
         if isinstance(ref_wav_list, str):
             ref_wav_list = [ref_wav_list]
-        audios = [np.ascontiguousarray(audio_io.load(f, sr=self.hps.data.sampling_rate)[0], dtype=np.float32)
-                  for f in ref_wav_list]
+        # (decoded on the host, resampled -- where the file's rate differs -- by the device kernel: audio_io.load_to_device)
+        audios = [audio_io.load_to_device(f, self.hps.data.sampling_rate, self.device) for f in ref_wav_list]
         gs = self.extract_se_from_audio(audios)
         if se_save_path is not None:
             os.makedirs(os.path.dirname(se_save_path), exist_ok=True)
@@ -323,8 +323,7 @@ class ToneColorConverter(OpenVoiceBaseClass):
     def convert(self, audio_src_path, src_se, tgt_se, output_path=None, tau=0.3, message="default"):
         """reference: openvoice/api.py:141-160."""
         hps = self.hps
-        audio, _ = audio_io.load(audio_src_path, sr=hps.data.sampling_rate)
-        y = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32)).unsqueeze(0)
+        y = audio_io.load_to_device(audio_src_path, hps.data.sampling_rate, self.device).unsqueeze(0)
         o_hat, _ = self.convert_batch(y, src_se, tgt_se, tau=tau)
         audio = o_hat[0, 0].data.cpu().float().numpy()
         audio = self.add_watermark(audio, message)

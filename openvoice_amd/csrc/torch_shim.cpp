@@ -74,12 +74,14 @@ struct DeviceScope {
 
 template <typename E> bool dtype_ok(at::ScalarType s);
 template <> bool dtype_ok<float>(at::ScalarType s) { return s == at::kFloat; }
+template <> bool dtype_ok<double>(at::ScalarType s) { return s == at::kDouble; }
 template <> bool dtype_ok<int64_t>(at::ScalarType s) { return s == at::kLong; }
 template <> bool dtype_ok<int32_t>(at::ScalarType s) { return s == at::kInt; }
 template <> bool dtype_ok<uint16_t>(at::ScalarType s) { return s == at::kBFloat16 || s == at::kShort || s == at::kUInt16; }
 template <> bool dtype_ok<unsigned long long>(at::ScalarType s) { return s == at::kLong || s == at::kUInt64; }
 template <typename E> const char* dtype_name();
 template <> const char* dtype_name<float>() { return "float32"; }
+template <> const char* dtype_name<double>() { return "float64"; }
 template <> const char* dtype_name<int64_t>() { return "int64"; }
 template <> const char* dtype_name<int32_t>() { return "int32"; }
 template <> const char* dtype_name<uint16_t>() { return "bfloat16 (or int16 bit patterns)"; }
@@ -376,6 +378,7 @@ TORCH_LIBRARY(openvoice_amd, m) {
   bind_device<&ov_linear_f32>(m, "linear_f32");
   bind_device<&ov_sequence_mask_f32>(m, "sequence_mask_f32");
   bind_device<&ov_unpad_rows_f32>(m, "unpad_rows_f32");
+  bind_device<&ov_polyphase_fir_f32>(m, "polyphase_fir_f32");
   bind_device<&ov_layernorm_freq_f32>(m, "layernorm_freq_f32");
   bind_device<&ov_conv2d_s2_relu_f32>(m, "conv2d_s2_relu_f32");
   bind_device<&ov_gru_f32>(m, "gru_f32");

@@ -319,4 +319,4 @@ def test_conv_split3_params_struct_matches_header_field_order():
     assert ctypes.sizeof(_lib.ConvSplit3Params) == 128     # 5 pointers, 3 int64, 8 int32, 3 float, 1 int32, 2 pointers
     lib = _lib.load()
     assert lib.ov_conv1d_split3(None, None) == -1
-    assert lib.ov_version() >= _lib.MIN_VERSION == 205
+    assert lib.ov_version() >= _lib.MIN_VERSION == 206

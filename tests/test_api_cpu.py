@@ -225,3 +225,24 @@ def test_kaiser_best_resampler_is_band_limited_interpolation():
     assert audio_io.resample(x, 22050, 22050) is x
     with pytest.raises(ValueError):
         audio_io.resample(x, 48000, 22050, "sinc_fastest")
+
+
+def test_kaiser_best_phase_weights_are_what_both_resampler_forms_apply():
+    """``audio_io.kaiser_best_phases``: [P][2 taps] float64 weights shared by the host restatement and the device kernel
+    (``ov_polyphase_fir_f32``, tests/test_gpu_resample.py).  The kernel's indexing -- y[t] = h[t % P] . x[(t Q) // P -
+    taps + 1 ...] -- restated in numpy equals ``resample_kaiser_best``; at equal rates' simplest ratio (2 : 1) there is
+    one phase, symmetric about the sample it sits on."""
+    import numpy as np
+    from openvoice_amd import audio_io
+    h, P, Q, taps = audio_io.kaiser_best_phases(44100, 22050)
+    assert (P, Q) == (1, 2) and h.shape == (1, 2 * taps) and h.dtype == np.float64
+    assert np.allclose(h[0, :taps - 1][::-1], h[0, taps:2 * taps - 1])      # x[n - k] and x[n + k] weigh the same (k >= 1)
+    for sr_in, sr_out in ((48000, 22050), (16000, 22050)):
+        h, P, Q, taps = audio_io.kaiser_best_phases(sr_in, sr_out)
+        x = np.random.default_rng(sr_in).standard_normal(3000).astype(np.float32)
+        want = audio_io.resample_kaiser_best(x, sr_in, sr_out)
+        xp = np.concatenate([np.zeros(taps), x.astype(np.float64), np.zeros(taps + Q + 1)])
+        t = np.arange(len(want))
+        n = (t * Q) // P
+        got = np.array([h[tt % P] @ xp[nn + 1:nn + 1 + 2 * taps] for tt, nn in zip(t, n)]).astype(np.float32)
+        assert np.abs(got - want).max() <= 1e-6
