@@ -133,6 +133,55 @@ def _tables():
     return t
 
 
+_CORE = None                                            # ctypes handle of libov_mp3.so; False = not built
+
+
+def _core():
+    """The C Huffman core (csrc/mp3_core.c -> libov_mp3.so) when it is built, else None (the Python form below is used).
+    ``OPENVOICE_AMD_MP3_CORE=0`` forces the Python form (tests compare the two)."""
+    global _CORE
+    if os.environ.get("OPENVOICE_AMD_MP3_CORE", "1") == "0":
+        return None
+    if _CORE is None:
+        import ctypes
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libov_mp3.so")
+        try:
+            lib = ctypes.CDLL(path)
+            lib.ovmp3_huffman.restype = ctypes.c_int64
+            lib.ovmp3_huffman.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                          ctypes.c_void_p]
+            _CORE = lib
+        except OSError:
+            _CORE = False
+    return _CORE or None
+
+
+def _huffman_core(lib, br, g, end, bounds, t):
+    """``_huffman`` through the C core: the same look-up tables as uint32 arrays, the same bit positions."""
+    import ctypes
+    c = t.get("core")
+    if c is None:
+        c = t["core"] = dict(
+            lut={tid: np.asarray(lut, dtype=np.uint32) for tid, (_, lut) in t["huff"].items()},
+            quad=[np.asarray(lut, dtype=np.uint32) for _, lut in t["quad"]])
+    ptrs = (ctypes.c_void_p * 3)()
+    ml, lb = np.zeros(3, dtype=np.int32), np.zeros(3, dtype=np.int32)
+    for region in range(3):
+        sel = g["table_select"][region]
+        tid = TABLE_OF[sel]
+        if tid:
+            ptrs[region] = c["lut"][tid].ctypes.data
+            ml[region], lb[region] = t["huff"][tid][0], LINBITS[sel]
+    q = g["count1table_select"]
+    out = np.empty(578, dtype=np.int32)
+    b = np.asarray(bounds, dtype=np.int32)
+    lib.ovmp3_huffman(br.buf, len(br.buf), br.pos, end, b.ctypes.data, ctypes.addressof(ptrs), ml.ctypes.data, lb.ctypes.data,
+                      c["quad"][q].ctypes.data, t["quad"][q][0], out.ctypes.data)
+    br.pos = end
+    return out[:576]
+
+
 class _Bits:
     """MSB-first bit reader over a bytes-like object."""
     __slots__ = ("buf", "pos", "n")
@@ -376,6 +425,9 @@ def _huffman(br, g, end, rate_index, t):
         r1 = int(li[min(g["region0_count"] + 1, 22)])
         r2 = int(li[min(g["region0_count"] + g["region1_count"] + 2, 22)])
     bounds = (min(r1, big), min(r2, big), big)
+    lib = _core()
+    if lib is not None:
+        return _huffman_core(lib, br, g, end, bounds, t)
     buf, pos = br.buf, br.pos
     i = 0
     for region in range(3):
@@ -653,20 +705,21 @@ def decode(data, trim_gapless=True, clip=True):
         # ---- hybrid filter bank (2.4.3.4.9 / .10): reorder, alias reduction, IMDCT, overlap-add, frequency inversion -- over
         # blocks of granules (one numpy call per step and block instead of per granule; blocks small enough to stay in cache)
         tail = np.zeros((32, 18))                                           # second IMDCT half of the granule before
-        blocks = []
+        hist = np.zeros((16, 64))                                           # the last 16 matrixed slots of the block before
+        at = 0
         for g0 in range(0, len(lines[ch]), HYBRID_BLOCK):
-            sb, tail = _hybrid(np.stack(lines[ch][g0:g0 + HYBRID_BLOCK]), np.asarray(kinds[ch][g0:g0 + HYBRID_BLOCK]), tail,
-                               row, t)
-            blocks.append(sb)
-        s = np.concatenate(blocks, axis=0)                                  # [slots][32 subbands]
-        # ---- polyphase synthesis, all time slots at once: V = S N, out[t][j] = sum_i D[64 i + j] V[t - 2 i][j] + D[64 i + 32 + j] V[t - 2 i - 1][32 + j]
-        v = np.concatenate([np.zeros((16, 64)), s @ t["synth"]], axis=0)    # 16 slots of history
-        n = s.shape[0]
-        out = np.zeros((n, 32))
-        for i in range(8):
-            out += win[64 * i:64 * i + 32] * v[16 - 2 * i:16 - 2 * i + n, :32]
-            out += win[64 * i + 32:64 * i + 64] * v[15 - 2 * i:15 - 2 * i + n, 32:]
-        pcm[ch] = out.reshape(-1)
+            s, tail = _hybrid(np.stack(lines[ch][g0:g0 + HYBRID_BLOCK]), np.asarray(kinds[ch][g0:g0 + HYBRID_BLOCK]), tail,
+                              row, t)                                       # [slots][32 subbands]
+            # ---- polyphase synthesis of the block's slots: V = S N, out[t][j] = sum_i D[64 i + j] V[t - 2 i][j] + D[64 i + 32 + j] V[t - 2 i - 1][32 + j]
+            v = np.concatenate([hist, s @ t["synth"]], axis=0)
+            hist = v[-16:]
+            n = s.shape[0]
+            out = np.zeros((n, 32))
+            for i in range(8):
+                out += win[64 * i:64 * i + 32] * v[16 - 2 * i:16 - 2 * i + n, :32]
+                out += win[64 * i + 32:64 * i + 64] * v[15 - 2 * i:15 - 2 * i + n, 32:]
+            pcm[ch, at:at + 32 * n] = out.reshape(-1)
+            at += 32 * n
     if trim_gapless and info["xing"] and (info["start_pad"] or info["end_pad"]):
         # what FFmpeg's demuxer does with the LAME fields: skip start_pad + 528 + 1 samples, end at
         # frames * 1152 - end_pad + 528 + 1 (the decoder itself delays the signal by 528 + 1 samples)

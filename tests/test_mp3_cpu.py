@@ -175,3 +175,21 @@ def test_truncated_prefixed_and_corrupted_streams_decode_without_surprises():
     broken[4001] ^= 0x55
     pcm, _ = mp3.decode(bytes(broken))
     assert pcm.shape == full.shape and np.isfinite(pcm).all() and np.abs(pcm).max() <= 1.0
+
+
+def test_c_huffman_core_and_python_form_decode_identically(monkeypatch):
+    """The Huffman decoding runs in C when ``libov_mp3.so`` is built (csrc/mp3_core.c, part of ``make`` /
+    ``__graft_entry__.build()``) and in Python otherwise: same tables, same bit positions, bit-identical PCM -- on a real
+    joint-stereo file and on synthetic streams with escape values, all block kinds and both count1 tables."""
+    if mp3._core() is None:
+        pytest.skip("libov_mp3.so is not built")
+    streams = [open(p, "rb").read() for p in (CASES["invalid_keypress"],) if os.path.exists(p)]
+    for name in ("mp3_syn_mpeg1_48000_stereo_ms", "mp3_lsf_mpeg25_11025_stereo", "mp3_syn_mpeg2_16000_intensity"):
+        streams.append(bytes(np.load(os.path.join(GOLDEN, f"{name}.npz"))["stream"]))
+    for data in streams:
+        with_core, rate = mp3.decode(data)
+        monkeypatch.setenv("OPENVOICE_AMD_MP3_CORE", "0")
+        assert mp3._core() is None
+        in_python, rate2 = mp3.decode(data)
+        monkeypatch.delenv("OPENVOICE_AMD_MP3_CORE")
+        assert rate == rate2 and np.array_equal(with_core, in_python)
