@@ -119,3 +119,17 @@ def test_split_conv_traffic_per_instance_and_its_gate_in_bench(tmp_path, monkeyp
     from openvoice_amd.hostinfo import split3_source_digest
     with open(os.path.join(ROOT, "profiles", "split3_traffic_latest.json")) as fh:
         assert json.load(fh)["split3_source_digest"] == split3_source_digest()
+
+
+def test_committed_counter_records_belong_to_the_committed_sources():
+    """bench.py reports a PMC figure only when the committed record's digest equals the running tree's; a record gone stale
+    (a kernel source, the C ABI header or engine.py edited without re-running the PMC passes: scripts/gpu_r5_s27.sh /
+    gpu_r5_s20.sh / profile_bf16.sh) would silently turn ``roofline.traffic`` into null on the contract line -- fail here
+    instead."""
+    sys.path.insert(0, ROOT)
+    from openvoice_amd.engine import PAIR_POLICY
+    from openvoice_amd.hostinfo import bf16_source_digest, launch_config_digest, split3_source_digest
+    load = lambda name: json.load(open(os.path.join(ROOT, "profiles", name)))
+    assert load("pmc_traffic_latest.json")["launch_config_digest"] == launch_config_digest(32, 861, True, PAIR_POLICY)
+    assert load("split3_traffic_latest.json")["split3_source_digest"] == split3_source_digest()
+    assert load("bf16_counters_latest.json")["bf16_source_digest"] == bf16_source_digest()
