@@ -516,11 +516,53 @@ int ov_split3_from_f32(const float* x, uint16_t* planes, int64_t plane_stride, i
 int ov_split3_to_f32(const uint16_t* a, const uint16_t* b, const uint16_t* c, int64_t plane_stride, float* out, int B,
                      int C, int L, float in_slope, float scale, ov_stream_t stream);
 
+/* ---- Winograd-domain fp32 Conv1d (round 6; openvoice_amd/csrc/conv1d_wino.h) --------------------------------------
+ * The stride-1 'same' convs of ResBlock1, reference openvoice/modules.py:296-306 -- xt = c1(lrelu(x)), xt = c2(lrelu(xt)),
+ * x = xt + x -- and the MRF sum / mean of models.py:280-286, with fewer executed multiplies than the direct form:
+ *   out = (conv1d(lrelu(x, in_slope), w, dilation dil) + bias [+ res] [+ add]) * scale
+ * evaluated as ceil(K/3) shifted 3-tap groups by the minimal-filtering algorithm F(4, 3) (interpolation points 0, +-1, +-2,
+ * infinity): weights transformed once in float64 at pack time, input tiles transformed in fp32 on the way into LDS, the
+ * products of all groups and input channels accumulated in the transform domain on v_mfma_f32_32x32x2_f32 (six GEMMs,
+ * one per point), the inverse transform + operands in the epilogue.  fp32 arithmetic throughout; executed MACs per
+ * output and (co, ci): 1.5 (K = 3), 4.5 (K = 7), 6 (K = 11) instead of K.  The transforms round where the direct conv
+ * does not: against float64 the result carries ~4x the rounding error of ov_conv1d_f32 (tests/test_gpu_wino.py).
+ * Tensors are fp32 [B][C][L], rows x_ld / out_ld floats apart (0 = L); L, x_ld, out_ld multiples of 4 and every
+ * pointer 16-byte aligned; Cin % ov_conv1d_wino_chunk(K) == 0, Cout % 128 == 0; out must alias neither x, res nor add. */
+typedef struct ov_conv1d_wino_params {
+  const float* x;        /* [B][Cin][L] */
+  const float* w;        /* ov_conv1d_wino_pack_f32(Cout, Cin, K) */
+  const float* bias;     /* [Cout] natural row order; required (zeros if none) */
+  float* out;            /* [B][Cout][L] */
+  const float* res;      /* residual, indexed like out, or NULL */
+  const float* add;      /* second addend (MRF running sum), indexed like out, or NULL */
+  int64_t x_bstride, out_bstride, res_bstride, add_bstride;   /* elements between consecutive utterances */
+  int32_t B, Cin, Cout, L;
+  int32_t x_ld, out_ld;  /* row strides in floats; 0 = L */
+  int32_t K, dil;
+  int32_t nwg;           /* 0 = one workgroup per resident slot; n > 0 forces n workgroups (tests) */
+  int32_t reserved0;
+  float in_slope;        /* leaky-ReLU slope applied to x while staging (1.0f = identity) */
+  float scale;
+} ov_conv1d_wino_params;
+int ov_conv1d_wino_f32(const ov_conv1d_wino_params* p, ov_stream_t stream);
+/* 1 when (Cin, Cout, K, dil) has an instance, else 0 (callers then use ov_conv1d_f32). */
+int ov_conv1d_wino_supported(int Cin, int Cout, int K, int dil);
+/* Input channels per LDS fill of the K-tap instance (the packed stream is ordered by it); 0 = no instance. */
+int ov_conv1d_wino_chunk(int K);
+/* Floats of the packed transform-domain weights; 0 when the shape has no instance. */
+size_t ov_conv1d_wino_pack_size(int Cout, int Cin, int K);
+/* HOST w [Cout][Cin][K] fp32 -> U_p[co][g][ci] = sum_k G[p][k] w[co][ci][3g + k] (float64, rounded once to fp32) in
+ * 32x32x2 A-fragment order: 1 KiB sub-record ((mt * Cin/CI + c) * (CI * G / 4) + sp) * 3 + j holds for lane l elements
+ * 4j .. 4j + 3 of the 12-vector [k-step 2sp: p = 0..5][k-step 2sp + 1: p = 0..5] of row 32 mt + (l & 31) and k-row
+ * 2 * kstep + (l >> 5) = g * CI + ci_local of chunk c; three zero sub-records close the stream (HOST dst). */
+int ov_conv1d_wino_pack_f32(const float* w, int Cout, int Cin, int K, float* dst);
+
 /* Library/ABI version (major*100 + minor).  2.01: ov_conv1d_params.col_limit, ov_conv_post_tanh_limited_f32,
  * ov_frame_limits_i32.  2.02: ov_unpad_rows_f32, ov_conv1d_bf16_pack16, ov_resblock_pair2_bf16cl (+ _supported).
  * 2.03: ov_conv1d_split3 (+ _pack_size, _pack, _supported), ov_split3_from_f32, ov_split3_to_f32.  2.04:
  * ov_conv1d_split3_params.col_limit / col_limit_scale.  2.05: ov_wn_layer_params.acts / row_split (the field that
- * was `reserved`; the struct grew by one pointer at its end).  2.06: ov_polyphase_fir_f32.  The Python binding
+ * was `reserved`; the struct grew by one pointer at its end).  2.06: ov_polyphase_fir_f32.  2.07: ov_conv1d_wino_f32 (+ _supported, _chunk,
+ * _pack_size, _pack_f32).  The Python binding
  * refuses a library older than the entry points it calls (openvoice_amd/_lib.py MIN_VERSION). */
 int ov_version(void);
 /* 0 for a production build; non-zero = a measurement build with parts of the kernels compiled out (results are

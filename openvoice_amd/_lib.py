@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OPENVOICE_AMD_LIB") or os.path.join(_HERE, "libopenvoice_amd.so")
 
 OV_OK = 0
-MIN_VERSION = 206     # ov_version() of the newest entry point this package calls (include/openvoice_amd.h)
+MIN_VERSION = 207     # ov_version() of the newest entry point this package calls (include/openvoice_amd.h)
 OV_ERRORS = {-1: "OV_E_BADARG", -2: "OV_E_UNSUPPORTED", -3: "OV_E_ALIGN", -4: "OV_E_LAUNCH"}
 
 EPI_LINEAR, EPI_GATE, EPI_RESSKIP, EPI_COUPLE, EPI_POSTERIOR, EPI_CONVT, EPI_MAGNITUDE = range(7)
@@ -100,6 +100,17 @@ class ConvSplit3Params(ctypes.Structure):
                 ("col_limit_scale", ctypes.c_int32), ("dbg", _fp), ("col_limit", _fp)]
 
 
+class ConvWinoParams(ctypes.Structure):
+    """Mirror of ``ov_conv1d_wino_params`` (include/openvoice_amd.h)."""
+    _fields_ = [("x", _fp), ("w", _fp), ("bias", _fp), ("out", _fp), ("res", _fp), ("add", _fp),
+                ("x_bstride", ctypes.c_int64), ("out_bstride", ctypes.c_int64), ("res_bstride", ctypes.c_int64),
+                ("add_bstride", ctypes.c_int64),
+                ("B", ctypes.c_int32), ("Cin", ctypes.c_int32), ("Cout", ctypes.c_int32), ("L", ctypes.c_int32),
+                ("x_ld", ctypes.c_int32), ("out_ld", ctypes.c_int32), ("K", ctypes.c_int32), ("dil", ctypes.c_int32),
+                ("nwg", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+                ("in_slope", ctypes.c_float), ("scale", ctypes.c_float)]
+
+
 class WnLayerParams(ctypes.Structure):
     """Mirror of ``ov_wn_layer_params`` (include/openvoice_amd.h)."""
     _fields_ = [("x", _fp), ("out", _fp), ("skip", _fp), ("w_in", _fp), ("b_in", _fp), ("cond", _fp), ("w_rs", _fp),
@@ -154,6 +165,11 @@ SIGNATURES = {
     "ov_conv1d_split3_supported": (ctypes.c_int, [_i, _i, _i, _i]),
     "ov_split3_from_f32": (ctypes.c_int, [_fp, _fp, _i64, _i, _i, _i, ctypes.c_float, _fp]),
     "ov_split3_to_f32": (ctypes.c_int, [_fp, _fp, _fp, _i64, _fp, _i, _i, _i, ctypes.c_float, ctypes.c_float, _fp]),
+    "ov_conv1d_wino_f32": (ctypes.c_int, [ctypes.POINTER(ConvWinoParams), _fp]),
+    "ov_conv1d_wino_supported": (ctypes.c_int, [_i, _i, _i, _i]),
+    "ov_conv1d_wino_chunk": (ctypes.c_int, [_i]),
+    "ov_conv1d_wino_pack_size": (ctypes.c_size_t, [_i, _i, _i]),
+    "ov_conv1d_wino_pack_f32": (ctypes.c_int, [_fp, _i, _i, _i, _fp]),
     "ov_frame_hops_f32": (ctypes.c_int, [_fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
     "ov_embed_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, ctypes.c_float, _fp]),
     "ov_layernorm_ch_f32": (ctypes.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, ctypes.c_float, _i, _fp]),
@@ -223,7 +239,7 @@ _ops = None
 VALUE_FUNCS = {"ov_version", "ov_build_experiment", "ov_conv1d_pack_size", "ov_conv1d_pack_rows", "ov_wn_pack_size",
                "ov_conv1d_bf16_pack_size", "ov_resblock_pair_supported", "ov_wn_layer_supported", "ov_wn_layer_tile",
                "ov_resblock_pair_bf16_supported", "ov_resblock_pair2_bf16_supported", "ov_conv1d_split3_pack_size",
-               "ov_conv1d_split3_supported"}
+               "ov_conv1d_split3_supported", "ov_conv1d_wino_supported", "ov_conv1d_wino_chunk", "ov_conv1d_wino_pack_size"}
 
 
 def binding():

@@ -1,0 +1,342 @@
+// Winograd-domain Conv1d on the gfx950 fp32 matrix pipe: the K-tap stride-1 'same' conv of a ResBlock
+// (reference: openvoice/modules.py:296-309) computed as ceil(K/3) shifted 3-tap groups, each by the minimal-filtering
+// algorithm F(4, 3) -- 6 products per 4 outputs per (co, ci, group) where the direct form needs 12 -- with the
+// products of all groups and input channels accumulated in the TRANSFORM domain on v_mfma_f32_32x32x2_f32:
+//
+//   out[co][4j + i] = sum_p At[i][p] * Y_p[co][j],      Y_p[co][j] = sum_{g, ci} U_p[co][g][ci] * V_p[g][ci][j]
+//   U_p[co][g][ci]  = sum_k G[p][k] * w[co][ci][3g + k]               (weights: float64 at pack time, once)
+//   V_p[g][ci][j]   = sum_m Bt[p][m] * act(x[ci][4j + 3g + m - PAD])  (inputs: VALU, on the way into LDS)
+//
+// i.e. six independent GEMMs (one per interpolation point p: 0, +-1, +-2, infinity) with M = co, N = tile index j,
+// K_gemm = (group, ci).  Executed MACs per 4 outputs and (co, ci): K = 3: 6 (direct 12), K = 7: 18 (28), K = 11: 24 (44).
+// fp32 throughout; the transforms round where the direct form does not, so the result carries ~4x the direct kernel's
+// rounding error (measured against float64: profiles/r06_*), two orders of magnitude inside the path's 1e-3 bar.
+//
+// One workgroup = 4 MATRIX waves (wave w owns output rows 32w .. 32w + 31 of a 128-row M-block x 32 tiles = 128
+// columns: 6 accumulator fragments = 96 VGPRs) + 2 HELPER waves; 2 workgroups per CU.  Input channels are walked in
+// chunks of CI.  Per chunk the helpers (a) stage the raw rows (leaky ReLU applied, zero outside [0, L)) from HBM
+// through registers into LDS, one chunk ahead, and (b) transform the previous raw chunk into V[k = g*CI + ci][tile][6]
+// (5 ds_read_b128 -> 48 VALU -> 12 ds_write_b64 per (ci, tile) at K = 11), double buffered; ONE s_barrier per chunk.
+// A matrix wave reads its B operands as three conflict-free ds_read_b64 per k-step (two points each) and streams its A
+// operands (U, fragment order, 3 KiB per k-step pair) from L2 one pair ahead; the epilogue applies At, adds bias /
+// residual / MRF running sum, scales, and stores 16 bytes per lane and row (a lane's 4 outputs are consecutive columns).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+
+#include "conv1d_mfma.h"
+#include "openvoice_amd.h"
+
+namespace ovkw {
+
+using ovk::f32x16;
+using ovk::f32x2;
+using ovk::f32x4;
+
+constexpr int NT = 32;          // Winograd tiles per N-block = one MFMA N fragment
+constexpr int NCOL = 4 * NT;    // output columns per N-block
+constexpr int RW = 144;         // floats per raw LDS row: column t0 - 8 + c at index c
+constexpr int RW4 = RW / 4;
+constexpr int NHELP = 2;        // helper waves per workgroup
+constexpr int REC = 256;        // floats per 1 KiB weight sub-record
+constexpr int MAX_COUT = 512;   // rows of the bias vector kept in LDS
+
+// Geometry of a K-tap conv: group g holds taps 3g .. 3g + 2 (taps >= K are zero).
+template <int K>
+struct Geo {
+  static constexpr int G = (K + 2) / 3;
+  static constexpr int PAD = (K - 1) / 2;
+  static constexpr int OFF0 = 8 - PAD;                          // raw index of input m = 0 of (tile 0, group 0)
+  static constexpr int WSTART = OFF0 / 4 * 4;                   // aligned start of a tile's input window
+  static constexpr int WLEN = OFF0 - WSTART + 3 * (G - 1) + 6;  // floats of the window all groups read
+  static constexpr int NB128 = (WLEN + 3) / 4;
+  static_assert(PAD <= 8 && WSTART + 4 * (NT - 1) + 4 * NB128 <= RW, "input window exceeds the raw row");
+};
+
+// Packed weights: sub-record ((mt * nchunks + c) * NPAIR + sp) * 3 + j, 64 lanes x 4 floats; lane l holds elements
+// 4j .. 4j + 3 of its 12-vector [k-step 2sp: p = 0..5][k-step 2sp + 1: p = 0..5] of row 32 mt + (l & 31), k-row
+// kk = 2 * kstep + (l >> 5) of chunk c, kk = g * CI + ci_local.  Three zero sub-records close the stream.
+__host__ __device__ inline size_t wino_pack_floats(int Cout, int Cin, int K, int CI) {
+  const int G = (K + 2) / 3;
+  return ((size_t)(Cout / 32) * (Cin / CI) * (CI * G / 4) * 3 + 3) * REC;
+}
+
+template <int K, int CI>
+__global__ __launch_bounds__(64 * (4 + NHELP), 3) void conv1d_wino_kernel(const ov_conv1d_wino_params p) {
+  using Ge = Geo<K>;
+  constexpr int G = Ge::G, KR = CI * G, NSTEP = KR / 2, NPAIR = NSTEP / 2;
+  static_assert(KR % 4 == 0 && CI % 2 == 0, "k-rows in whole k-step pairs");
+  constexpr int RAWBUF = CI * RW;        // floats per raw buffer
+  constexpr int VBUF = KR * NT * 6;      // floats per V buffer
+  __shared__ __attribute__((aligned(16))) float raw[2 * RAWBUF];
+  __shared__ __attribute__((aligned(16))) float Vs[2 * VBUF];
+  __shared__ __attribute__((aligned(16))) float bias_s[MAX_COUT];   // read back 16 bytes at a time at every item start
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = p.L;
+  const int nchunks = p.Cin / CI;
+  const int ntiles = (L + NCOL - 1) / NCOL;
+  const int mblocks = p.Cout / 128;
+  const int total = ntiles * mblocks * p.B;
+  auto decode = [&](int w, int& ub, int& utile, int& umblk) {
+    const int g = w / mblocks;
+    umblk = w - g * mblocks;
+    ub = g / ntiles;
+    utile = g - ub * ntiles;
+  };
+  // XCD-contiguous order (see conv1d_mfma.h): XCD x = blockIdx.x % 8 owns a contiguous eighth of the list
+  int wid0 = blockIdx.x, wend = total, wstride = gridDim.x;
+  if ((gridDim.x & 7u) == 0) {
+    const int xcd = blockIdx.x & 7;
+    const int lo = (int)(((long long)xcd * total) >> 3);
+    wend = (int)(((long long)(xcd + 1) * total) >> 3);
+    wid0 = lo + (int)(blockIdx.x >> 3);
+    wstride = gridDim.x >> 3;
+  }
+  if (wid0 >= wend) return;
+  const int nitems = (wend - wid0 + wstride - 1) / wstride;
+  const int nstream = nitems * nchunks;      // chunks this workgroup walks, across its items
+  for (int i = tid; i < p.Cout; i += 64 * (4 + NHELP)) bias_s[i] = p.bias[i];   // visible after barrier (A)
+
+  const bool is_helper = (wave == 4) | (wave == 5);
+  if (is_helper) {
+    // ================================ helper waves ================================================
+    const float slope = p.in_slope;
+    const uint32_t ldx = (uint32_t)p.x_ld;
+    const int hl = (wave - 4) * 64 + lane;
+    constexpr int NITEM = CI * RW4;                          // 16-byte staging vectors per chunk
+    constexpr int NLOAD = (NITEM + 64 * NHELP - 1) / (64 * NHELP);
+    f32x4 stg[NLOAD];
+    int nval[NLOAD];
+    int lwid = wid0, lchunk = 0, lpos = 0;                   // position of the staging stream
+    int lb, ltile, lmblk;
+    decode(lwid, lb, ltile, lmblk);
+
+    auto issue_loads = [&]() {
+      const bool live = lpos < nstream;
+      const int t0 = ltile * NCOL;
+      const float* __restrict__ xb = p.x + (int64_t)lb * p.x_bstride;
+#pragma unroll
+      for (int i = 0; i < NLOAD; ++i) {
+        const int idx = i * (64 * NHELP) + hl;
+        const int row = idx / RW4, c4 = idx - row * RW4;
+        const int ci = lchunk * CI + row;
+        const int t = t0 - 8 + 4 * c4;                       // multiple of 4: a vector is wholly inside or outside
+        const bool ok = live && idx < NITEM && t >= 0 && t < L;
+        const uint32_t goff = ok ? (uint32_t)ci * ldx + (uint32_t)t : 0u;
+        nval[i] = ok ? min(L - t, 4) : 0;
+        stg[i] = *reinterpret_cast<const f32x4*>(xb + goff);
+      }
+      ++lpos;
+      if (++lchunk == nchunks) {
+        lchunk = 0;
+        lwid += wstride;
+        if (lwid < wend) decode(lwid, lb, ltile, lmblk);
+      }
+    };
+    auto write_raw = [&](int buf) {
+      float* dst = raw + buf * RAWBUF;
+#pragma unroll
+      for (int i = 0; i < NLOAD; ++i) {
+        const int idx = i * (64 * NHELP) + hl;
+        if (idx < NITEM) {
+          f32x4 v = stg[i];
+          const int n = nval[i];
+          v[0] = n > 0 ? ovk::lrelu(v[0], slope) : 0.f;
+          v[1] = n > 1 ? ovk::lrelu(v[1], slope) : 0.f;
+          v[2] = n > 2 ? ovk::lrelu(v[2], slope) : 0.f;
+          v[3] = n > 3 ? ovk::lrelu(v[3], slope) : 0.f;
+          *reinterpret_cast<f32x4*>(dst + 4 * idx) = v;       // row * RW + 4 * c4 == 4 * idx
+        }
+      }
+    };
+    // raw[buf] -> V[buf]: item = (ci_local, tile); V[(g * CI + ci_local) * NT + tile][6]
+    auto transform = [&](int buf) {
+      const float* src = raw + buf * RAWBUF;
+      float* dst = Vs + buf * VBUF;
+      constexpr int ROUNDS = CI * NT / (64 * NHELP);
+      static_assert(CI * NT % (64 * NHELP) == 0, "whole rounds of helper lanes");
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) {
+        const int idx = r * (64 * NHELP) + hl;
+        const int tile = idx & (NT - 1), cil = idx >> 5;
+        float win[4 * Ge::NB128];
+#pragma unroll
+        for (int q = 0; q < Ge::NB128; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src + cil * RW + Ge::WSTART + 4 * tile + 4 * q);
+          win[4 * q] = v[0]; win[4 * q + 1] = v[1]; win[4 * q + 2] = v[2]; win[4 * q + 3] = v[3];
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const int o = Ge::OFF0 - Ge::WSTART + 3 * g;
+          const float d0 = win[o], d1 = win[o + 1], d2 = win[o + 2], d3 = win[o + 3], d4 = win[o + 4], d5 = win[o + 5];
+          // Bt d, points 0, 1, -1, 2, -2, infinity
+          const float t1 = __builtin_fmaf(-4.f, d2, d4), t2 = __builtin_fmaf(-4.f, d1, d3);
+          const float t3 = d4 - d2, t4 = d3 - d1;
+          f32x2 v01, v23, v45;
+          v01[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+          v01[1] = t1 + t2;
+          v23[0] = t1 - t2;
+          v23[1] = __builtin_fmaf(2.f, t4, t3);
+          v45[0] = __builtin_fmaf(-2.f, t4, t3);
+          v45[1] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+          float* o6 = dst + ((g * CI + cil) * NT + tile) * 6;
+          *reinterpret_cast<f32x2*>(o6) = v01;
+          *reinterpret_cast<f32x2*>(o6 + 2) = v23;
+          *reinterpret_cast<f32x2*>(o6 + 4) = v45;
+        }
+      }
+    };
+
+    issue_loads();
+    write_raw(0);                 // chunk 0
+    issue_loads();                // chunk 1 in registers
+    __syncthreads();              // (A) raw[0] complete
+    transform(0);
+    write_raw(1);
+    __syncthreads();              // (B) V[0], raw[1] complete
+    for (int i = 0; i < nstream; ++i) {
+      issue_loads();              // chunk i + 2 (nothing beyond the stream's end)
+      if (i + 1 < nstream) transform((i + 1) & 1);
+      write_raw(i & 1);
+      __syncthreads();            // V[(i + 1) & 1] and raw[i & 1] handed over; V[i & 1] free again
+    }
+    return;
+  }
+
+  // ================================== matrix waves ================================================
+  const int half = lane >> 5, n = lane & 31;
+  const f32x4* __restrict__ wbase = reinterpret_cast<const f32x4*>(p.w);
+  const uint32_t LD = (uint32_t)p.out_ld;
+  int wid = wid0, b, tile, mblk;
+  decode(wid, b, tile, mblk);
+  int mtile = mblk * 4 + wave;
+  // sub-record index of the first k-step pair of (mtile, chunk 0); the stream of an item is contiguous
+  uint32_t rec = (uint32_t)mtile * (uint32_t)nchunks * (uint32_t)(NPAIR * 3);
+  f32x4 a_cur[3], a_nxt[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) a_cur[j] = wbase[(size_t)(rec + j) * 64 + lane];
+  const int voffB = (half * NT + n) * 6;       // this lane's float offset inside a k-step's two k-rows
+
+  __syncthreads();   // (A)
+  __syncthreads();   // (B)
+  int it = 0;
+  while (true) {
+    f32x16 acc[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    // At column of point 1 is (1, 1, 1, 1): a bias there reaches all four outputs of a tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_s + mtile * 32 + 4 * half + 8 * i);
+      acc[1][4 * i] = bq[0]; acc[1][4 * i + 1] = bq[1]; acc[1][4 * i + 2] = bq[2]; acc[1][4 * i + 3] = bq[3];
+    }
+
+    for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
+      const float* vb = Vs + (it & 1) * VBUF + voffB;
+      f32x2 bcur[3], bnxt[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) bcur[q] = *reinterpret_cast<const f32x2*>(vb + 2 * q);
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) {
+        const int s2 = s & 1;
+        if (s2 == 0) {
+          rec += 3;   // the sub-records after the last real pair are zeros written by the packer
+#pragma unroll
+          for (int j = 0; j < 3; ++j) a_nxt[j] = wbase[(size_t)(rec + j) * 64 + lane];
+        }
+        if (s + 1 < NSTEP) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) bnxt[q] = *reinterpret_cast<const f32x2*>(vb + (s + 1) * (2 * NT * 6) + 2 * q);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const int e = s2 * 6 + q;
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[e >> 2][e & 3], bcur[q >> 1][q & 1], acc[q], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < NSTEP) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) bcur[q] = bnxt[q];
+        }
+        if (s2 == 1) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) a_cur[j] = a_nxt[j];
+        }
+      }
+      __syncthreads();
+    }
+
+    // next work item: its first weight pair and bias are in flight while this item's epilogue runs
+    const int nwid = wid + wstride;
+    const bool more = nwid < wend;
+    int nb = 0, ntile = 0, nmblk = 0;
+    if (more) decode(nwid, nb, ntile, nmblk);
+    const int nmtile = nmblk * 4 + wave;
+    const int ob = b, otile = tile, omtile = mtile;
+    if (more) {
+      rec = (uint32_t)nmtile * (uint32_t)nchunks * (uint32_t)(NPAIR * 3);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) a_cur[j] = wbase[(size_t)(rec + j) * 64 + lane];
+      wid = nwid; b = nb; tile = ntile; mblk = nmblk; mtile = nmtile;
+    }
+
+    // ---- epilogue: out = (At Y + res + add) * scale, 16 bytes per lane and row --------------------------------
+    {
+      const uint32_t col = (uint32_t)otile * NCOL + 4u * (uint32_t)n;
+      const bool colok = col < (uint32_t)L;                 // L % 4 == 0: a lane's 4 columns are in or out together
+      const uint32_t ccol = colok ? col : 0u;
+      const float scale = p.scale;
+      float* outb = p.out + (int64_t)ob * p.out_bstride;
+      const float* resb = p.res ? p.res + (int64_t)ob * p.res_bstride : nullptr;
+      const float* addb = p.add ? p.add + (int64_t)ob * p.add_bstride : nullptr;
+      const uint32_t rbase = (uint32_t)omtile * 32u + 4u * (uint32_t)half;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {                       // 4 rows at a time: bounds the operand temporaries
+        f32x4 rv[4], av[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t off = (rbase + (uint32_t)(j + 8 * rg)) * LD + ccol;
+          rv[j] = resb ? *reinterpret_cast<const f32x4*>(resb + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+          av[j] = addb ? *reinterpret_cast<const f32x4*>(addb + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * rg + j;
+          const float y0 = acc[0][r], y1 = acc[1][r], y2 = acc[2][r], y3 = acc[3][r], y4 = acc[4][r], y5 = acc[5][r];
+          const float s1 = y1 + y2, d1 = y1 - y2, s2 = y3 + y4, d2 = y3 - y4;
+          f32x4 o;
+          o[0] = (y0 + s1) + s2;
+          o[1] = __builtin_fmaf(2.f, d2, d1);
+          o[2] = __builtin_fmaf(4.f, s2, s1);
+          o[3] = __builtin_fmaf(8.f, d2, d1) + y5;
+          o = ((o + rv[j]) + av[j]) * scale;
+          if (colok) *reinterpret_cast<f32x4*>(outb + (rbase + (uint32_t)(j + 8 * rg)) * LD + col) = o;
+        }
+      }
+    }
+    if (!more) break;
+  }
+}
+
+template <int K, int CI>
+int wino_launch(const ov_conv1d_wino_params* p, hipStream_t stream) {
+  const int ntiles = (p->L + NCOL - 1) / NCOL;
+  const long total = (long)ntiles * (p->Cout / 128) * p->B;
+  auto kernel = conv1d_wino_kernel<K, CI>;
+  static std::atomic<int> slot_cache[ovk::OV_MAX_DEVICES];
+  const int slots = ovk::resident_workgroups(reinterpret_cast<const void*>(kernel), 64 * (4 + NHELP), slot_cache);
+  long nwg = p->nwg > 0 ? p->nwg : slots;
+  if (nwg > total) nwg = total;
+  if (nwg >= 8) nwg = (nwg + 7) / 8 * 8;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)nwg), dim3(64 * (4 + NHELP)), 0, stream, *p);
+  return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
+}
+
+}  // namespace ovkw

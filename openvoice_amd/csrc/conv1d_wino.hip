@@ -1,0 +1,86 @@
+// C ABI of the Winograd-domain fp32 Conv1d (kernel: conv1d_wino.h): weight packer, dispatcher, entry points.
+#include "conv1d_wino.h"
+
+#include <cstring>
+
+using namespace ovkw;
+
+namespace {
+
+// F(4, 3), points 0, 1, -1, 2, -2, infinity: the weight transform G (6 x 3).  Bt and At live in the kernel.
+const double kG[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                         {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
+
+constexpr int wino_ci(int K) { return K == 3 ? 16 : (K == 7 || K == 11) ? 8 : 0; }
+
+}  // namespace
+
+extern "C" {
+
+int ov_conv1d_wino_chunk(int K) { return wino_ci(K); }
+
+int ov_conv1d_wino_supported(int Cin, int Cout, int K, int dil) {
+  const int ci = wino_ci(K);
+  if (ci == 0 || dil != 1) return 0;
+  return (Cin > 0 && Cin % ci == 0 && Cout > 0 && Cout % 128 == 0) ? 1 : 0;
+}
+
+size_t ov_conv1d_wino_pack_size(int Cout, int Cin, int K) {
+  const int ci = wino_ci(K);
+  if (ci == 0 || Cin <= 0 || Cout <= 0 || Cin % ci != 0 || Cout % 32 != 0) return 0;
+  return wino_pack_floats(Cout, Cin, K, ci);
+}
+
+int ov_conv1d_wino_pack_f32(const float* w, int Cout, int Cin, int K, float* dst) {
+  const size_t nfl = ov_conv1d_wino_pack_size(Cout, Cin, K);
+  if (!w || !dst || nfl == 0) return OV_E_BADARG;
+  const int CI = wino_ci(K), G = (K + 2) / 3, KR = CI * G, NPAIR = KR / 4, nchunks = Cin / CI;
+  std::memset(dst, 0, nfl * sizeof(float));
+  for (int mt = 0; mt < Cout / 32; ++mt)
+    for (int c = 0; c < nchunks; ++c)
+      for (int sp = 0; sp < NPAIR; ++sp)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 12; ++e) {
+            const int kstep = 2 * sp + e / 6, pt = e % 6;
+            const int kk = 2 * kstep + (lane >> 5);
+            const int g = kk / CI, ci = c * CI + kk % CI;
+            const int co = 32 * mt + (lane & 31);
+            double u = 0.0;
+            for (int k = 0; k < 3; ++k) {
+              const int tap = 3 * g + k;
+              if (tap < K) u += kG[pt][k] * (double)w[((size_t)co * Cin + ci) * K + tap];
+            }
+            const size_t sub = (((size_t)mt * nchunks + c) * NPAIR + sp) * 3 + e / 4;
+            dst[sub * REC + (size_t)lane * 4 + e % 4] = (float)u;
+          }
+  return OV_OK;
+}
+
+int ov_conv1d_wino_f32(const ov_conv1d_wino_params* pin, ov_stream_t stream) {
+  if (!pin) return OV_E_BADARG;
+  ov_conv1d_wino_params q = *pin;
+  if (!q.x || !q.w || !q.bias || !q.out) return OV_E_BADARG;
+  if (q.B <= 0 || q.L <= 0 || q.nwg < 0) return OV_E_BADARG;
+  if (q.x_ld == 0) q.x_ld = q.L;
+  if (q.out_ld == 0) q.out_ld = q.L;
+  if (q.x_ld < q.L || q.out_ld < q.L) return OV_E_BADARG;
+  if (!ov_conv1d_wino_supported(q.Cin, q.Cout, q.K, q.dil)) return OV_E_UNSUPPORTED;
+  if (!(q.in_slope > 0.f && q.in_slope <= 1.f)) return OV_E_UNSUPPORTED;
+  if (q.out == q.x || q.out == q.res || q.out == q.add) return OV_E_BADARG;
+  auto mis = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) != 0; };
+  if (mis(q.x) || mis(q.w) || mis(q.out) || (q.res && mis(q.res)) || (q.add && mis(q.add)) || (q.L & 3) || (q.x_ld & 3) ||
+      (q.out_ld & 3) || (q.x_bstride & 3) || (q.out_bstride & 3) || (q.res && (q.res_bstride & 3)) ||
+      (q.add && (q.add_bstride & 3)))
+    return OV_E_ALIGN;
+  // 32-bit element offsets inside one utterance
+  if ((int64_t)q.Cin * q.x_ld >= (1LL << 31) || (int64_t)q.Cout * q.out_ld >= (1LL << 31)) return OV_E_BADARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (q.K) {
+    case 3: return wino_launch<3, wino_ci(3)>(&q, st);
+    case 7: return wino_launch<7, wino_ci(7)>(&q, st);
+    case 11: return wino_launch<11, wino_ci(11)>(&q, st);
+  }
+  return OV_E_UNSUPPORTED;
+}
+
+}  // extern "C"

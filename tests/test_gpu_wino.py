@@ -1,0 +1,87 @@
+"""Winograd-domain fp32 conv (csrc/conv1d_wino.h, ``ov_conv1d_wino_f32``) against a float64 conv of the same operands
+and against the direct fp32 MFMA kernel: every instance, ragged lengths around the 128-column tile, one and several
+M-blocks, residual / running-sum / scale operands, padded rows, forced workgroup counts (items that span utterances).
+Bar: max-abs error vs float64 <= 16x the direct kernel's (measured ~4x) and <= 2e-5 of the output scale.
+reference: openvoice/modules.py:296-309."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _setup(C, K, B, L, seed, cout=None):
+    from openvoice_amd import wino
+    from openvoice_amd.engine import PackedConv
+    cout = C if cout is None else cout
+    gen = torch.Generator().manual_seed(seed)
+    w = torch.randn(cout, C, K, generator=gen) * (C * K) ** -0.5
+    b = torch.randn(cout, generator=gen) * 0.1
+    x = torch.randn(B, C, L, generator=gen).to(DEV)
+    return w, b, x, PackedConv(w, b, DEV, K=K, dil=1), wino.PackedConvWino(w, b, DEV, dil=1), gen
+
+
+def _f64(x, w, b, K, slope):
+    xa = F.leaky_relu(x.double(), slope)
+    return F.conv1d(xa.cpu(), w.double(), b.double(), padding=(K - 1) // 2).to(x.device)
+
+
+@pytest.mark.parametrize("C,K", [(128, 11), (128, 7), (128, 3), (256, 11), (256, 3)])
+@pytest.mark.parametrize("B,L", [(2, 1000), (1, 128), (3, 132), (1, 4)])
+def test_wino_matches_float64_and_direct(C, K, B, L):
+    from openvoice_amd import wino
+    from openvoice_amd.engine import launch_conv
+    w, b, x, direct, wn, _ = _setup(C, K, B, L, seed=C + K + L)
+    out_d = torch.empty(B, C, L, device=DEV)
+    out_w = torch.full((B, C, L), float("nan"), device=DEV)
+    launch_conv(direct, x, 0, C * L, out_d, 0, C * L, B, L, in_slope=0.1)
+    wino.launch_conv_wino(wn, x, C * L, out_w, C * L, B, L, in_slope=0.1)
+    ref = _f64(x, w, b, K, 0.1)
+    e_d = (out_d.double() - ref).abs().max().item()
+    e_w = (out_w.double() - ref).abs().max().item()
+    assert e_w <= max(16 * e_d, 1e-6), (e_w, e_d)
+    assert e_w <= 2e-5 * max(ref.abs().max().item(), 1.0), (e_w, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("K", [3, 7, 11])
+def test_wino_residual_running_sum_scale_and_padded_rows(K):
+    """out = (conv + bias + res + add) * scale with x rows 8 floats longer than L and out rows 4 longer; pad columns of
+    out stay untouched."""
+    from openvoice_amd import wino
+    C, B, L, xld, old = 128, 2, 520, 528, 524
+    w, b, _, _, wn, gen = _setup(C, K, B, L, seed=K)
+    x = torch.randn(B, C, xld, generator=gen).to(DEV)
+    res = torch.randn(B, C, old, generator=gen).to(DEV)
+    add = torch.randn(B, C, old, generator=gen).to(DEV)
+    out = torch.full((B, C, old), 7.0, device=DEV)
+    wino.launch_conv_wino(wn, x, C * xld, out, C * old, B, L, in_slope=0.1, scale=1.0 / 3, res=res, res_bs=C * old, add=add,
+                          add_bs=C * old, x_ld=xld, out_ld=old)
+    ref = (_f64(x[:, :, :L], w, b, K, 0.1) + res[:, :, :L].double() + add[:, :, :L].double()) / 3
+    assert (out[:, :, :L].double() - ref).abs().max().item() <= 2e-5
+    assert (out[:, :, L:] == 7.0).all()
+
+
+@pytest.mark.parametrize("nwg", [1, 3, 8, 24])
+def test_wino_forced_workgroup_counts_are_bit_identical(nwg):
+    """Persistent workgroups walk items across utterances and M-blocks; the result does not depend on the split."""
+    from openvoice_amd import wino
+    C, K, B, L = 256, 7, 3, 640
+    w, b, x, _, wn, _ = _setup(C, K, B, L, seed=99)
+    ref = torch.empty(B, C, L, device=DEV)
+    wino.launch_conv_wino(wn, x, C * L, ref, C * L, B, L, in_slope=0.1)
+    out = torch.full((B, C, L), float("nan"), device=DEV)
+    wino.launch_conv_wino(wn, x, C * L, out, C * L, B, L, in_slope=0.1, nwg=nwg)
+    assert torch.equal(out, ref)
+
+
+def test_wino_refuses_what_it_cannot_run():
+    from openvoice_amd import _lib, wino
+    w, b, x, _, wn, _ = _setup(128, 11, 1, 256, seed=1)
+    out = torch.empty(1, 128, 256, device=DEV)
+    with pytest.raises(_lib.OvError):
+        wino.launch_conv_wino(wn, x, 128 * 256, x, 128 * 256, 1, 256)            # out aliases x
+    with pytest.raises(_lib.OvError):
+        wino.launch_conv_wino(wn, x, 128 * 254, out, 128 * 254, 1, 254)          # L % 4
+    assert not wino.supported(128, 128, 11, 3) and not wino.supported(64, 64, 11, 1)

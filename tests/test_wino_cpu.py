@@ -1,0 +1,129 @@
+"""Host side of the Winograd-domain fp32 conv (csrc/conv1d_wino.h): the F(4, 3) matrices satisfy the
+minimal-filtering identity, the weight packer's sub-record order is what the kernel's matrix waves index, and the
+kernel's whole index algebra -- raw LDS rows, the per-tile input window, V[k-row][tile][6], A / B fragment lanes, the
+accumulator layout and the 16-byte stores -- emulated lane by lane reproduces a float64 conv.  No GPU needed to get an
+offset wrong.  reference: openvoice/modules.py:296-309."""
+import numpy as np
+import pytest
+import torch
+
+from openvoice_amd import _lib, wino
+
+NT, RW = 32, 144
+
+
+def geo(K):
+    G = (K + 2) // 3
+    pad = (K - 1) // 2
+    off0 = 8 - pad
+    wstart = off0 // 4 * 4
+    wlen = off0 - wstart + 3 * (G - 1) + 6
+    return G, pad, off0, wstart, (wlen + 3) // 4
+
+
+def test_f43_matrices_are_a_minimal_filtering_algorithm():
+    bt, g, at = (np.array(m, dtype=np.float64) for m in (wino.BT, wino.G, wino.AT))
+    rng = np.random.default_rng(0)
+    for _ in range(10):
+        d, w = rng.standard_normal(6), rng.standard_normal(3)
+        y = at @ ((g @ w) * (bt @ d))
+        ref = np.array([sum(w[k] * d[i + k] for k in range(3)) for i in range(4)])
+        assert np.abs(y - ref).max() < 1e-13
+
+
+def pack(w):
+    lib = _lib.load()
+    cout, cin, k = w.shape
+    n = lib.ov_conv1d_wino_pack_size(cout, cin, k)
+    dst = torch.empty(n, dtype=torch.float32)
+    assert lib.ov_conv1d_wino_pack_f32(w.contiguous().data_ptr(), cout, cin, k, dst.data_ptr()) == 0
+    return dst.numpy()
+
+
+@pytest.mark.parametrize("cout,cin,k", [(128, 32, 3), (128, 16, 7), (256, 24, 11)])
+def test_weight_packer_sub_record_order(cout, cin, k):
+    lib = _lib.load()
+    ci = lib.ov_conv1d_wino_chunk(k)
+    G = (k + 2) // 3
+    w = torch.randn(cout, cin, k, generator=torch.Generator().manual_seed(2)) * (cin * k) ** -0.5
+    packed = pack(w)
+    npair = ci * G // 4
+    assert packed.size == ((cout // 32) * (cin // ci) * npair * 3 + 3) * 256
+    assert (packed[-768:] == 0).all()
+    wp = np.zeros((cout, cin, 3 * G))
+    wp[:, :, :k] = w.numpy()
+    u = np.einsum("pk,ocgk->ocgp", np.array(wino.G), wp.reshape(cout, cin, G, 3)).astype(np.float32)   # [co][ci][g][p]
+    rec = packed[:-768].reshape(cout // 32, cin // ci, npair, 3, 64, 4)
+    rng = np.random.default_rng(3)
+    for _ in range(2000):
+        mt, c, sp, lane, e = (rng.integers(cout // 32), rng.integers(cin // ci), rng.integers(npair), rng.integers(64),
+                              rng.integers(12))
+        kk = 2 * (2 * sp + e // 6) + (lane >> 5)
+        want = u[32 * mt + (lane & 31), c * ci + kk % ci, kk // ci, e % 6]
+        # (float64 sums of three products rounded once: equal up to the summation order of the float64 terms)
+        assert abs(float(rec[mt, c, sp, e // 4, lane, e % 4]) - float(want)) <= 2.0 ** -23 * abs(float(want))
+    assert lib.ov_conv1d_wino_pack_size(100, 128, 3) == 0 and lib.ov_conv1d_wino_pack_size(128, 128, 5) == 0
+    assert lib.ov_conv1d_wino_supported(128, 128, 11, 1) == 1 and lib.ov_conv1d_wino_supported(128, 128, 11, 2) == 0
+    assert lib.ov_conv1d_wino_supported(64, 64, 7, 1) == 0      # Cout in whole 128-row blocks
+
+
+@pytest.mark.parametrize("k,cin,L", [(11, 16, 260), (7, 8, 128), (3, 32, 132)])
+def test_kernel_index_algebra_reproduces_the_conv(k, cin, L):
+    """One M-block (128 rows), the helper / matrix wave arithmetic of conv1d_wino_kernel replayed with numpy indexing
+    exactly as the kernel forms its addresses (fp32 transforms, float64 accumulation so that only indices are on trial)."""
+    lib = _lib.load()
+    ci_chunk = lib.ov_conv1d_wino_chunk(k)
+    G, pad, off0, wstart, nb128 = geo(k)
+    cout, slope = 128, 0.1
+    gen = torch.Generator().manual_seed(5)
+    w = torch.randn(cout, cin, k, generator=gen) * (cin * k) ** -0.5
+    x = torch.randn(cin, L, generator=gen).numpy()
+    bias = torch.randn(cout, generator=gen).numpy()
+    packed = pack(w)
+    nchunks, kr = cin // ci_chunk, ci_chunk * G
+    npair = kr // 4
+    ntiles = (L + 127) // 128
+    out = np.zeros((cout, L))
+    bt, at = np.array(wino.BT, dtype=np.float32), np.array(wino.AT, dtype=np.float64)
+    for tile in range(ntiles):
+        t0 = tile * 128
+        y = np.zeros((4, 6, 32, 32))                      # [wave][p][row in fragment][tile n]
+        y[:, 1] = bias.reshape(4, 32)[:, :, None]
+        for c in range(nchunks):
+            raw = np.zeros((ci_chunk, RW), dtype=np.float32)
+            for idx in range(ci_chunk * RW // 4):         # staging vectors
+                row, c4 = divmod(idx, RW // 4)
+                t = t0 - 8 + 4 * c4
+                for e in range(4):
+                    if 0 <= t + e < L:
+                        v = x[c * ci_chunk + row, t + e]
+                        raw[row, 4 * c4 + e] = v if v > 0 else v * slope
+            V = np.zeros((kr, NT, 6), dtype=np.float32)
+            for idx in range(ci_chunk * NT):              # transform items
+                tl, cil = idx & 31, idx >> 5
+                win = raw[cil, wstart + 4 * tl: wstart + 4 * tl + 4 * nb128]
+                for g in range(G):
+                    o = off0 - wstart + 3 * g
+                    V[g * ci_chunk + cil, tl] = bt @ win[o:o + 6]
+            for wave in range(4):                          # matrix waves: sub-records -> A fragments, V -> B fragments
+                mt = wave
+                base = (mt * nchunks + c) * npair * 3
+                for s in range(kr // 2):
+                    sp, s2 = s >> 1, s & 1
+                    for q in range(6):
+                        e = s2 * 6 + q
+                        sub = packed[(base + sp * 3 + (e >> 2)) * 256:(base + sp * 3 + (e >> 2) + 1) * 256].reshape(64, 4)
+                        a = sub[:, e & 3]                  # lane -> A[row = lane & 31][k = lane >> 5]
+                        for half in range(2):
+                            b = V[2 * s + half, :, q]      # lane (half, n) -> B[k = half][n]
+                            y[wave, q] += np.outer(a[32 * half:32 * half + 32].astype(np.float64), b.astype(np.float64))
+        o = np.einsum("ip,wprn->wrni", at, y)              # [wave][row][tile n][i]
+        for wave in range(4):
+            for n in range(32):
+                col = t0 + 4 * n
+                if col < L:
+                    out[32 * wave:32 * wave + 32, col:col + 4] = o[wave, :, n, :]
+    xa = np.where(x > 0, x, slope * x)
+    xp = np.pad(xa, ((0, 0), (pad, pad)))
+    ref = bias[:, None] + sum(w.numpy()[:, :, j].astype(np.float64) @ xp[:, j:j + L] for j in range(k))
+    assert np.abs(out - ref).max() < 2e-5, np.abs(out - ref).max()
