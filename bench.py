@@ -596,18 +596,28 @@ def main():
     torch.cuda.synchronize()
     prof, engine.profile = engine.profile, None
     by_tag = {}
-    for tag, flops, e0, e1 in prof:
-        rec = by_tag.setdefault(tag, [0, 0.0, 0.0])
+    wino_n, wino_alg, wino_s = 0, 0.0, 0.0
+    for r in prof:
+        tag, flops, e0, e1 = r[:4]
+        rec = by_tag.setdefault(tag, [0, 0.0, 0.0, 0.0])
+        dt = e0.elapsed_time(e1) * 1e-3
         rec[0] += 1
         rec[1] += flops
-        rec[2] += e0.elapsed_time(e1) * 1e-3
+        rec[2] += dt
+        rec[3] += r[4] if len(r) > 4 else flops      # FLOPs the kernels EXECUTE (Winograd-domain launches: fewer)
+        if len(r) > 4:
+            wino_n, wino_alg, wino_s = wino_n + 1, wino_alg + flops, wino_s + dt
     if args.bf16_generator:
         from openvoice_amd.bf16 import generator_alg_bytes
-        n_mrf, f_mrf, t_mrf = by_tag["gen_bf16"][0], 0.0, by_tag["gen_bf16"][2]
+        n_mrf, f_mrf, t_mrf, x_mrf = by_tag["gen_bf16"][0], 0.0, by_tag["gen_bf16"][2], 0.0
         gen_bytes = generator_alg_bytes(cfg, B, frames)
     else:
-        n_mrf, f_mrf, t_mrf = by_tag["mrf"]
-    achieved = f_mrf / t_mrf / 1e12
+        n_mrf, f_mrf, t_mrf, x_mrf = by_tag["mrf"]
+    # priced on the FLOPs the matrix pipe executes: the Winograd-domain launches execute 6 ceil(K/3) / (4 K) of their
+    # algorithmic FLOPs, so the fraction of the fp32 MFMA peak stays a utilisation (<= 1); what the same time would
+    # mean for the direct form is `algorithmic_equivalent_tflops`
+    achieved = x_mrf / t_mrf / 1e12
+    alg_equiv = f_mrf / t_mrf / 1e12
     from openvoice_amd.engine import PAIR_POLICY
     fused_set = PAIR_POLICY if engine.fuse_pairs else ()
     traffic, traffic_note = pmc_traffic(B, frames, engine.fuse_pairs, PAIR_POLICY, n_mrf, engine.chain_streams)
@@ -659,8 +669,17 @@ def main():
                          "traffic_unit": "HBM bytes per MRF launch (rocprofv3 PMC, profiles/pmc_traffic_latest.json)",
                          "traffic_source": traffic_note,
                          "alg_bytes_per_launch": round(alg_bytes),
-                         "kernel": "ovk::conv1d_mfma_kernel (+ ovk::respair_mfma_kernel where a ResBlock pair is one "
-                                   "launch) on the MRF ResBlock convs",
+                         "achieved_is": "EXECUTED matrix FLOPs of the MRF launches / their HIP-event time",
+                         "algorithmic_equivalent_tflops": round(alg_equiv, 2),
+                         "executed_over_algorithmic_flops": round(x_mrf / f_mrf, 4) if f_mrf else None,
+                         "winograd": {"launches_per_step": wino_n,
+                                      "share_of_mrf_alg_flops": round(wino_alg / f_mrf, 4) if f_mrf else None,
+                                      "ms_per_step": round(wino_s * 1e3, 3),
+                                      "which": "ResBlock convs with C % 128 == 0 and dilation 1 (ov_conv1d_wino_f32: nested "
+                                               "F(4,3), fp32 MFMA); every other conv runs the direct implicit GEMM"}
+                         if wino_n else None,
+                         "kernel": "ovkw::conv1d_wino_kernel (Winograd-domain, where it has an instance) + ovk::conv1d_mfma_kernel "
+                                   "(+ ovk::respair_mfma_kernel where a ResBlock pair is one launch) on the MRF ResBlock convs",
                          "fused_pairs": sorted(f"C={c} k={k}" for c, k in fused_set),
                          "launches_per_step": n_mrf, "avg_launch_ms": round(t_mrf / n_mrf * 1e3, 4),
                          "alg_gflop_per_launch": round(f_mrf / n_mrf / 1e9, 2),
@@ -673,7 +692,7 @@ def main():
         if opt_in is not None:
             out["opt_in_split_bf16x3"] = opt_in
         if args.split_bf16x3:
-            n_s, f_s, t_s = by_tag["mrf_split"]
+            n_s, f_s, t_s = by_tag["mrf_split"][:3]
             pf = args.split_products * f_s / t_s / 1e15
             out["dtype"] = (f"f32 (enc_q, flow, C=32 stage) + bf16x3 split-precision MRF stages ({args.split_products} bf16 plane "
                             f"products per fp32 product, fp32 accumulation)")

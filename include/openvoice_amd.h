@@ -527,7 +527,8 @@ int ov_split3_to_f32(const uint16_t* a, const uint16_t* b, const uint16_t* c, in
  * output and (co, ci): 1.5 (K = 3), 4.5 (K = 7), 6 (K = 11) instead of K.  The transforms round where the direct conv
  * does not: against float64 the result carries ~4x the rounding error of ov_conv1d_f32 (tests/test_gpu_wino.py).
  * Tensors are fp32 [B][C][L], rows x_ld / out_ld floats apart (0 = L); L, x_ld, out_ld multiples of 4 and every
- * pointer 16-byte aligned; Cin % ov_conv1d_wino_chunk(K) == 0, Cout % 128 == 0; out must alias neither x, res nor add. */
+ * pointer 16-byte aligned; Cin % ov_conv1d_wino_chunk(K) == 0, Cout % 128 == 0; out must not alias x
+ * (it may be the very tensor passed as res or add -- the MRF running sum is accumulated in place). */
 typedef struct ov_conv1d_wino_params {
   const float* x;        /* [B][Cin][L] */
   const float* w;        /* ov_conv1d_wino_pack_f32(Cout, Cin, K) */
@@ -540,9 +541,12 @@ typedef struct ov_conv1d_wino_params {
   int32_t x_ld, out_ld;  /* row strides in floats; 0 = L */
   int32_t K, dil;
   int32_t nwg;           /* 0 = one workgroup per resident slot; n > 0 forces n workgroups (tests) */
-  int32_t reserved0;
+  int32_t frags;         /* 128-column fragments per matrix wave: 0 = chosen by the dispatcher, else 1 or 2 (tuning knob) */
   float in_slope;        /* leaky-ReLU slope applied to x while staging (1.0f = identity) */
   float scale;
+  unsigned long long* dbg; /* measurement only, NULL in production: [workgroups][8 waves][8] shader-clock ticks per phase
+                          * (matrix waves: k-step loops, chunk barriers, epilogue, item set-up; helper waves: staging
+                          * issue, transform, raw write, barriers); [7] = chunks */
 } ov_conv1d_wino_params;
 int ov_conv1d_wino_f32(const ov_conv1d_wino_params* p, ov_stream_t stream);
 /* 1 when (Cin, Cout, K, dil) has an instance, else 0 (callers then use ov_conv1d_f32). */

@@ -107,8 +107,8 @@ class ConvWinoParams(ctypes.Structure):
                 ("add_bstride", ctypes.c_int64),
                 ("B", ctypes.c_int32), ("Cin", ctypes.c_int32), ("Cout", ctypes.c_int32), ("L", ctypes.c_int32),
                 ("x_ld", ctypes.c_int32), ("out_ld", ctypes.c_int32), ("K", ctypes.c_int32), ("dil", ctypes.c_int32),
-                ("nwg", ctypes.c_int32), ("reserved0", ctypes.c_int32),
-                ("in_slope", ctypes.c_float), ("scale", ctypes.c_float)]
+                ("nwg", ctypes.c_int32), ("frags", ctypes.c_int32),
+                ("in_slope", ctypes.c_float), ("scale", ctypes.c_float), ("dbg", _fp)]
 
 
 class WnLayerParams(ctypes.Structure):

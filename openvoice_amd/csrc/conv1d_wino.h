@@ -34,11 +34,6 @@ using ovk::f32x16;
 using ovk::f32x2;
 using ovk::f32x4;
 
-constexpr int NT = 32;          // Winograd tiles per N-block = one MFMA N fragment
-constexpr int NCOL = 4 * NT;    // output columns per N-block
-constexpr int RW = 144;         // floats per raw LDS row: column t0 - 8 + c at index c
-constexpr int RW4 = RW / 4;
-constexpr int NHELP = 2;        // helper waves per workgroup
 constexpr int REC = 256;        // floats per 1 KiB weight sub-record
 constexpr int MAX_COUT = 512;   // rows of the bias vector kept in LDS
 
@@ -51,7 +46,7 @@ struct Geo {
   static constexpr int WSTART = OFF0 / 4 * 4;                   // aligned start of a tile's input window
   static constexpr int WLEN = OFF0 - WSTART + 3 * (G - 1) + 6;  // floats of the window all groups read
   static constexpr int NB128 = (WLEN + 3) / 4;
-  static_assert(PAD <= 8 && WSTART + 4 * (NT - 1) + 4 * NB128 <= RW, "input window exceeds the raw row");
+  static_assert(PAD <= 8 && WSTART + 4 * NB128 <= 20, "input window exceeds the raw row (128 NF + 16 floats)");
 };
 
 // Packed weights: sub-record ((mt * nchunks + c) * NPAIR + sp) * 3 + j, 64 lanes x 4 floats; lane l holds elements
@@ -62,10 +57,30 @@ __host__ __device__ inline size_t wino_pack_floats(int Cout, int Cin, int K, int
   return ((size_t)(Cout / 32) * (Cin / CI) * (CI * G / 4) * 3 + 3) * REC;
 }
 
-template <int K, int CI>
-__global__ __launch_bounds__(64 * (4 + NHELP), 3) void conv1d_wino_kernel(const ov_conv1d_wino_params p) {
+// phase timers (DBG instances only: the dispatcher selects them when ov_conv1d_wino_params.dbg is set)
+#ifndef OVW_EXP
+#define OVW_EXP 0   // measurement builds only (scripts/exp_wino.sh): 1 = MFMAs replaced by one FMA; 2 = helper transform skipped
+#endif
+#define OVW_MARK(q)                                                \
+  if constexpr (DBG) {                                             \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    tph[q] += now_ - tlast;                                        \
+    tlast = now_;                                                  \
+  }
+
+// NF = MFMA N fragments (of 32 tiles = 128 columns) per matrix wave.  NF = 1: 96 accumulator registers, 2 helper waves, two
+// workgroups per CU (they cover each other's barriers and epilogues).  NF = 2: 192 accumulator registers, 4 helper
+// waves, ONE workgroup per CU -- every A fragment feeds two MFMAs, which halves the weight stream from L2 (at NF = 1 the
+// 512 workgroups pull 12 TB/s of fragments, 3/4 of what the L2s deliver with nothing else running: profiles/r06_s4).
+template <int K, int CI, int NF, bool DBG>
+__global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_wino_kernel(const ov_conv1d_wino_params p) {
   using Ge = Geo<K>;
   constexpr int G = Ge::G, KR = CI * G, NSTEP = KR / 2, NPAIR = NSTEP / 2;
+  constexpr int NT = 32 * NF;          // Winograd tiles per N-block
+  constexpr int NCOL = 4 * NT;         // output columns per N-block
+  constexpr int RW = NCOL + 16;        // floats per raw LDS row: column t0 - 8 + c at index c
+  constexpr int RW4 = RW / 4;
+  constexpr int NHELP = 2 * NF;        // helper waves
   static_assert(KR % 4 == 0 && CI % 2 == 0, "k-rows in whole k-step pairs");
   constexpr int RAWBUF = CI * RW;        // floats per raw buffer
   constexpr int VBUF = KR * NT * 6;      // floats per V buffer
@@ -101,9 +116,13 @@ __global__ __launch_bounds__(64 * (4 + NHELP), 3) void conv1d_wino_kernel(const 
   const int nstream = nitems * nchunks;      // chunks this workgroup walks, across its items
   for (int i = tid; i < p.Cout; i += 64 * (4 + NHELP)) bias_s[i] = p.bias[i];   // visible after barrier (A)
 
-  const bool is_helper = (wave == 4) | (wave == 5);
+  const bool is_helper = wave >= 4;
   if (is_helper) {
     // ================================ helper waves ================================================
+    // Above the matrix waves in the issue arbiter: a helper's ~200 instructions per chunk are a few per cent of its
+    // SIMD's cycles, but at equal priority each of them queued behind a 64-cycle MFMA of the two matrix waves it shares
+    // the SIMD with (phase timers, profiles/r06_s3: the transform alone took 63 % of a chunk period).
+    __builtin_amdgcn_s_setprio(3);
     const float slope = p.in_slope;
     const uint32_t ldx = (uint32_t)p.x_ld;
     const int hl = (wave - 4) * 64 + lane;
@@ -162,7 +181,7 @@ __global__ __launch_bounds__(64 * (4 + NHELP), 3) void conv1d_wino_kernel(const 
 #pragma unroll
       for (int r = 0; r < ROUNDS; ++r) {
         const int idx = r * (64 * NHELP) + hl;
-        const int tile = idx & (NT - 1), cil = idx >> 5;
+        const int tile = idx & (NT - 1), cil = idx / NT;
         float win[4 * Ge::NB128];
 #pragma unroll
         for (int q = 0; q < Ge::NB128; ++q) {
@@ -191,6 +210,8 @@ __global__ __launch_bounds__(64 * (4 + NHELP), 3) void conv1d_wino_kernel(const 
       }
     };
 
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = DBG ? __builtin_readcyclecounter() : 0ull;
     issue_loads();
     write_raw(0);                 // chunk 0
     issue_loads();                // chunk 1 in registers
@@ -198,11 +219,24 @@ __global__ __launch_bounds__(64 * (4 + NHELP), 3) void conv1d_wino_kernel(const 
     transform(0);
     write_raw(1);
     __syncthreads();              // (B) V[0], raw[1] complete
+    OVW_MARK(4)
     for (int i = 0; i < nstream; ++i) {
       issue_loads();              // chunk i + 2 (nothing beyond the stream's end)
-      if (i + 1 < nstream) transform((i + 1) & 1);
+      OVW_MARK(0)
+      if (OVW_EXP != 2 && i + 1 < nstream) transform((i + 1) & 1);
+      OVW_MARK(1)
       write_raw(i & 1);
+      OVW_MARK(2)
       __syncthreads();            // V[(i + 1) & 1] and raw[i & 1] handed over; V[i & 1] free again
+      OVW_MARK(3)
+    }
+    if constexpr (DBG) {
+      if (lane == 0) {
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+        tph[7] = (unsigned long long)nstream;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d[q] = tph[q];
+      }
     }
     return;
   }
@@ -219,29 +253,41 @@ __global__ __launch_bounds__(64 * (4 + NHELP), 3) void conv1d_wino_kernel(const 
   f32x4 a_cur[3], a_nxt[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) a_cur[j] = wbase[(size_t)(rec + j) * 64 + lane];
-  const int voffB = (half * NT + n) * 6;       // this lane's float offset inside a k-step's two k-rows
+  const int voffB = (half * NT + n) * 6;       // this lane's float offset inside a k-step's two k-rows (fragment 0)
 
   __syncthreads();   // (A)
   __syncthreads();   // (B)
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = DBG ? __builtin_readcyclecounter() : 0ull;
   int it = 0;
   while (true) {
-    f32x16 acc[6];
+    f32x16 acc[6][NF];
 #pragma unroll
     for (int q = 0; q < 6; ++q)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][f][r] = 0.f;
     // At column of point 1 is (1, 1, 1, 1): a bias there reaches all four outputs of a tile
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_s + mtile * 32 + 4 * half + 8 * i);
-      acc[1][4 * i] = bq[0]; acc[1][4 * i + 1] = bq[1]; acc[1][4 * i + 2] = bq[2]; acc[1][4 * i + 3] = bq[3];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        acc[1][f][4 * i] = bq[0]; acc[1][f][4 * i + 1] = bq[1]; acc[1][f][4 * i + 2] = bq[2]; acc[1][f][4 * i + 3] = bq[3];
+      }
     }
 
+    OVW_MARK(3)
     for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
       const float* vb = Vs + (it & 1) * VBUF + voffB;
-      f32x2 bcur[3], bnxt[3];
+      // B operands: ONE register set, refilled in place -- the two points of pair qq are read for k-step s + 1 right after
+      // the MFMAs of k-step s that consumed them have issued (4 NF MFMAs = 256 NF cycles later they are needed again)
+      f32x2 bq[NF][3];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) bcur[q] = *reinterpret_cast<const f32x2*>(vb + 2 * q);
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq) bq[f][qq] = *reinterpret_cast<const f32x2*>(vb + f * (32 * 6) + 2 * qq);
 #pragma unroll
       for (int s = 0; s < NSTEP; ++s) {
         const int s2 = s & 1;
@@ -250,27 +296,36 @@ __global__ __launch_bounds__(64 * (4 + NHELP), 3) void conv1d_wino_kernel(const 
 #pragma unroll
           for (int j = 0; j < 3; ++j) a_nxt[j] = wbase[(size_t)(rec + j) * 64 + lane];
         }
-        if (s + 1 < NSTEP) {
 #pragma unroll
-          for (int q = 0; q < 3; ++q) bnxt[q] = *reinterpret_cast<const f32x2*>(vb + (s + 1) * (2 * NT * 6) + 2 * q);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int qq = 0; qq < 3; ++qq) {
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          const int e = s2 * 6 + q;
-          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[e >> 2][e & 3], bcur[q >> 1][q & 1], acc[q], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < NSTEP) {
+          for (int t = 0; t < 2; ++t) {
+            const int q = 2 * qq + t, e = s2 * 6 + q;
 #pragma unroll
-          for (int q = 0; q < 3; ++q) bcur[q] = bnxt[q];
+            for (int f = 0; f < NF; ++f) {
+#if OVW_EXP == 1   // measurement build: no MFMAs (what do the helpers cost when the matrix pipe is idle?)
+              acc[q][f][0] += a_cur[e >> 2][e & 3] * bq[f][qq][t];
+#else
+              acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[e >> 2][e & 3], bq[f][qq][t], acc[q][f], 0, 0, 0);
+#endif
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (s + 1 < NSTEP) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+              bq[f][qq] = *reinterpret_cast<const f32x2*>(vb + (s + 1) * (2 * NT * 6) + f * (32 * 6) + 2 * qq);
+          }
         }
         if (s2 == 1) {
 #pragma unroll
           for (int j = 0; j < 3; ++j) a_cur[j] = a_nxt[j];
         }
       }
+      OVW_MARK(0)
       __syncthreads();
+      OVW_MARK(1)
     }
 
     // next work item: its first weight pair and bias are in flight while this item's epilogue runs
@@ -289,47 +344,69 @@ __global__ __launch_bounds__(64 * (4 + NHELP), 3) void conv1d_wino_kernel(const 
 
     // ---- epilogue: out = (At Y + res + add) * scale, 16 bytes per lane and row --------------------------------
     {
-      const uint32_t col = (uint32_t)otile * NCOL + 4u * (uint32_t)n;
-      const bool colok = col < (uint32_t)L;                 // L % 4 == 0: a lane's 4 columns are in or out together
-      const uint32_t ccol = colok ? col : 0u;
       const float scale = p.scale;
       float* outb = p.out + (int64_t)ob * p.out_bstride;
       const float* resb = p.res ? p.res + (int64_t)ob * p.res_bstride : nullptr;
       const float* addb = p.add ? p.add + (int64_t)ob * p.add_bstride : nullptr;
       const uint32_t rbase = (uint32_t)omtile * 32u + 4u * (uint32_t)half;
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {                       // 4 rows at a time: bounds the operand temporaries
-        f32x4 rv[4], av[4];
+      for (int f = 0; f < NF; ++f) {
+        const uint32_t col = (uint32_t)otile * NCOL + 128u * f + 4u * (uint32_t)n;
+        const bool colok = col < (uint32_t)L;               // L % 4 == 0: a lane's 4 columns are in or out together
+        const uint32_t ccol = colok ? col : 0u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t off = (rbase + (uint32_t)(j + 8 * rg)) * LD + ccol;
-          rv[j] = resb ? *reinterpret_cast<const f32x4*>(resb + off) : f32x4{0.f, 0.f, 0.f, 0.f};
-          av[j] = addb ? *reinterpret_cast<const f32x4*>(addb + off) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int rg = 0; rg < 4; ++rg) {                     // 4 rows at a time: bounds the operand temporaries
+          f32x4 rv[4], av[4];
+          if (resb) {                                        // (one uniform branch per group: the loads go out together)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = 4 * rg + j;
-          const float y0 = acc[0][r], y1 = acc[1][r], y2 = acc[2][r], y3 = acc[3][r], y4 = acc[4][r], y5 = acc[5][r];
-          const float s1 = y1 + y2, d1 = y1 - y2, s2 = y3 + y4, d2 = y3 - y4;
-          f32x4 o;
-          o[0] = (y0 + s1) + s2;
-          o[1] = __builtin_fmaf(2.f, d2, d1);
-          o[2] = __builtin_fmaf(4.f, s2, s1);
-          o[3] = __builtin_fmaf(8.f, d2, d1) + y5;
-          o = ((o + rv[j]) + av[j]) * scale;
-          if (colok) *reinterpret_cast<f32x4*>(outb + (rbase + (uint32_t)(j + 8 * rg)) * LD + col) = o;
+            for (int j = 0; j < 4; ++j) rv[j] = *reinterpret_cast<const f32x4*>(resb + (rbase + (uint32_t)(j + 8 * rg)) * LD + ccol);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          if (addb) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) av[j] = *reinterpret_cast<const f32x4*>(addb + (rbase + (uint32_t)(j + 8 * rg)) * LD + ccol);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) av[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * rg + j;
+            const float y0 = acc[0][f][r], y1 = acc[1][f][r], y2 = acc[2][f][r], y3 = acc[3][f][r], y4 = acc[4][f][r],
+                        y5 = acc[5][f][r];
+            const float s1 = y1 + y2, d1 = y1 - y2, s2 = y3 + y4, d2 = y3 - y4;
+            f32x4 o;
+            o[0] = (y0 + s1) + s2;
+            o[1] = __builtin_fmaf(2.f, d2, d1);
+            o[2] = __builtin_fmaf(4.f, s2, s1);
+            o[3] = __builtin_fmaf(8.f, d2, d1) + y5;
+            o = ((o + rv[j]) + av[j]) * scale;
+            if (colok) *reinterpret_cast<f32x4*>(outb + (rbase + (uint32_t)(j + 8 * rg)) * LD + col) = o;
+          }
         }
       }
     }
+    OVW_MARK(2)
     if (!more) break;
+  }
+  if constexpr (DBG) {
+    if (lane == 0) {
+      unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+      tph[7] = (unsigned long long)it;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) d[q] = tph[q];
+    }
   }
 }
 
-template <int K, int CI>
+template <int K, int CI, int NF, bool DBG>
 int wino_launch(const ov_conv1d_wino_params* p, hipStream_t stream) {
+  constexpr int NCOL = 128 * NF, NHELP = 2 * NF;
   const int ntiles = (p->L + NCOL - 1) / NCOL;
   const long total = (long)ntiles * (p->Cout / 128) * p->B;
-  auto kernel = conv1d_wino_kernel<K, CI>;
+  auto kernel = conv1d_wino_kernel<K, CI, NF, DBG>;
   static std::atomic<int> slot_cache[ovk::OV_MAX_DEVICES];
   const int slots = ovk::resident_workgroups(reinterpret_cast<const void*>(kernel), 64 * (4 + NHELP), slot_cache);
   long nwg = p->nwg > 0 ? p->nwg : slots;

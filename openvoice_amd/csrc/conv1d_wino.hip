@@ -66,7 +66,7 @@ int ov_conv1d_wino_f32(const ov_conv1d_wino_params* pin, ov_stream_t stream) {
   if (q.x_ld < q.L || q.out_ld < q.L) return OV_E_BADARG;
   if (!ov_conv1d_wino_supported(q.Cin, q.Cout, q.K, q.dil)) return OV_E_UNSUPPORTED;
   if (!(q.in_slope > 0.f && q.in_slope <= 1.f)) return OV_E_UNSUPPORTED;
-  if (q.out == q.x || q.out == q.res || q.out == q.add) return OV_E_BADARG;
+  if (q.out == q.x) return OV_E_BADARG;   // (out may BE res or add: a lane reads exactly the 16 bytes it then writes)
   auto mis = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) != 0; };
   if (mis(q.x) || mis(q.w) || mis(q.out) || (q.res && mis(q.res)) || (q.add && mis(q.add)) || (q.L & 3) || (q.x_ld & 3) ||
       (q.out_ld & 3) || (q.x_bstride & 3) || (q.out_bstride & 3) || (q.res && (q.res_bstride & 3)) ||
@@ -75,11 +75,18 @@ int ov_conv1d_wino_f32(const ov_conv1d_wino_params* pin, ov_stream_t stream) {
   // 32-bit element offsets inside one utterance
   if ((int64_t)q.Cin * q.x_ld >= (1LL << 31) || (int64_t)q.Cout * q.out_ld >= (1LL << 31)) return OV_E_BADARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (q.frags < 0 || q.frags > 2) return OV_E_BADARG;
+  const int nf = q.frags ? q.frags : 2;
+#define OVW_CASE(KK)                                                                                                  \
+  case KK:                                                                                                            \
+    if (nf == 1) return q.dbg ? wino_launch<KK, wino_ci(KK), 1, true>(&q, st) : wino_launch<KK, wino_ci(KK), 1, false>(&q, st); \
+    return q.dbg ? wino_launch<KK, wino_ci(KK), 2, true>(&q, st) : wino_launch<KK, wino_ci(KK), 2, false>(&q, st);
   switch (q.K) {
-    case 3: return wino_launch<3, wino_ci(3)>(&q, st);
-    case 7: return wino_launch<7, wino_ci(7)>(&q, st);
-    case 11: return wino_launch<11, wino_ci(11)>(&q, st);
+    OVW_CASE(3)
+    OVW_CASE(7)
+    OVW_CASE(11)
   }
+#undef OVW_CASE
   return OV_E_UNSUPPORTED;
 }
 

@@ -452,6 +452,26 @@ class ConverterEngine:
                     pairs.append((c1, c2))
                 stage.append(pairs)
             self.resblocks.append(stage)
+        # Winograd-domain twins (csrc/conv1d_wino.h) of the ResBlock convs of the MFMA-bound stages: the same fp32 conv
+        # with 1.6-2x fewer executed multiplies; per stage / ResBlock / pair (w1 | None, w2 | None)
+        self.wino_resblocks = []
+        from . import wino as _wino
+        ch = cfg["upsample_initial_channel"]
+        for i in range(len(cfg["upsample_rates"])):
+            ch //= 2
+            stage = []
+            for j, (rk, rd) in enumerate(zip(kernels, dils)):
+                rb = f"dec.resblocks.{i * len(kernels) + j}"
+                pairs = []
+                for n, d in enumerate(rd):
+                    w1 = w2 = None
+                    if _wino.supported(ch, ch, rk, d):
+                        w1 = _wino.PackedConvWino(effective_weight(sd, f"{rb}.convs1.{n}"), sd[f"{rb}.convs1.{n}.bias"], dev, dil=d)
+                    if _wino.supported(ch, ch, rk, 1):
+                        w2 = _wino.PackedConvWino(effective_weight(sd, f"{rb}.convs2.{n}"), sd[f"{rb}.convs2.{n}.bias"], dev, dil=1)
+                    pairs.append((w1, w2))
+                stage.append(pairs)
+            self.wino_resblocks.append(stage)
         self.final_channels = ch
         self.post_w = sd["dec.conv_post.weight"][0].contiguous().to(dev)   # [C, 7]
         self.total_upsample = 1
@@ -490,6 +510,9 @@ class ConverterEngine:
         self.fuse_wn = True      # WaveNet layers as one launch each (ov_wn_layer_f32) where the shape has an instance
         self.wn_row_split = 0    # 0: the launcher splits a layer's rows over two launches for one or two utterances; 1: never
         self.fuse_pairs = True   # ResBlock pairs of the HBM-bound stages as one launch each (PAIR_POLICY)
+        # ResBlock convs of the MFMA-bound stages (C a multiple of 128) in the Winograd domain (ov_conv1d_wino_f32):
+        # fp32 arithmetic, 6 G / (4 K) of the direct form's multiplies, ~4x its rounding error
+        self.use_winograd = True
         # opt-in fast generator: bf16 activations, fp32 accumulation (waveform within
         # ~1e-2 of the fp32 path instead of ~1e-5).  Built lazily by use_bf16_generator().
         self._state_dict_for_bf16 = sd
@@ -516,6 +539,22 @@ class ConverterEngine:
         if alg_flops is None:
             alg_flops = 2.0 * layer.rows * (kwargs.get("cin") or layer.cin) * layer.K * L * B
         self.profile.append((tag, alg_flops, e0, e1))
+
+    def _wino(self, layer, x, out, bs, B, L, res=None, add=None, scale=1.0):
+        """One Winograd-domain ResBlock conv (leaky ReLU on the input, LINEAR epilogue); profiled under the MRF tag with its
+        algorithmic FLOPs and, as a fifth field, the FLOPs the kernel EXECUTES (6 ceil(K/3) / (4 K) of them)."""
+        from . import wino
+        kw = dict(in_slope=LRELU_SLOPE, scale=scale, res=res, res_bs=bs if res is not None else 0, add=add,
+                  add_bs=bs if add is not None else 0)
+        if self.profile is None:
+            wino.launch_conv_wino(layer, x, bs, out, bs, B, L, **kw)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        wino.launch_conv_wino(layer, x, bs, out, bs, B, L, **kw)
+        e1.record()
+        alg = 2.0 * layer.cout * layer.cin * layer.K * L * B
+        self.profile.append(("mrf", alg, e0, e1, alg * 6 * ((layer.K + 2) // 3) / (4.0 * layer.K)))
 
     def _pair(self, c1, c2, x, out, bs, B, L, add, scale, **lim):
         """One fused ResBlock1 iteration; profiled under the same tag as the two launches it replaces, with their
@@ -919,6 +958,9 @@ class ConverterEngine:
                 cur = u
                 fused = self.fuse_pairs and L % 4 == 0 and all(
                     (ch, c1.K) in PAIR_POLICY and pair_supported(ch, c1.K, c1.dil) for c1, _ in pairs)
+                # Winograd-domain convs where an instance exists (C a multiple of 128); the length-aware work lists
+                # (skip_padding) stay on the direct kernels
+                wn = self.wino_resblocks[i][j] if (self.use_winograd and limits is None and L % 4 == 0) else None
                 for n, (c1, c2) in enumerate(pairs):
                     last = n == len(pairs) - 1
                     if last and concurrent and j > 0:
@@ -930,10 +972,17 @@ class ConverterEngine:
                         dst = acc if last else (t1_ if cur is ra_ else ra_)
                         self._pair(c1, c2, cur, dst, bs, B, L, add, scale, **lim(rate))
                     else:
-                        self._conv(c1, cur, 0, bs, t1_, 0, bs, B, L, in_slope=LRELU_SLOPE, tag="mrf", **lim(rate))
+                        w1, w2 = wn[n] if wn is not None else (None, None)
+                        if w1 is not None:
+                            self._wino(w1, cur, t1_, bs, B, L)
+                        else:
+                            self._conv(c1, cur, 0, bs, t1_, 0, bs, B, L, in_slope=LRELU_SLOPE, tag="mrf", **lim(rate))
                         dst = acc if last else ra_
-                        self._conv(c2, t1_, 0, bs, dst, 0, bs, B, L, in_slope=LRELU_SLOPE, res=cur, res_bs=bs,
-                                   add=add, add_bs=bs, scale=scale, tag="mrf", **lim(rate))
+                        if w2 is not None:
+                            self._wino(w2, t1_, dst, bs, B, L, res=cur, add=add, scale=scale)
+                        else:
+                            self._conv(c2, t1_, 0, bs, dst, 0, bs, B, L, in_slope=LRELU_SLOPE, res=cur, res_bs=bs,
+                                       add=add, add_bs=bs, scale=scale, tag="mrf", **lim(rate))
                     cur = dst
 
             if not concurrent:

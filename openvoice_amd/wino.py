@@ -41,11 +41,11 @@ class PackedConvWino:
 
 
 def launch_conv_wino(layer, x, x_bs, out, out_bs, B, L, in_slope=1.0, scale=1.0, res=None, res_bs=0, add=None, add_bs=0,
-                     x_ld=0, out_ld=0, nwg=0):
+                     x_ld=0, out_ld=0, nwg=0, dbg=None, frags=0):
     """One launch on torch's current stream of ``x``'s device; strides in elements (``*_ld`` 0 = dense rows)."""
     if _lib.use_torch_binding():
-        _lib.torch_op("conv1d_wino_f32", x, layer.w, layer.bias, out, res, add,
-                      [B, layer.cin, layer.cout, L, x_ld, out_ld, layer.K, layer.dil, nwg, x_bs, out_bs, res_bs, add_bs],
+        _lib.torch_op("conv1d_wino_f32", x, layer.w, layer.bias, out, res, add, dbg,
+                      [B, layer.cin, layer.cout, L, x_ld, out_ld, layer.K, layer.dil, nwg, x_bs, out_bs, res_bs, add_bs, frags],
                       [in_slope, scale])
         return
     p = _lib.ConvWinoParams()
@@ -53,7 +53,8 @@ def launch_conv_wino(layer, x, x_bs, out, out_bs, B, L, in_slope=1.0, scale=1.0,
     p.x, p.w, p.bias, p.out, p.res, p.add = vp(x), vp(layer.w), vp(layer.bias), vp(out), vp(res), vp(add)
     p.x_bstride, p.out_bstride, p.res_bstride, p.add_bstride = x_bs, out_bs, res_bs, add_bs
     p.B, p.Cin, p.Cout, p.L, p.x_ld, p.out_ld = B, layer.cin, layer.cout, L, x_ld, out_ld
-    p.K, p.dil, p.nwg = layer.K, layer.dil, nwg
+    p.K, p.dil, p.nwg, p.frags = layer.K, layer.dil, nwg, frags
     p.in_slope, p.scale = in_slope, scale
+    p.dbg = vp(dbg)
     stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(_lib.load().ov_conv1d_wino_f32(ctypes.byref(p), stream), "ov_conv1d_wino_f32")

@@ -28,16 +28,17 @@ def _f64(x, w, b, K, slope):
     return F.conv1d(xa.cpu(), w.double(), b.double(), padding=(K - 1) // 2).to(x.device)
 
 
+@pytest.mark.parametrize("frags", [1, 2])
 @pytest.mark.parametrize("C,K", [(128, 11), (128, 7), (128, 3), (256, 11), (256, 3)])
-@pytest.mark.parametrize("B,L", [(2, 1000), (1, 128), (3, 132), (1, 4)])
-def test_wino_matches_float64_and_direct(C, K, B, L):
+@pytest.mark.parametrize("B,L", [(2, 1000), (1, 128), (3, 132), (1, 4), (2, 260)])
+def test_wino_matches_float64_and_direct(C, K, B, L, frags):
     from openvoice_amd import wino
     from openvoice_amd.engine import launch_conv
     w, b, x, direct, wn, _ = _setup(C, K, B, L, seed=C + K + L)
     out_d = torch.empty(B, C, L, device=DEV)
     out_w = torch.full((B, C, L), float("nan"), device=DEV)
     launch_conv(direct, x, 0, C * L, out_d, 0, C * L, B, L, in_slope=0.1)
-    wino.launch_conv_wino(wn, x, C * L, out_w, C * L, B, L, in_slope=0.1)
+    wino.launch_conv_wino(wn, x, C * L, out_w, C * L, B, L, in_slope=0.1, frags=frags)
     ref = _f64(x, w, b, K, 0.1)
     e_d = (out_d.double() - ref).abs().max().item()
     e_w = (out_w.double() - ref).abs().max().item()
@@ -45,8 +46,9 @@ def test_wino_matches_float64_and_direct(C, K, B, L):
     assert e_w <= 2e-5 * max(ref.abs().max().item(), 1.0), (e_w, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("frags", [1, 2])
 @pytest.mark.parametrize("K", [3, 7, 11])
-def test_wino_residual_running_sum_scale_and_padded_rows(K):
+def test_wino_residual_running_sum_scale_and_padded_rows(K, frags):
     """out = (conv + bias + res + add) * scale with x rows 8 floats longer than L and out rows 4 longer; pad columns of
     out stay untouched."""
     from openvoice_amd import wino
@@ -57,22 +59,23 @@ def test_wino_residual_running_sum_scale_and_padded_rows(K):
     add = torch.randn(B, C, old, generator=gen).to(DEV)
     out = torch.full((B, C, old), 7.0, device=DEV)
     wino.launch_conv_wino(wn, x, C * xld, out, C * old, B, L, in_slope=0.1, scale=1.0 / 3, res=res, res_bs=C * old, add=add,
-                          add_bs=C * old, x_ld=xld, out_ld=old)
+                          add_bs=C * old, x_ld=xld, out_ld=old, frags=frags)
     ref = (_f64(x[:, :, :L], w, b, K, 0.1) + res[:, :, :L].double() + add[:, :, :L].double()) / 3
     assert (out[:, :, :L].double() - ref).abs().max().item() <= 2e-5
     assert (out[:, :, L:] == 7.0).all()
 
 
+@pytest.mark.parametrize("frags", [1, 2])
 @pytest.mark.parametrize("nwg", [1, 3, 8, 24])
-def test_wino_forced_workgroup_counts_are_bit_identical(nwg):
+def test_wino_forced_workgroup_counts_are_bit_identical(nwg, frags):
     """Persistent workgroups walk items across utterances and M-blocks; the result does not depend on the split."""
     from openvoice_amd import wino
     C, K, B, L = 256, 7, 3, 640
     w, b, x, _, wn, _ = _setup(C, K, B, L, seed=99)
     ref = torch.empty(B, C, L, device=DEV)
-    wino.launch_conv_wino(wn, x, C * L, ref, C * L, B, L, in_slope=0.1)
+    wino.launch_conv_wino(wn, x, C * L, ref, C * L, B, L, in_slope=0.1, frags=frags)
     out = torch.full((B, C, L), float("nan"), device=DEV)
-    wino.launch_conv_wino(wn, x, C * L, out, C * L, B, L, in_slope=0.1, nwg=nwg)
+    wino.launch_conv_wino(wn, x, C * L, out, C * L, B, L, in_slope=0.1, nwg=nwg, frags=frags)
     assert torch.equal(out, ref)
 
 

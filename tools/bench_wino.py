@@ -30,7 +30,7 @@ DEV = "cuda:0"
 MACS_PER_4 = {3: 6, 7: 18, 11: 24}      # executed multiply-accumulates per 4 outputs and (co, ci)
 
 
-def one_shape(sd, C, K, d, B, L, reps, err_items=2, with_res=False):
+def one_shape(sd, C, K, d, B, L, reps, err_items=2, with_res=False, frags=0):
     rb = {256: 0, 128: 3, 64: 6, 32: 9}[C] + {3: 0, 7: 1, 11: 2}[K]
     n = {1: 0, 3: 1, 5: 2}[d]
     gen = torch.Generator().manual_seed(C + K + d)
@@ -45,7 +45,7 @@ def one_shape(sd, C, K, d, B, L, reps, err_items=2, with_res=False):
     for name in ("calibrated", "stress_gain4"):
         x = x0 if name == "calibrated" else 4.0 * x0 * torch.exp2(2.0 * torch.randn(B, C, 1, generator=gen).to(DEV))
         run_d = lambda: launch_conv(direct, x, 0, C * L, out_d, 0, C * L, B, L, in_slope=LRELU_SLOPE)
-        run_w = lambda: wino.launch_conv_wino(wn, x, C * L, out_w, C * L, B, L, in_slope=LRELU_SLOPE)
+        run_w = lambda: wino.launch_conv_wino(wn, x, C * L, out_w, C * L, B, L, in_slope=LRELU_SLOPE, frags=frags)
         out_w.fill_(float("nan"))
         run_d()
         run_w()
@@ -70,7 +70,7 @@ def one_shape(sd, C, K, d, B, L, reps, err_items=2, with_res=False):
                 run_dr = lambda: launch_conv(direct, x, 0, C * L, out_d, 0, C * L, B, L, in_slope=LRELU_SLOPE, res=res,
                                              res_bs=C * L)
                 run_wr = lambda: wino.launch_conv_wino(wn, x, C * L, out_w, C * L, B, L, in_slope=LRELU_SLOPE, res=res,
-                                                       res_bs=C * L)
+                                                       res_bs=C * L, frags=frags)
                 run_dr(); run_wr()
                 rec["res_form_max_abs_wino_vs_direct"] = (out_w - out_d).abs().max().item()
                 td, tw = [], []
@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--shapes", action="store_true", help="every (C, K, dilation) with an instance, not only the gate shape")
     ap.add_argument("--res", action="store_true", help="also time the residual form")
+    ap.add_argument("--frags", type=int, default=0, help="128-column fragments per matrix wave (0 = dispatcher)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     sd = synthetic_state_dict(CONVERTER_MODEL_CONFIG, 513, seed=1234)
@@ -99,7 +100,7 @@ def main():
     rows = []
     for C, K, d in shapes:
         L = args.frames * {256: 8, 128: 64, 64: 128}[C]
-        row = one_shape(sd, C, K, d, args.batch, L, args.reps, with_res=args.res)
+        row = one_shape(sd, C, K, d, args.batch, L, args.reps, with_res=args.res, frags=args.frags)
         rows.append(row)
         c, s = row["calibrated"], row["stress_gain4"]
         print(f"C={C} K={K} d={d}: direct {c['ms_direct']:.3f} ms ({c['tflops_direct']:.1f} TF/s)  wino {c['ms_wino']:.3f} ms "
