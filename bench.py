@@ -675,7 +675,7 @@ def main():
                          "winograd": {"launches_per_step": wino_n,
                                       "share_of_mrf_alg_flops": round(wino_alg / f_mrf, 4) if f_mrf else None,
                                       "ms_per_step": round(wino_s * 1e3, 3),
-                                      "which": "ResBlock convs with C % 128 == 0 and dilation 1 (ov_conv1d_wino_f32: nested "
+                                      "which": "ResBlock convs with C % 128 == 0, dilations 1 / 3 / 5 (ov_conv1d_wino_f32: nested "
                                                "F(4,3), fp32 MFMA); every other conv runs the direct implicit GEMM"}
                          if wino_n else None,
                          "kernel": "ovkw::conv1d_wino_kernel (Winograd-domain, where it has an instance) + ovk::conv1d_mfma_kernel "

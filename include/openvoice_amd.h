@@ -547,6 +547,11 @@ typedef struct ov_conv1d_wino_params {
   unsigned long long* dbg; /* measurement only, NULL in production: [workgroups][8 waves][8] shader-clock ticks per phase
                           * (matrix waves: k-step loops, chunk barriers, epilogue, item set-up; helper waves: staging
                           * issue, transform, raw write, barriers); [7] = chunks */
+  const int32_t* col_limit; /* DEVICE int32 [B] or NULL: length-aware work list exactly as ov_conv1d_params.col_limit --
+                          * column blocks that start at or beyond col_limit[b] * col_limit_scale are neither computed
+                          * nor written, what is computed is bit-identical to the full launch; B <= 256, else ignored */
+  int32_t col_limit_scale;
+  int32_t reserved0;
 } ov_conv1d_wino_params;
 int ov_conv1d_wino_f32(const ov_conv1d_wino_params* p, ov_stream_t stream);
 /* 1 when (Cin, Cout, K, dil) has an instance, else 0 (callers then use ov_conv1d_f32). */

@@ -108,7 +108,8 @@ class ConvWinoParams(ctypes.Structure):
                 ("B", ctypes.c_int32), ("Cin", ctypes.c_int32), ("Cout", ctypes.c_int32), ("L", ctypes.c_int32),
                 ("x_ld", ctypes.c_int32), ("out_ld", ctypes.c_int32), ("K", ctypes.c_int32), ("dil", ctypes.c_int32),
                 ("nwg", ctypes.c_int32), ("frags", ctypes.c_int32),
-                ("in_slope", ctypes.c_float), ("scale", ctypes.c_float), ("dbg", _fp)]
+                ("in_slope", ctypes.c_float), ("scale", ctypes.c_float), ("dbg", _fp),
+                ("col_limit", _fp), ("col_limit_scale", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
 
 
 class WnLayerParams(ctypes.Structure):

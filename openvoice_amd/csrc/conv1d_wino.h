@@ -37,6 +37,24 @@ using ovk::f32x4;
 constexpr int REC = 256;        // floats per 1 KiB weight sub-record
 constexpr int MAX_COUT = 512;   // rows of the bias vector kept in LDS
 
+// Dilation DIL > 1 (the first conv of each ResBlock pair, reference openvoice/modules.py:228-251): an output at column
+// t reads x[t + (tap - PAD) DIL], so the columns of one residue class r = t mod DIL form a dilation-1 problem of their own.
+// A Winograd tile is then 4 outputs DIL apart, r + DIL (4j + i), and an N-block of 32 NF tiles holds ALL DIL classes of a
+// contiguous column range: tile n = r * J + j with J = (32 NF) / DIL tiles per class, 4 J DIL columns per block (the
+// 32 NF - DIL J left-over tiles compute a duplicate of tile 0 and are not stored: 1.6 % at DIL = 3, 6.3 % at DIL = 5).
+template <int K, int DIL, int NF>
+struct GeoD {
+  static constexpr int G = (K + 2) / 3;
+  static constexpr int NT = 32 * NF;
+  static constexpr int J = NT / DIL;                             // tiles per residue class
+  static constexpr int NCOL = 4 * J * DIL;                       // output columns per N-block
+  static constexpr int PADD = (K - 1) / 2 * DIL;                 // 'same' padding in columns
+  static constexpr int PADA = (PADD + 3) / 4 * 4;                // raw rows start at column t0 - PADA (16-byte aligned)
+  static constexpr int NV = 3 * (G - 1) + 6;                     // inputs a tile reads, DIL apart
+  static constexpr int RW = (PADA - PADD + DIL - 1 + DIL * (4 * (J - 1) + NV - 1) + 1 + 3) / 4 * 4;   // floats per raw row
+  static_assert(DIL == 3 || DIL == 5, "dilated instances: 3 and 5");
+};
+
 // Geometry of a K-tap conv: group g holds taps 3g .. 3g + 2 (taps >= K are zero).
 template <int K>
 struct Geo {
@@ -72,21 +90,28 @@ __host__ __device__ inline size_t wino_pack_floats(int Cout, int Cin, int K, int
 // workgroups per CU (they cover each other's barriers and epilogues).  NF = 2: 192 accumulator registers, 4 helper
 // waves, ONE workgroup per CU -- every A fragment feeds two MFMAs, which halves the weight stream from L2 (at NF = 1 the
 // 512 workgroups pull 12 TB/s of fragments, 3/4 of what the L2s deliver with nothing else running: profiles/r06_s4).
-template <int K, int CI, int NF, bool DBG>
+template <int K, int DIL, int CI, int NF, bool DBG>
 __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_wino_kernel(const ov_conv1d_wino_params p) {
   using Ge = Geo<K>;
+  using Gd = GeoD<K, DIL == 1 ? 3 : DIL, NF>;   // (only read when DIL > 1)
   constexpr int G = Ge::G, KR = CI * G, NSTEP = KR / 2, NPAIR = NSTEP / 2;
   constexpr int NT = 32 * NF;          // Winograd tiles per N-block
-  constexpr int NCOL = 4 * NT;         // output columns per N-block
-  constexpr int RW = NCOL + 16;        // floats per raw LDS row: column t0 - 8 + c at index c
+  constexpr int NCOL = DIL == 1 ? 4 * NT : Gd::NCOL;     // output columns per N-block
+  constexpr int RW = DIL == 1 ? NCOL + 16 : Gd::RW;      // floats per raw LDS row: column t0 - ORG + c at index c
+  constexpr int ORG = DIL == 1 ? 8 : Gd::PADA;
   constexpr int RW4 = RW / 4;
   constexpr int NHELP = 2 * NF;        // helper waves
+  static_assert(DIL == 1 || NF == 2, "dilated instances run two fragments per wave");
   static_assert(KR % 4 == 0 && CI % 2 == 0, "k-rows in whole k-step pairs");
   constexpr int RAWBUF = CI * RW;        // floats per raw buffer
   constexpr int VBUF = KR * NT * 6;      // floats per V buffer
   __shared__ __attribute__((aligned(16))) float raw[2 * RAWBUF];
   __shared__ __attribute__((aligned(16))) float Vs[2 * VBUF];
   __shared__ __attribute__((aligned(16))) float bias_s[MAX_COUT];   // read back 16 bytes at a time at every item start
+  // DIL > 1: a lane's four outputs are DIL columns apart; they leave through an 8-row x 256-column tile per matrix wave
+  // (written 4 bytes at a time, read back as whole rows) so that the global stores are 16 bytes per lane as at DIL = 1
+  constexpr int OST = 256;
+  __shared__ __attribute__((aligned(16))) float ostage[DIL == 1 ? 4 : 4 * 8 * OST];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -95,12 +120,52 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
   const int nchunks = p.Cin / CI;
   const int ntiles = (L + NCOL - 1) / NCOL;
   const int mblocks = p.Cout / 128;
-  const int total = ntiles * mblocks * p.B;
+  int total = ntiles * mblocks * p.B;
+  // Length-aware work list (ov_conv1d_wino_params.col_limit, as ov_conv1d_params.col_limit): utterance b contributes only
+  // the N-blocks that start before its column limit; lim_pref[b] = blocks of the utterances before b, so the list stays
+  // dense and is dealt evenly whatever the lengths are.  One wave computes the prefix sums once per workgroup.
+  __shared__ int lim_pref[ovk::LIMIT_MAX_BATCH + 1];
+  const bool limited = p.col_limit != nullptr;
+  if (limited) {
+    if (wave == 0) {
+      int carry = 0;
+      for (int base = 0; base < p.B; base += 64) {
+        const int bb = base + lane;
+        int nb = 0;
+        if (bb < p.B) {
+          long long c = (long long)p.col_limit[bb] * p.col_limit_scale;
+          c = c < 0 ? 0 : (c > L ? L : c);
+          nb = ((int)c + NCOL - 1) / NCOL;
+        }
+        int sc = nb;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int v = __shfl_up(sc, d, 64);
+          if (lane >= d) sc += v;
+        }
+        if (bb < p.B) lim_pref[bb + 1] = carry + sc;
+        carry += __shfl(sc, 63, 64);
+      }
+      if (lane == 0) lim_pref[0] = 0;
+    }
+    __syncthreads();
+    total = __builtin_amdgcn_readfirstlane(lim_pref[p.B]) * mblocks;
+  }
   auto decode = [&](int w, int& ub, int& utile, int& umblk) {
     const int g = w / mblocks;
     umblk = w - g * mblocks;
-    ub = g / ntiles;
-    utile = g - ub * ntiles;
+    if (!limited) {
+      ub = g / ntiles;
+      utile = g - ub * ntiles;
+      return;
+    }
+    int lo = 0, hi = p.B;                      // lim_pref[lo] <= g < lim_pref[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (__builtin_amdgcn_readfirstlane(lim_pref[mid]) <= g) lo = mid; else hi = mid;
+    }
+    ub = lo;
+    utile = g - __builtin_amdgcn_readfirstlane(lim_pref[lo]);
   };
   // XCD-contiguous order (see conv1d_mfma.h): XCD x = blockIdx.x % 8 owns a contiguous eighth of the list
   int wid0 = blockIdx.x, wend = total, wstride = gridDim.x;
@@ -143,7 +208,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
         const int idx = i * (64 * NHELP) + hl;
         const int row = idx / RW4, c4 = idx - row * RW4;
         const int ci = lchunk * CI + row;
-        const int t = t0 - 8 + 4 * c4;                       // multiple of 4: a vector is wholly inside or outside
+        const int t = t0 - ORG + 4 * c4;                     // multiple of 4: a vector is wholly inside or outside
         const bool ok = live && idx < NITEM && t >= 0 && t < L;
         const uint32_t goff = ok ? (uint32_t)ci * ldx + (uint32_t)t : 0u;
         nval[i] = ok ? min(L - t, 4) : 0;
@@ -182,15 +247,24 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
       for (int r = 0; r < ROUNDS; ++r) {
         const int idx = r * (64 * NHELP) + hl;
         const int tile = idx & (NT - 1), cil = idx / NT;
-        float win[4 * Ge::NB128];
+        constexpr int NWIN = DIL == 1 ? 4 * Ge::NB128 : Gd::NV;
+        float win[NWIN];
+        if constexpr (DIL == 1) {
 #pragma unroll
-        for (int q = 0; q < Ge::NB128; ++q) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(src + cil * RW + Ge::WSTART + 4 * tile + 4 * q);
-          win[4 * q] = v[0]; win[4 * q + 1] = v[1]; win[4 * q + 2] = v[2]; win[4 * q + 3] = v[3];
+          for (int q = 0; q < Ge::NB128; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + cil * RW + Ge::WSTART + 4 * tile + 4 * q);
+            win[4 * q] = v[0]; win[4 * q + 1] = v[1]; win[4 * q + 2] = v[2]; win[4 * q + 3] = v[3];
+          }
+        } else {
+          // tile -> (residue class, tile of the class); the left-over tiles duplicate tile 0 (never stored)
+          const int rc0 = tile / Gd::J, rc = rc0 < DIL ? rc0 : 0, jt = rc0 < DIL ? tile - rc0 * Gd::J : 0;
+          const float* s0 = src + cil * RW + (Gd::PADA - Gd::PADD) + rc + 4 * DIL * jt;
+#pragma unroll
+          for (int u = 0; u < Gd::NV; ++u) win[u] = s0[DIL * u];
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-          const int o = Ge::OFF0 - Ge::WSTART + 3 * g;
+          const int o = (DIL == 1 ? Ge::OFF0 - Ge::WSTART : 0) + 3 * g;
           const float d0 = win[o], d1 = win[o + 1], d2 = win[o + 2], d3 = win[o + 3], d4 = win[o + 4], d5 = win[o + 5];
           // Bt d, points 0, 1, -1, 2, -2, infinity
           const float t1 = __builtin_fmaf(-4.f, d2, d4), t2 = __builtin_fmaf(-4.f, d1, d3);
@@ -349,6 +423,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
       const float* resb = p.res ? p.res + (int64_t)ob * p.res_bstride : nullptr;
       const float* addb = p.add ? p.add + (int64_t)ob * p.add_bstride : nullptr;
       const uint32_t rbase = (uint32_t)omtile * 32u + 4u * (uint32_t)half;
+      if constexpr (DIL == 1) {
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         const uint32_t col = (uint32_t)otile * NCOL + 128u * f + 4u * (uint32_t)n;
@@ -387,6 +462,67 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
           }
         }
       }
+          } else {
+        float* ost = ostage + wave * (8 * OST);
+        const uint32_t c0 = (uint32_t)otile * NCOL;            // first column of the N-block (multiple of 4)
+        // this lane's tiles: fragment f, tile 32 f + n -> columns rcl + DIL (4 jt + i) of the block, or none
+        int cbase[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const int tl = 32 * f + n, rc0 = tl / Gd::J;
+          cbase[f] = rc0 < DIL ? rc0 + 4 * DIL * (tl - rc0 * Gd::J) : -1;
+        }
+        const uint32_t col = c0 + 4u * (uint32_t)lane;         // the 16 bytes this lane stores of each row
+        const bool colok = 4 * lane < NCOL && col < (uint32_t)L;
+        const uint32_t ccol = colok ? col : 0u;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * rg + j;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+              const float y0 = acc[0][f][r], y1 = acc[1][f][r], y2 = acc[2][f][r], y3 = acc[3][f][r], y4 = acc[4][f][r],
+                          y5 = acc[5][f][r];
+              const float s1 = y1 + y2, d1 = y1 - y2, s2 = y3 + y4, d2 = y3 - y4;
+              if (cbase[f] >= 0) {
+                float* o = ost + (4 * half + j) * OST + cbase[f];
+                o[0] = (y0 + s1) + s2;
+                o[DIL] = __builtin_fmaf(2.f, d2, d1);
+                o[2 * DIL] = __builtin_fmaf(4.f, s2, s1);
+                o[3 * DIL] = __builtin_fmaf(8.f, d2, d1) + y5;
+              }
+            }
+          }
+          // (same wave wrote and now reads: LDS operations of a wave complete in order)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {                     // rows 4 hh + j of the stage = output rows 4 hh + 8 rg + j
+            f32x4 rv[4], av[4], ov[4];
+            const uint32_t r0 = (uint32_t)omtile * 32u + 4u * hh + 8u * rg;
+            if (resb) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) rv[j] = *reinterpret_cast<const f32x4*>(resb + (r0 + j) * LD + ccol);
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) rv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (addb) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) av[j] = *reinterpret_cast<const f32x4*>(addb + (r0 + j) * LD + ccol);
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) av[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ov[j] = *reinterpret_cast<const f32x4*>(ost + (4 * hh + j) * OST + 4 * (lane & 63));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const f32x4 o = ((ov[j] + rv[j]) + av[j]) * scale;
+              if (colok) *reinterpret_cast<f32x4*>(outb + (r0 + j) * LD + col) = o;
+            }
+          }
+        }
+      }
     }
     OVW_MARK(2)
     if (!more) break;
@@ -401,12 +537,12 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
   }
 }
 
-template <int K, int CI, int NF, bool DBG>
+template <int K, int DIL, int CI, int NF, bool DBG>
 int wino_launch(const ov_conv1d_wino_params* p, hipStream_t stream) {
-  constexpr int NCOL = 128 * NF, NHELP = 2 * NF;
+  constexpr int NCOL = DIL == 1 ? 128 * NF : GeoD<K, DIL == 1 ? 3 : DIL, NF>::NCOL, NHELP = 2 * NF;
   const int ntiles = (p->L + NCOL - 1) / NCOL;
-  const long total = (long)ntiles * (p->Cout / 128) * p->B;
-  auto kernel = conv1d_wino_kernel<K, CI, NF, DBG>;
+  const long total = (long)ntiles * (p->Cout / 128) * p->B;   // (an upper bound under a column limit: idle workgroups exit)
+  auto kernel = conv1d_wino_kernel<K, DIL, CI, NF, DBG>;
   static std::atomic<int> slot_cache[ovk::OV_MAX_DEVICES];
   const int slots = ovk::resident_workgroups(reinterpret_cast<const void*>(kernel), 64 * (4 + NHELP), slot_cache);
   long nwg = p->nwg > 0 ? p->nwg : slots;
@@ -415,5 +551,23 @@ int wino_launch(const ov_conv1d_wino_params* p, hipStream_t stream) {
   hipLaunchKernelGGL(kernel, dim3((unsigned)nwg), dim3(64 * (4 + NHELP)), 0, stream, *p);
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
 }
+
+constexpr int wino_ci(int K) { return K == 3 ? 16 : (K == 7 || K == 11) ? 8 : 0; }
+
+// One translation unit per kernel size (conv1d_wino_k3 / k7 / k11.hip) so that the instances compile in parallel.
+int wino_dispatch_k3(const ov_conv1d_wino_params* p, int nf, hipStream_t stream);
+int wino_dispatch_k7(const ov_conv1d_wino_params* p, int nf, hipStream_t stream);
+int wino_dispatch_k11(const ov_conv1d_wino_params* p, int nf, hipStream_t stream);
+
+#define OVW_DEFINE_DISPATCH(KK)                                                                                          \
+  int ovkw::wino_dispatch_k##KK(const ov_conv1d_wino_params* p, int nf, hipStream_t st) {                                \
+    constexpr int CI = ovkw::wino_ci(KK);                                                                                \
+    const bool dbg = p->dbg != nullptr;                                                                                  \
+    if (p->dil == 1 && nf == 1) return dbg ? wino_launch<KK, 1, CI, 1, true>(p, st) : wino_launch<KK, 1, CI, 1, false>(p, st); \
+    if (p->dil == 1) return dbg ? wino_launch<KK, 1, CI, 2, true>(p, st) : wino_launch<KK, 1, CI, 2, false>(p, st);        \
+    if (p->dil == 3) return dbg ? wino_launch<KK, 3, CI, 2, true>(p, st) : wino_launch<KK, 3, CI, 2, false>(p, st);        \
+    if (p->dil == 5) return dbg ? wino_launch<KK, 5, CI, 2, true>(p, st) : wino_launch<KK, 5, CI, 2, false>(p, st);        \
+    return OV_E_UNSUPPORTED;                                                                                             \
+  }
 
 }  // namespace ovkw

@@ -11,8 +11,6 @@ namespace {
 const double kG[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                          {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
 
-constexpr int wino_ci(int K) { return K == 3 ? 16 : (K == 7 || K == 11) ? 8 : 0; }
-
 }  // namespace
 
 extern "C" {
@@ -21,7 +19,7 @@ int ov_conv1d_wino_chunk(int K) { return wino_ci(K); }
 
 int ov_conv1d_wino_supported(int Cin, int Cout, int K, int dil) {
   const int ci = wino_ci(K);
-  if (ci == 0 || dil != 1) return 0;
+  if (ci == 0 || (dil != 1 && dil != 3 && dil != 5)) return 0;
   return (Cin > 0 && Cin % ci == 0 && Cout > 0 && Cout % 128 == 0) ? 1 : 0;
 }
 
@@ -61,6 +59,8 @@ int ov_conv1d_wino_f32(const ov_conv1d_wino_params* pin, ov_stream_t stream) {
   ov_conv1d_wino_params q = *pin;
   if (!q.x || !q.w || !q.bias || !q.out) return OV_E_BADARG;
   if (q.B <= 0 || q.L <= 0 || q.nwg < 0) return OV_E_BADARG;
+  if (q.col_limit && (q.col_limit_scale <= 0 || (reinterpret_cast<uintptr_t>(q.col_limit) & 3))) return OV_E_BADARG;
+  if (q.col_limit && q.B > ovk::LIMIT_MAX_BATCH) q.col_limit = nullptr;   // documented: whole tensors
   if (q.x_ld == 0) q.x_ld = q.L;
   if (q.out_ld == 0) q.out_ld = q.L;
   if (q.x_ld < q.L || q.out_ld < q.L) return OV_E_BADARG;
@@ -77,16 +77,12 @@ int ov_conv1d_wino_f32(const ov_conv1d_wino_params* pin, ov_stream_t stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (q.frags < 0 || q.frags > 2) return OV_E_BADARG;
   const int nf = q.frags ? q.frags : 2;
-#define OVW_CASE(KK)                                                                                                  \
-  case KK:                                                                                                            \
-    if (nf == 1) return q.dbg ? wino_launch<KK, wino_ci(KK), 1, true>(&q, st) : wino_launch<KK, wino_ci(KK), 1, false>(&q, st); \
-    return q.dbg ? wino_launch<KK, wino_ci(KK), 2, true>(&q, st) : wino_launch<KK, wino_ci(KK), 2, false>(&q, st);
+  if (q.dil != 1 && nf != 2) return OV_E_UNSUPPORTED;       // the dilated instances run two fragments per wave
   switch (q.K) {
-    OVW_CASE(3)
-    OVW_CASE(7)
-    OVW_CASE(11)
+    case 3: return wino_dispatch_k3(&q, nf, st);
+    case 7: return wino_dispatch_k7(&q, nf, st);
+    case 11: return wino_dispatch_k11(&q, nf, st);
   }
-#undef OVW_CASE
   return OV_E_UNSUPPORTED;
 }
 

@@ -352,15 +352,18 @@ void conv1d_split3(const OptTensor& x, const OptTensor& w, const OptTensor& bias
   finish(ov_conv1d_split3(&p, c.stream()), "ov_conv1d_split3");
 }
 
-// ip = [B, Cin, Cout, L, x_ld, out_ld, K, dil, nwg, x_bstride, out_bstride, res_bstride, add_bstride, frags]; fp = [in_slope, scale]
+// ip = [B, Cin, Cout, L, x_ld, out_ld, K, dil, nwg, x_bstride, out_bstride, res_bstride, add_bstride, frags,
+//       col_limit_scale]; fp = [in_slope, scale]
 void conv1d_wino_f32(const OptTensor& x, const OptTensor& w, const OptTensor& bias, const OptTensor& out, const OptTensor& res,
-                     const OptTensor& add, const OptTensor& dbg, at::IntArrayRef ip, at::ArrayRef<double> fp) {
-  TORCH_CHECK(ip.size() == 14 && fp.size() == 2, "openvoice_amd::conv1d_wino_f32: 14 integer and 2 float parameters");
+                     const OptTensor& add, const OptTensor& dbg, const OptTensor& col_limit, at::IntArrayRef ip,
+                     at::ArrayRef<double> fp) {
+  TORCH_CHECK(ip.size() == 15 && fp.size() == 2, "openvoice_amd::conv1d_wino_f32: 15 integer and 2 float parameters");
   Ctx c{"conv1d_wino_f32", false};
   ov_conv1d_wino_params p{};
   p.x = sptr<float>(x, c, 0); p.w = sptr<float>(w, c, 1); p.bias = sptr<float>(bias, c, 2);
   p.out = sptr<float>(out, c, 3); p.res = sptr<float>(res, c, 4); p.add = sptr<float>(add, c, 5);
   p.dbg = sptr<unsigned long long>(dbg, c, 6);
+  p.col_limit = sptr<int32_t>(col_limit, c, 7); p.col_limit_scale = (int32_t)ip[14];
   p.B = (int32_t)ip[0]; p.Cin = (int32_t)ip[1]; p.Cout = (int32_t)ip[2]; p.L = (int32_t)ip[3];
   p.x_ld = (int32_t)ip[4]; p.out_ld = (int32_t)ip[5]; p.K = (int32_t)ip[6]; p.dil = (int32_t)ip[7]; p.nwg = (int32_t)ip[8];
   p.x_bstride = ip[9]; p.out_bstride = ip[10]; p.res_bstride = ip[11]; p.add_bstride = ip[12]; p.frags = (int32_t)ip[13];
@@ -388,7 +391,7 @@ TORCH_LIBRARY(openvoice_amd, m) {
   m.def("conv1d_split3(Tensor? x, Tensor? w, Tensor? bias, Tensor(a!)? out, Tensor? res, Tensor(b!)? dbg, "
         "Tensor? col_limit, int[] ip, float[] fp) -> ()", &conv1d_split3);
   m.def("conv1d_wino_f32(Tensor? x, Tensor? w, Tensor? bias, Tensor(a!)? out, Tensor? res, Tensor? add, Tensor(b!)? dbg, "
-        "int[] ip, float[] fp) -> ()",
+        "Tensor? col_limit, int[] ip, float[] fp) -> ()",
         &conv1d_wino_f32);
   // ---- device entry points with flat argument lists (schema derived from the C prototype)
   bind_device<&ov_frame_hops_f32>(m, "frame_hops_f32");

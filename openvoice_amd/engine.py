@@ -540,12 +540,12 @@ class ConverterEngine:
             alg_flops = 2.0 * layer.rows * (kwargs.get("cin") or layer.cin) * layer.K * L * B
         self.profile.append((tag, alg_flops, e0, e1))
 
-    def _wino(self, layer, x, out, bs, B, L, res=None, add=None, scale=1.0):
+    def _wino(self, layer, x, out, bs, B, L, res=None, add=None, scale=1.0, **lim):
         """One Winograd-domain ResBlock conv (leaky ReLU on the input, LINEAR epilogue); profiled under the MRF tag with its
         algorithmic FLOPs and, as a fifth field, the FLOPs the kernel EXECUTES (6 ceil(K/3) / (4 K) of them)."""
         from . import wino
         kw = dict(in_slope=LRELU_SLOPE, scale=scale, res=res, res_bs=bs if res is not None else 0, add=add,
-                  add_bs=bs if add is not None else 0)
+                  add_bs=bs if add is not None else 0, **lim)
         if self.profile is None:
             wino.launch_conv_wino(layer, x, bs, out, bs, B, L, **kw)
             return
@@ -958,9 +958,9 @@ class ConverterEngine:
                 cur = u
                 fused = self.fuse_pairs and L % 4 == 0 and all(
                     (ch, c1.K) in PAIR_POLICY and pair_supported(ch, c1.K, c1.dil) for c1, _ in pairs)
-                # Winograd-domain convs where an instance exists (C a multiple of 128); the length-aware work lists
-                # (skip_padding) stay on the direct kernels
-                wn = self.wino_resblocks[i][j] if (self.use_winograd and limits is None and L % 4 == 0) else None
+                # Winograd-domain convs where an instance exists (C a multiple of 128); they carry the same
+                # length-aware work lists (skip_padding) as the direct kernels
+                wn = self.wino_resblocks[i][j] if (self.use_winograd and L % 4 == 0) else None
                 for n, (c1, c2) in enumerate(pairs):
                     last = n == len(pairs) - 1
                     if last and concurrent and j > 0:
@@ -974,12 +974,12 @@ class ConverterEngine:
                     else:
                         w1, w2 = wn[n] if wn is not None else (None, None)
                         if w1 is not None:
-                            self._wino(w1, cur, t1_, bs, B, L)
+                            self._wino(w1, cur, t1_, bs, B, L, **lim(rate))
                         else:
                             self._conv(c1, cur, 0, bs, t1_, 0, bs, B, L, in_slope=LRELU_SLOPE, tag="mrf", **lim(rate))
                         dst = acc if last else ra_
                         if w2 is not None:
-                            self._wino(w2, t1_, dst, bs, B, L, res=cur, add=add, scale=scale)
+                            self._wino(w2, t1_, dst, bs, B, L, res=cur, add=add, scale=scale, **lim(rate))
                         else:
                             self._conv(c2, t1_, 0, bs, dst, 0, bs, B, L, in_slope=LRELU_SLOPE, res=cur, res_bs=bs,
                                        add=add, add_bs=bs, scale=scale, tag="mrf", **lim(rate))

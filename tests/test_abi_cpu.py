@@ -319,4 +319,27 @@ def test_conv_split3_params_struct_matches_header_field_order():
     assert ctypes.sizeof(_lib.ConvSplit3Params) == 128     # 5 pointers, 3 int64, 8 int32, 3 float, 1 int32, 2 pointers
     lib = _lib.load()
     assert lib.ov_conv1d_split3(None, None) == -1
-    assert lib.ov_version() >= _lib.MIN_VERSION == 206
+    assert lib.ov_version() >= _lib.MIN_VERSION >= 206
+
+
+def test_conv_wino_params_struct_matches_header_field_order():
+    """ABI 2.07: ``ov_conv1d_wino_params`` field for field against the ctypes mirror, and the entry point's argument checks
+    that need no GPU."""
+    header = open(os.path.join(REPO, "include", "openvoice_amd.h")).read()
+    body = header[header.index("typedef struct ov_conv1d_wino_params {"):header.index("} ov_conv1d_wino_params;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        first, *rest = decl.split(",")
+        names.append(re.findall(r"(\w+)$", first.strip())[0])
+        names += [r.strip() for r in rest]
+    assert names == [f[0] for f in _lib.ConvWinoParams._fields_]
+    import ctypes
+    assert ctypes.sizeof(_lib.ConvWinoParams) == 6 * 8 + 4 * 8 + 10 * 4 + 2 * 4 + 8 + 8 + 2 * 4
+    lib = _lib.load()
+    assert lib.ov_conv1d_wino_f32(None, None) == -1
+    assert lib.ov_version() >= 207
+    assert [lib.ov_conv1d_wino_chunk(k) for k in (3, 5, 7, 11)] == [16, 0, 8, 8]

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _setup(C, K, B, L, seed, cout=None):
+def _setup(C, K, B, L, seed, cout=None, dil=1):
     from openvoice_amd import wino
     from openvoice_amd.engine import PackedConv
     cout = C if cout is None else cout
@@ -20,12 +20,12 @@ def _setup(C, K, B, L, seed, cout=None):
     w = torch.randn(cout, C, K, generator=gen) * (C * K) ** -0.5
     b = torch.randn(cout, generator=gen) * 0.1
     x = torch.randn(B, C, L, generator=gen).to(DEV)
-    return w, b, x, PackedConv(w, b, DEV, K=K, dil=1), wino.PackedConvWino(w, b, DEV, dil=1), gen
+    return w, b, x, PackedConv(w, b, DEV, K=K, dil=dil), wino.PackedConvWino(w, b, DEV, dil=dil), gen
 
 
-def _f64(x, w, b, K, slope):
+def _f64(x, w, b, K, slope, dil=1):
     xa = F.leaky_relu(x.double(), slope)
-    return F.conv1d(xa.cpu(), w.double(), b.double(), padding=(K - 1) // 2).to(x.device)
+    return F.conv1d(xa.cpu(), w.double(), b.double(), padding=(K - 1) // 2 * dil, dilation=dil).to(x.device)
 
 
 @pytest.mark.parametrize("frags", [1, 2])
@@ -44,6 +44,41 @@ def test_wino_matches_float64_and_direct(C, K, B, L, frags):
     e_w = (out_w.double() - ref).abs().max().item()
     assert e_w <= max(16 * e_d, 1e-6), (e_w, e_d)
     assert e_w <= 2e-5 * max(ref.abs().max().item(), 1.0), (e_w, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dil", [3, 5])
+@pytest.mark.parametrize("C,K", [(128, 11), (128, 7), (128, 3), (256, 11), (256, 7)])
+@pytest.mark.parametrize("B,L", [(2, 1000), (1, 252), (3, 244), (1, 4), (2, 512)])
+def test_dilated_wino_matches_float64_and_direct(C, K, B, L, dil):
+    from openvoice_amd import wino
+    from openvoice_amd.engine import launch_conv
+    w, b, x, direct, wn, gen = _setup(C, K, B, L, seed=C + K + L + dil, dil=dil)
+    res = torch.randn(B, C, L, generator=gen).to(DEV)
+    out_d = torch.empty(B, C, L, device=DEV)
+    out_w = torch.full((B, C, L), float("nan"), device=DEV)
+    launch_conv(direct, x, 0, C * L, out_d, 0, C * L, B, L, in_slope=0.1, res=res, res_bs=C * L, scale=0.5)
+    wino.launch_conv_wino(wn, x, C * L, out_w, C * L, B, L, in_slope=0.1, res=res, res_bs=C * L, scale=0.5)
+    ref = (_f64(x, w, b, K, 0.1, dil) + res.double()) * 0.5
+    e_d = (out_d.double() - ref).abs().max().item()
+    e_w = (out_w.double() - ref).abs().max().item()
+    assert e_w <= max(16 * e_d, 1e-6), (e_w, e_d)
+    assert e_w <= 2e-5 * max(ref.abs().max().item(), 1.0), (e_w, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dil", [3, 5])
+def test_dilated_wino_forced_workgroup_counts_and_in_place_running_sum(dil):
+    from openvoice_amd import wino
+    C, K, B, L = 256, 7, 3, 700
+    w, b, x, _, wn, gen = _setup(C, K, B, L, seed=5 + dil, dil=dil)
+    acc0 = torch.randn(B, C, L, generator=gen).to(DEV)
+    ref = acc0.clone()
+    wino.launch_conv_wino(wn, x, C * L, ref, C * L, B, L, in_slope=0.1, add=ref, add_bs=C * L, scale=1.0 / 3)
+    want = (_f64(x, w, b, K, 0.1, dil) + acc0.double()) / 3
+    assert (ref.double() - want).abs().max().item() <= 2e-5
+    for nwg in (1, 5, 16):
+        out = acc0.clone()
+        wino.launch_conv_wino(wn, x, C * L, out, C * L, B, L, in_slope=0.1, add=out, add_bs=C * L, scale=1.0 / 3, nwg=nwg)
+        assert torch.equal(out, ref)
 
 
 @pytest.mark.parametrize("frags", [1, 2])
@@ -87,4 +122,25 @@ def test_wino_refuses_what_it_cannot_run():
         wino.launch_conv_wino(wn, x, 128 * 256, x, 128 * 256, 1, 256)            # out aliases x
     with pytest.raises(_lib.OvError):
         wino.launch_conv_wino(wn, x, 128 * 254, out, 128 * 254, 1, 254)          # L % 4
-    assert not wino.supported(128, 128, 11, 3) and not wino.supported(64, 64, 11, 1)
+    assert wino.supported(128, 128, 11, 3) and not wino.supported(128, 128, 11, 2) and not wino.supported(64, 64, 11, 1)
+
+
+@pytest.mark.parametrize("K,dil", [(11, 1), (7, 3), (3, 5)])
+def test_wino_length_aware_work_list(K, dil):
+    """col_limit: blocks at or beyond an utterance's limit are neither computed nor written (NaN poison stays), what is
+    computed is bit-identical to the full launch; limits 0, 1, mid-block, a block boundary, beyond L."""
+    from openvoice_amd import wino
+    C, B, L = 128, 6, 1200
+    w, b, x, _, wn, _ = _setup(C, K, B, L, seed=31 + K, dil=dil)
+    ncol = 256 if dil == 1 else 4 * (64 // dil) * dil
+    full = torch.empty(B, C, L, device=DEV)
+    wino.launch_conv_wino(wn, x, C * L, full, C * L, B, L, in_slope=0.1)
+    limits = torch.tensor([0, 1, ncol + 5, 2 * ncol, L + 50, 300], dtype=torch.int32, device=DEV)
+    for scale, lim in ((1, limits), (2, (limits + 1) // 2)):
+        out = torch.full((B, C, L), float("nan"), device=DEV)
+        wino.launch_conv_wino(wn, x, C * L, out, C * L, B, L, in_slope=0.1, col_limit=lim, col_limit_scale=scale)
+        for bi in range(B):
+            cols = min(L, int(lim[bi].item()) * scale)
+            done = min(L, (cols + ncol - 1) // ncol * ncol)
+            assert torch.equal(out[bi, :, :done], full[bi, :, :done]), (bi, cols)
+            assert torch.isnan(out[bi, :, done:]).all(), (bi, cols)

@@ -64,6 +64,7 @@ def test_weight_packer_sub_record_order(cout, cin, k):
         assert abs(float(rec[mt, c, sp, e // 4, lane, e % 4]) - float(want)) <= 2.0 ** -23 * abs(float(want))
     assert lib.ov_conv1d_wino_pack_size(100, 128, 3) == 0 and lib.ov_conv1d_wino_pack_size(128, 128, 5) == 0
     assert lib.ov_conv1d_wino_supported(128, 128, 11, 1) == 1 and lib.ov_conv1d_wino_supported(128, 128, 11, 2) == 0
+    assert lib.ov_conv1d_wino_supported(128, 128, 11, 5) == 1 and lib.ov_conv1d_wino_supported(256, 256, 3, 3) == 1
     assert lib.ov_conv1d_wino_supported(64, 64, 7, 1) == 0      # Cout in whole 128-row blocks
 
 
@@ -126,4 +127,84 @@ def test_kernel_index_algebra_reproduces_the_conv(k, cin, L):
     xa = np.where(x > 0, x, slope * x)
     xp = np.pad(xa, ((0, 0), (pad, pad)))
     ref = bias[:, None] + sum(w.numpy()[:, :, j].astype(np.float64) @ xp[:, j:j + L] for j in range(k))
+    assert np.abs(out - ref).max() < 2e-5, np.abs(out - ref).max()
+
+
+@pytest.mark.parametrize("k,dil,cin,L", [(11, 3, 8, 300), (11, 5, 8, 244), (7, 5, 8, 100), (3, 3, 16, 256)])
+def test_dilated_kernel_index_algebra_reproduces_the_conv(k, dil, cin, L):
+    """Dilated instances (two fragments per wave): tile n = rc * J + jt holds the outputs rc + dil (4 jt + i) of a
+    4 J dil-column block; raw rows start PADA columns before the block; a tile reads 3 (G - 1) + 6 inputs dil apart; the
+    outputs leave through an 8-row x 256-column stage and are stored 16 bytes per lane.  Replayed with the kernel's
+    own index formulas."""
+    lib = _lib.load()
+    ci_chunk = lib.ov_conv1d_wino_chunk(k)
+    G = (k + 2) // 3
+    NT = 64
+    J = NT // dil
+    ncol = 4 * J * dil
+    padd = (k - 1) // 2 * dil
+    pada = (padd + 3) // 4 * 4
+    nv = 3 * (G - 1) + 6
+    rw = (pada - padd + dil - 1 + dil * (4 * (J - 1) + nv - 1) + 1 + 3) // 4 * 4
+    cout, slope = 128, 0.1
+    gen = torch.Generator().manual_seed(7)
+    w = torch.randn(cout, cin, k, generator=gen) * (cin * k) ** -0.5
+    x = torch.randn(cin, L, generator=gen).numpy()
+    bias = torch.randn(cout, generator=gen).numpy()
+    packed = pack(w)
+    nchunks, kr = cin // ci_chunk, ci_chunk * G
+    npair = kr // 4
+    ntiles = (L + ncol - 1) // ncol
+    out = np.full((cout, L), np.nan)
+    bt, at = np.array(wino.BT, dtype=np.float32), np.array(wino.AT, dtype=np.float64)
+    for tile in range(ntiles):
+        t0 = tile * ncol
+        y = np.zeros((4, 6, 32, NT))
+        y[:, 1] = bias.reshape(4, 32)[:, :, None]
+        for c in range(nchunks):
+            raw = np.zeros((ci_chunk, rw), dtype=np.float32)
+            for idx in range(ci_chunk * rw // 4):
+                row, c4 = divmod(idx, rw // 4)
+                t = t0 - pada + 4 * c4
+                for e in range(4):
+                    if 0 <= t + e < L:
+                        v = x[c * ci_chunk + row, t + e]
+                        raw[row, 4 * c4 + e] = v if v > 0 else v * slope
+            V = np.zeros((kr, NT, 6), dtype=np.float32)
+            for idx in range(ci_chunk * NT):
+                tl, cil = idx & (NT - 1), idx // NT
+                rc0 = tl // J
+                rc, jt = (rc0, tl - rc0 * J) if rc0 < dil else (0, 0)
+                s0 = (pada - padd) + rc + 4 * dil * jt
+                win = raw[cil, s0: s0 + dil * nv: dil]
+                assert win.size == nv
+                for g in range(G):
+                    V[g * ci_chunk + cil, tl] = bt @ win[3 * g: 3 * g + 6]
+            for wave in range(4):
+                base = (wave * nchunks + c) * npair * 3
+                for s in range(kr // 2):
+                    sp, s2 = s >> 1, s & 1
+                    for q in range(6):
+                        e = s2 * 6 + q
+                        sub = packed[(base + sp * 3 + (e >> 2)) * 256:(base + sp * 3 + (e >> 2) + 1) * 256].reshape(64, 4)
+                        a = sub[:, e & 3]
+                        for half in range(2):
+                            y[wave, q] += np.outer(a[32 * half:32 * half + 32].astype(np.float64), V[2 * s + half, :, q].astype(np.float64))
+        o = np.einsum("ip,wprn->wrni", at, y)              # [wave][row][tile][i]
+        stage = np.full((4, 32, 256), np.nan)              # (the kernel walks it 8 rows at a time)
+        for tl in range(NT):
+            rc0 = tl // J
+            if rc0 >= dil:
+                continue
+            cb = rc0 + 4 * dil * (tl - rc0 * J)
+            for i in range(4):
+                stage[:, :, cb + i * dil] = o[:, :, tl, i]
+        for lane in range(64):
+            col = t0 + 4 * lane
+            if 4 * lane < ncol and col < L:
+                out[:, col:col + 4] = stage[:, :, 4 * lane:4 * lane + 4].reshape(128, 4)
+    xa = np.where(x > 0, x, slope * x)
+    xp = np.pad(xa, ((0, 0), (padd, padd)))
+    ref = bias[:, None] + sum(w.numpy()[:, :, j].astype(np.float64) @ xp[:, j * dil:j * dil + L] for j in range(k))
+    assert not np.isnan(out).any()
     assert np.abs(out - ref).max() < 2e-5, np.abs(out - ref).max()
