@@ -527,7 +527,7 @@ int ov_split3_to_f32(const uint16_t* a, const uint16_t* b, const uint16_t* c, in
  * output and (co, ci): 1.5 (K = 3), 4.5 (K = 7), 6 (K = 11) instead of K.  The transforms round where the direct conv
  * does not: against float64 the result carries ~4x the rounding error of ov_conv1d_f32 (tests/test_gpu_wino.py).
  * Tensors are fp32 [B][C][L], rows x_ld / out_ld floats apart (0 = L); L, x_ld, out_ld multiples of 4 and every
- * pointer 16-byte aligned; Cin % ov_conv1d_wino_chunk(K) == 0, Cout % 128 == 0; out must not alias x
+ * pointer 16-byte aligned; Cin % ov_conv1d_wino_chunk(K, Cout) == 0, Cout % 64 == 0 and <= 512; out must not alias x
  * (it may be the very tensor passed as res or add -- the MRF running sum is accumulated in place). */
 typedef struct ov_conv1d_wino_params {
   const float* x;        /* [B][Cin][L] */
@@ -556,8 +556,9 @@ typedef struct ov_conv1d_wino_params {
 int ov_conv1d_wino_f32(const ov_conv1d_wino_params* p, ov_stream_t stream);
 /* 1 when (Cin, Cout, K, dil) has an instance, else 0 (callers then use ov_conv1d_f32). */
 int ov_conv1d_wino_supported(int Cin, int Cout, int K, int dil);
-/* Input channels per LDS fill of the K-tap instance (the packed stream is ordered by it); 0 = no instance. */
-int ov_conv1d_wino_chunk(int K);
+/* Input channels per LDS fill of the instance for K taps and Cout rows (Cout % 128 == 0: four 32-row fragments per
+ * workgroup; Cout % 64 == 0: two); the packed stream is ordered by it; 0 = no instance. */
+int ov_conv1d_wino_chunk(int K, int Cout);
 /* Floats of the packed transform-domain weights; 0 when the shape has no instance. */
 size_t ov_conv1d_wino_pack_size(int Cout, int Cin, int K);
 /* HOST w [Cout][Cin][K] fp32 -> U_p[co][g][ci] = sum_k G[p][k] w[co][ci][3g + k] (float64, rounded once to fp32) in

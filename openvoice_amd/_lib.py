@@ -168,7 +168,7 @@ SIGNATURES = {
     "ov_split3_to_f32": (ctypes.c_int, [_fp, _fp, _fp, _i64, _fp, _i, _i, _i, ctypes.c_float, ctypes.c_float, _fp]),
     "ov_conv1d_wino_f32": (ctypes.c_int, [ctypes.POINTER(ConvWinoParams), _fp]),
     "ov_conv1d_wino_supported": (ctypes.c_int, [_i, _i, _i, _i]),
-    "ov_conv1d_wino_chunk": (ctypes.c_int, [_i]),
+    "ov_conv1d_wino_chunk": (ctypes.c_int, [_i, _i]),
     "ov_conv1d_wino_pack_size": (ctypes.c_size_t, [_i, _i, _i]),
     "ov_conv1d_wino_pack_f32": (ctypes.c_int, [_fp, _i, _i, _i, _fp]),
     "ov_frame_hops_f32": (ctypes.c_int, [_fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),

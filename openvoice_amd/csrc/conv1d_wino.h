@@ -90,14 +90,22 @@ __host__ __device__ inline size_t wino_pack_floats(int Cout, int Cin, int K, int
 // workgroups per CU (they cover each other's barriers and epilogues).  NF = 2: 192 accumulator registers, 4 helper
 // waves, ONE workgroup per CU -- every A fragment feeds two MFMAs, which halves the weight stream from L2 (at NF = 1 the
 // 512 workgroups pull 12 TB/s of fragments, 3/4 of what the L2s deliver with nothing else running: profiles/r06_s4).
-template <int K, int DIL, int CI, int NF, bool DBG>
+// MW = matrix waves along M.  MW = 4: the four waves own the four 32-row fragments of a 128-row M-block and share one
+// column block.  MW = 2 (Cout a multiple of 64 only: the C = 64 stage): two 32-row fragments x TWO adjacent column
+// sub-blocks per workgroup (wave w: rows 32 (w & 1), sub-block w >> 1), so the workgroup still runs four matrix waves on a
+// 64-row layer; the waves of a sub-block pair stream the same A fragments.
+template <int K, int DIL, int CI, int NF, int MW, bool DBG>
 __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_wino_kernel(const ov_conv1d_wino_params p) {
   using Ge = Geo<K>;
   using Gd = GeoD<K, DIL == 1 ? 3 : DIL, NF>;   // (only read when DIL > 1)
   constexpr int G = Ge::G, KR = CI * G, NSTEP = KR / 2, NPAIR = NSTEP / 2;
-  constexpr int NT = 32 * NF;          // Winograd tiles per N-block
-  constexpr int NCOL = DIL == 1 ? 4 * NT : Gd::NCOL;     // output columns per N-block
-  constexpr int RW = DIL == 1 ? NCOL + 16 : Gd::RW;      // floats per raw LDS row: column t0 - ORG + c at index c
+  constexpr int NB = 4 / MW;           // column sub-blocks per workgroup
+  constexpr int NTS = 32 * NF;         // Winograd tiles per sub-block (what one matrix wave owns)
+  constexpr int NT = NTS * NB;         // Winograd tiles per N-block
+  constexpr int NCOLS = DIL == 1 ? 4 * NTS : Gd::NCOL;   // output columns per sub-block
+  constexpr int NCOL = NCOLS * NB;     // output columns per N-block
+  constexpr int RW = (DIL == 1 ? NCOLS + 16 : Gd::RW) + (NB - 1) * NCOLS;   // floats per raw LDS row: column t0 - ORG + c at index c
+  static_assert(MW == 4 || (MW == 2 && NF == 2), "two-row-fragment workgroups run two fragments per wave");
   constexpr int ORG = DIL == 1 ? 8 : Gd::PADA;
   constexpr int RW4 = RW / 4;
   constexpr int NHELP = 2 * NF;        // helper waves
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
   const int L = p.L;
   const int nchunks = p.Cin / CI;
   const int ntiles = (L + NCOL - 1) / NCOL;
-  const int mblocks = p.Cout / 128;
+  const int mblocks = p.Cout / (32 * MW);
   int total = ntiles * mblocks * p.B;
   // Length-aware work list (ov_conv1d_wino_params.col_limit, as ov_conv1d_params.col_limit): utterance b contributes only
   // the N-blocks that start before its column limit; lim_pref[b] = blocks of the utterances before b, so the list stays
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
 #pragma unroll
       for (int r = 0; r < ROUNDS; ++r) {
         const int idx = r * (64 * NHELP) + hl;
-        const int tile = idx & (NT - 1), cil = idx / NT;
+        const int tile = idx & (NT - 1), cil = idx / NT;     // tile of the N-block = sub-block * NTS + tile of the sub-block
         constexpr int NWIN = DIL == 1 ? 4 * Ge::NB128 : Gd::NV;
         float win[NWIN];
         if constexpr (DIL == 1) {
@@ -257,8 +265,9 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
           }
         } else {
           // tile -> (residue class, tile of the class); the left-over tiles duplicate tile 0 (never stored)
-          const int rc0 = tile / Gd::J, rc = rc0 < DIL ? rc0 : 0, jt = rc0 < DIL ? tile - rc0 * Gd::J : 0;
-          const float* s0 = src + cil * RW + (Gd::PADA - Gd::PADD) + rc + 4 * DIL * jt;
+          const int sub = tile / NTS, tl = tile - sub * NTS;
+          const int rc0 = tl / Gd::J, rc = rc0 < DIL ? rc0 : 0, jt = rc0 < DIL ? tl - rc0 * Gd::J : 0;
+          const float* s0 = src + cil * RW + (Gd::PADA - Gd::PADD) + sub * NCOLS + rc + 4 * DIL * jt;
 #pragma unroll
           for (int u = 0; u < Gd::NV; ++u) win[u] = s0[DIL * u];
         }
@@ -321,13 +330,14 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
   const uint32_t LD = (uint32_t)p.out_ld;
   int wid = wid0, b, tile, mblk;
   decode(wid, b, tile, mblk);
-  int mtile = mblk * 4 + wave;
+  const int wrow = MW == 4 ? wave : (wave & 1), wsub = MW == 4 ? 0 : (wave >> 1);
+  int mtile = mblk * MW + wrow;
   // sub-record index of the first k-step pair of (mtile, chunk 0); the stream of an item is contiguous
   uint32_t rec = (uint32_t)mtile * (uint32_t)nchunks * (uint32_t)(NPAIR * 3);
   f32x4 a_cur[3], a_nxt[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) a_cur[j] = wbase[(size_t)(rec + j) * 64 + lane];
-  const int voffB = (half * NT + n) * 6;       // this lane's float offset inside a k-step's two k-rows (fragment 0)
+  const int voffB = (half * NT + wsub * NTS + n) * 6;   // this lane's float offset inside a k-step's two k-rows (fragment 0)
 
   __syncthreads();   // (A)
   __syncthreads();   // (B)
@@ -407,7 +417,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
     const bool more = nwid < wend;
     int nb = 0, ntile = 0, nmblk = 0;
     if (more) decode(nwid, nb, ntile, nmblk);
-    const int nmtile = nmblk * 4 + wave;
+    const int nmtile = nmblk * MW + wrow;
     const int ob = b, otile = tile, omtile = mtile;
     if (more) {
       rec = (uint32_t)nmtile * (uint32_t)nchunks * (uint32_t)(NPAIR * 3);
@@ -426,7 +436,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
       if constexpr (DIL == 1) {
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
-        const uint32_t col = (uint32_t)otile * NCOL + 128u * f + 4u * (uint32_t)n;
+        const uint32_t col = (uint32_t)otile * NCOL + (uint32_t)(wsub * NCOLS) + 128u * f + 4u * (uint32_t)n;
         const bool colok = col < (uint32_t)L;               // L % 4 == 0: a lane's 4 columns are in or out together
         const uint32_t ccol = colok ? col : 0u;
 #pragma unroll
@@ -464,7 +474,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
       }
           } else {
         float* ost = ostage + wave * (8 * OST);
-        const uint32_t c0 = (uint32_t)otile * NCOL;            // first column of the N-block (multiple of 4)
+        const uint32_t c0 = (uint32_t)otile * NCOL + (uint32_t)(wsub * NCOLS);   // first column of this wave's sub-block (multiple of 4)
         // this lane's tiles: fragment f, tile 32 f + n -> columns rcl + DIL (4 jt + i) of the block, or none
         int cbase[NF];
 #pragma unroll
@@ -473,7 +483,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
           cbase[f] = rc0 < DIL ? rc0 + 4 * DIL * (tl - rc0 * Gd::J) : -1;
         }
         const uint32_t col = c0 + 4u * (uint32_t)lane;         // the 16 bytes this lane stores of each row
-        const bool colok = 4 * lane < NCOL && col < (uint32_t)L;
+        const bool colok = 4 * lane < NCOLS && col < (uint32_t)L;
         const uint32_t ccol = colok ? col : 0u;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
@@ -537,12 +547,12 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
   }
 }
 
-template <int K, int DIL, int CI, int NF, bool DBG>
+template <int K, int DIL, int CI, int NF, int MW, bool DBG>
 int wino_launch(const ov_conv1d_wino_params* p, hipStream_t stream) {
-  constexpr int NCOL = DIL == 1 ? 128 * NF : GeoD<K, DIL == 1 ? 3 : DIL, NF>::NCOL, NHELP = 2 * NF;
+  constexpr int NCOL = (DIL == 1 ? 128 * NF : GeoD<K, DIL == 1 ? 3 : DIL, NF>::NCOL) * (4 / MW), NHELP = 2 * NF;
   const int ntiles = (p->L + NCOL - 1) / NCOL;
-  const long total = (long)ntiles * (p->Cout / 128) * p->B;   // (an upper bound under a column limit: idle workgroups exit)
-  auto kernel = conv1d_wino_kernel<K, DIL, CI, NF, DBG>;
+  const long total = (long)ntiles * (p->Cout / (32 * MW)) * p->B;   // (an upper bound under a column limit: idle workgroups exit)
+  auto kernel = conv1d_wino_kernel<K, DIL, CI, NF, MW, DBG>;
   static std::atomic<int> slot_cache[ovk::OV_MAX_DEVICES];
   const int slots = ovk::resident_workgroups(reinterpret_cast<const void*>(kernel), 64 * (4 + NHELP), slot_cache);
   long nwg = p->nwg > 0 ? p->nwg : slots;
@@ -552,22 +562,32 @@ int wino_launch(const ov_conv1d_wino_params* p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? OV_OK : OV_E_LAUNCH;
 }
 
-constexpr int wino_ci(int K) { return K == 3 ? 16 : (K == 7 || K == 11) ? 8 : 0; }
+// Input channels per LDS fill: by kernel size and by the rows a workgroup covers (128: four row fragments; 64: two row
+// fragments x two column sub-blocks, i.e. twice the V tile per channel) -- the packed weight stream is ordered by it.
+constexpr int wino_ci(int K, int mw = 4) { return K == 3 ? (mw == 4 ? 16 : 8) : (K == 7 || K == 11) ? (mw == 4 ? 8 : 4) : 0; }
+constexpr int wino_mw(int Cout) { return Cout % 128 == 0 ? 4 : (Cout % 64 == 0 ? 2 : 0); }
 
 // One translation unit per kernel size (conv1d_wino_k3 / k7 / k11.hip) so that the instances compile in parallel.
 int wino_dispatch_k3(const ov_conv1d_wino_params* p, int nf, hipStream_t stream);
 int wino_dispatch_k7(const ov_conv1d_wino_params* p, int nf, hipStream_t stream);
 int wino_dispatch_k11(const ov_conv1d_wino_params* p, int nf, hipStream_t stream);
 
+#define OVW_DISPATCH_MW(KK, MWV)                                                                                        \
+  {                                                                                                                      \
+    constexpr int CI = ovkw::wino_ci(KK, MWV);                                                                           \
+    if (p->dil == 1 && nf == 1 && MWV == 4)                                                                              \
+      return dbg ? wino_launch<KK, 1, CI, 1, 4, true>(p, st) : wino_launch<KK, 1, CI, 1, 4, false>(p, st);                \
+    if (p->dil == 1) return dbg ? wino_launch<KK, 1, CI, 2, MWV, true>(p, st) : wino_launch<KK, 1, CI, 2, MWV, false>(p, st); \
+    if (p->dil == 3) return dbg ? wino_launch<KK, 3, CI, 2, MWV, true>(p, st) : wino_launch<KK, 3, CI, 2, MWV, false>(p, st); \
+    if (p->dil == 5) return dbg ? wino_launch<KK, 5, CI, 2, MWV, true>(p, st) : wino_launch<KK, 5, CI, 2, MWV, false>(p, st); \
+    return OV_E_UNSUPPORTED;                                                                                             \
+  }
 #define OVW_DEFINE_DISPATCH(KK)                                                                                          \
   int ovkw::wino_dispatch_k##KK(const ov_conv1d_wino_params* p, int nf, hipStream_t st) {                                \
-    constexpr int CI = ovkw::wino_ci(KK);                                                                                \
     const bool dbg = p->dbg != nullptr;                                                                                  \
-    if (p->dil == 1 && nf == 1) return dbg ? wino_launch<KK, 1, CI, 1, true>(p, st) : wino_launch<KK, 1, CI, 1, false>(p, st); \
-    if (p->dil == 1) return dbg ? wino_launch<KK, 1, CI, 2, true>(p, st) : wino_launch<KK, 1, CI, 2, false>(p, st);        \
-    if (p->dil == 3) return dbg ? wino_launch<KK, 3, CI, 2, true>(p, st) : wino_launch<KK, 3, CI, 2, false>(p, st);        \
-    if (p->dil == 5) return dbg ? wino_launch<KK, 5, CI, 2, true>(p, st) : wino_launch<KK, 5, CI, 2, false>(p, st);        \
-    return OV_E_UNSUPPORTED;                                                                                             \
+    if (ovkw::wino_mw(p->Cout) == 4) OVW_DISPATCH_MW(KK, 4)                                                              \
+    if (nf != 2) return OV_E_UNSUPPORTED;                                                                                \
+    OVW_DISPATCH_MW(KK, 2)                                                                                               \
   }
 
 }  // namespace ovkw

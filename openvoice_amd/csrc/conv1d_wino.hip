@@ -15,24 +15,24 @@ const double kG[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 
 
 extern "C" {
 
-int ov_conv1d_wino_chunk(int K) { return wino_ci(K); }
+int ov_conv1d_wino_chunk(int K, int Cout) { return Cout > 0 && wino_mw(Cout) ? wino_ci(K, wino_mw(Cout)) : 0; }
 
 int ov_conv1d_wino_supported(int Cin, int Cout, int K, int dil) {
-  const int ci = wino_ci(K);
+  const int ci = ov_conv1d_wino_chunk(K, Cout);
   if (ci == 0 || (dil != 1 && dil != 3 && dil != 5)) return 0;
-  return (Cin > 0 && Cin % ci == 0 && Cout > 0 && Cout % 128 == 0) ? 1 : 0;
+  return (Cin > 0 && Cin % ci == 0 && Cout <= MAX_COUT) ? 1 : 0;
 }
 
 size_t ov_conv1d_wino_pack_size(int Cout, int Cin, int K) {
-  const int ci = wino_ci(K);
-  if (ci == 0 || Cin <= 0 || Cout <= 0 || Cin % ci != 0 || Cout % 32 != 0) return 0;
+  const int ci = ov_conv1d_wino_chunk(K, Cout);
+  if (ci == 0 || Cin <= 0 || Cin % ci != 0) return 0;
   return wino_pack_floats(Cout, Cin, K, ci);
 }
 
 int ov_conv1d_wino_pack_f32(const float* w, int Cout, int Cin, int K, float* dst) {
   const size_t nfl = ov_conv1d_wino_pack_size(Cout, Cin, K);
   if (!w || !dst || nfl == 0) return OV_E_BADARG;
-  const int CI = wino_ci(K), G = (K + 2) / 3, KR = CI * G, NPAIR = KR / 4, nchunks = Cin / CI;
+  const int CI = ov_conv1d_wino_chunk(K, Cout), G = (K + 2) / 3, KR = CI * G, NPAIR = KR / 4, nchunks = Cin / CI;
   std::memset(dst, 0, nfl * sizeof(float));
   for (int mt = 0; mt < Cout / 32; ++mt)
     for (int c = 0; c < nchunks; ++c)

@@ -342,4 +342,5 @@ def test_conv_wino_params_struct_matches_header_field_order():
     lib = _lib.load()
     assert lib.ov_conv1d_wino_f32(None, None) == -1
     assert lib.ov_version() >= 207
-    assert [lib.ov_conv1d_wino_chunk(k) for k in (3, 5, 7, 11)] == [16, 0, 8, 8]
+    assert [lib.ov_conv1d_wino_chunk(k, 128) for k in (3, 5, 7, 11)] == [16, 0, 8, 8]
+    assert [lib.ov_conv1d_wino_chunk(k, 64) for k in (3, 7, 11)] == [8, 4, 4] and lib.ov_conv1d_wino_chunk(11, 96) == 0

@@ -40,10 +40,10 @@ def pack(w):
     return dst.numpy()
 
 
-@pytest.mark.parametrize("cout,cin,k", [(128, 32, 3), (128, 16, 7), (256, 24, 11)])
+@pytest.mark.parametrize("cout,cin,k", [(128, 32, 3), (128, 16, 7), (256, 24, 11), (64, 64, 11), (64, 16, 3)])
 def test_weight_packer_sub_record_order(cout, cin, k):
     lib = _lib.load()
-    ci = lib.ov_conv1d_wino_chunk(k)
+    ci = lib.ov_conv1d_wino_chunk(k, cout)
     G = (k + 2) // 3
     w = torch.randn(cout, cin, k, generator=torch.Generator().manual_seed(2)) * (cin * k) ** -0.5
     packed = pack(w)
@@ -65,18 +65,19 @@ def test_weight_packer_sub_record_order(cout, cin, k):
     assert lib.ov_conv1d_wino_pack_size(100, 128, 3) == 0 and lib.ov_conv1d_wino_pack_size(128, 128, 5) == 0
     assert lib.ov_conv1d_wino_supported(128, 128, 11, 1) == 1 and lib.ov_conv1d_wino_supported(128, 128, 11, 2) == 0
     assert lib.ov_conv1d_wino_supported(128, 128, 11, 5) == 1 and lib.ov_conv1d_wino_supported(256, 256, 3, 3) == 1
-    assert lib.ov_conv1d_wino_supported(64, 64, 7, 1) == 0      # Cout in whole 128-row blocks
+    assert lib.ov_conv1d_wino_supported(64, 64, 7, 1) == 1 and lib.ov_conv1d_wino_supported(32, 32, 7, 1) == 0
 
 
-@pytest.mark.parametrize("k,cin,L", [(11, 16, 260), (7, 8, 128), (3, 32, 132)])
-def test_kernel_index_algebra_reproduces_the_conv(k, cin, L):
+@pytest.mark.parametrize("k,cin,L,cout", [(11, 16, 260, 128), (7, 8, 128, 128), (3, 32, 132, 128), (11, 8, 520, 64), (3, 16, 260, 64)])
+def test_kernel_index_algebra_reproduces_the_conv(k, cin, L, cout):
     """One M-block (128 rows), the helper / matrix wave arithmetic of conv1d_wino_kernel replayed with numpy indexing
     exactly as the kernel forms its addresses (fp32 transforms, float64 accumulation so that only indices are on trial)."""
     lib = _lib.load()
-    ci_chunk = lib.ov_conv1d_wino_chunk(k)
+    ci_chunk = lib.ov_conv1d_wino_chunk(k, cout)
     G, pad, off0, wstart, nb128 = geo(k)
-    cout, slope = 128, 0.1
-    gen = torch.Generator().manual_seed(5)
+    slope = 0.1
+    nmt = cout // 32          # (a 64-row layer: two row fragments x two column sub-blocks per workgroup -- at dilation 1
+    gen = torch.Generator().manual_seed(5)   # the sub-blocks are consecutive 128-column ranges, so the same replay holds)
     w = torch.randn(cout, cin, k, generator=gen) * (cin * k) ** -0.5
     x = torch.randn(cin, L, generator=gen).numpy()
     bias = torch.randn(cout, generator=gen).numpy()
@@ -88,8 +89,8 @@ def test_kernel_index_algebra_reproduces_the_conv(k, cin, L):
     bt, at = np.array(wino.BT, dtype=np.float32), np.array(wino.AT, dtype=np.float64)
     for tile in range(ntiles):
         t0 = tile * 128
-        y = np.zeros((4, 6, 32, 32))                      # [wave][p][row in fragment][tile n]
-        y[:, 1] = bias.reshape(4, 32)[:, :, None]
+        y = np.zeros((nmt, 6, 32, 32))                    # [row fragment][p][row in fragment][tile n]
+        y[:, 1] = bias.reshape(nmt, 32)[:, :, None]
         for c in range(nchunks):
             raw = np.zeros((ci_chunk, RW), dtype=np.float32)
             for idx in range(ci_chunk * RW // 4):         # staging vectors
@@ -106,7 +107,7 @@ def test_kernel_index_algebra_reproduces_the_conv(k, cin, L):
                 for g in range(G):
                     o = off0 - wstart + 3 * g
                     V[g * ci_chunk + cil, tl] = bt @ win[o:o + 6]
-            for wave in range(4):                          # matrix waves: sub-records -> A fragments, V -> B fragments
+            for wave in range(nmt):                        # matrix waves: sub-records -> A fragments, V -> B fragments
                 mt = wave
                 base = (mt * nchunks + c) * npair * 3
                 for s in range(kr // 2):
@@ -119,7 +120,7 @@ def test_kernel_index_algebra_reproduces_the_conv(k, cin, L):
                             b = V[2 * s + half, :, q]      # lane (half, n) -> B[k = half][n]
                             y[wave, q] += np.outer(a[32 * half:32 * half + 32].astype(np.float64), b.astype(np.float64))
         o = np.einsum("ip,wprn->wrni", at, y)              # [wave][row][tile n][i]
-        for wave in range(4):
+        for wave in range(nmt):
             for n in range(32):
                 col = t0 + 4 * n
                 if col < L:
@@ -130,23 +131,28 @@ def test_kernel_index_algebra_reproduces_the_conv(k, cin, L):
     assert np.abs(out - ref).max() < 2e-5, np.abs(out - ref).max()
 
 
-@pytest.mark.parametrize("k,dil,cin,L", [(11, 3, 8, 300), (11, 5, 8, 244), (7, 5, 8, 100), (3, 3, 16, 256)])
-def test_dilated_kernel_index_algebra_reproduces_the_conv(k, dil, cin, L):
+@pytest.mark.parametrize("k,dil,cin,L,cout", [(11, 3, 8, 300, 128), (11, 5, 8, 244, 128), (7, 5, 8, 100, 128), (3, 3, 16, 256, 128),
+                                              (11, 3, 4, 600, 64), (7, 5, 8, 488, 64)])
+def test_dilated_kernel_index_algebra_reproduces_the_conv(k, dil, cin, L, cout):
     """Dilated instances (two fragments per wave): tile n = rc * J + jt holds the outputs rc + dil (4 jt + i) of a
     4 J dil-column block; raw rows start PADA columns before the block; a tile reads 3 (G - 1) + 6 inputs dil apart; the
     outputs leave through an 8-row x 256-column stage and are stored 16 bytes per lane.  Replayed with the kernel's
     own index formulas."""
     lib = _lib.load()
-    ci_chunk = lib.ov_conv1d_wino_chunk(k)
+    ci_chunk = lib.ov_conv1d_wino_chunk(k, cout)
     G = (k + 2) // 3
-    NT = 64
-    J = NT // dil
-    ncol = 4 * J * dil
+    NTS = 64                       # tiles per sub-block (one matrix wave's two fragments)
+    NB = 4 // (cout // 32) if cout == 64 else 1     # sub-blocks per workgroup: 2 on a 64-row layer
+    NT = NTS * NB
+    J = NTS // dil
+    ncols = 4 * J * dil            # columns per sub-block
+    ncol = ncols * NB
     padd = (k - 1) // 2 * dil
     pada = (padd + 3) // 4 * 4
     nv = 3 * (G - 1) + 6
-    rw = (pada - padd + dil - 1 + dil * (4 * (J - 1) + nv - 1) + 1 + 3) // 4 * 4
-    cout, slope = 128, 0.1
+    rw = (pada - padd + dil - 1 + dil * (4 * (J - 1) + nv - 1) + 1 + 3) // 4 * 4 + (NB - 1) * ncols
+    slope = 0.1
+    nmt = cout // 32
     gen = torch.Generator().manual_seed(7)
     w = torch.randn(cout, cin, k, generator=gen) * (cin * k) ** -0.5
     x = torch.randn(cin, L, generator=gen).numpy()
@@ -159,8 +165,8 @@ def test_dilated_kernel_index_algebra_reproduces_the_conv(k, dil, cin, L):
     bt, at = np.array(wino.BT, dtype=np.float32), np.array(wino.AT, dtype=np.float64)
     for tile in range(ntiles):
         t0 = tile * ncol
-        y = np.zeros((4, 6, 32, NT))
-        y[:, 1] = bias.reshape(4, 32)[:, :, None]
+        y = np.zeros((nmt, 6, 32, NT))
+        y[:, 1] = bias.reshape(nmt, 32)[:, :, None]
         for c in range(nchunks):
             raw = np.zeros((ci_chunk, rw), dtype=np.float32)
             for idx in range(ci_chunk * rw // 4):
@@ -172,15 +178,16 @@ def test_dilated_kernel_index_algebra_reproduces_the_conv(k, dil, cin, L):
                         raw[row, 4 * c4 + e] = v if v > 0 else v * slope
             V = np.zeros((kr, NT, 6), dtype=np.float32)
             for idx in range(ci_chunk * NT):
-                tl, cil = idx & (NT - 1), idx // NT
+                tile, cil = idx & (NT - 1), idx // NT
+                sub, tl = divmod(tile, NTS)
                 rc0 = tl // J
                 rc, jt = (rc0, tl - rc0 * J) if rc0 < dil else (0, 0)
-                s0 = (pada - padd) + rc + 4 * dil * jt
+                s0 = (pada - padd) + sub * ncols + rc + 4 * dil * jt
                 win = raw[cil, s0: s0 + dil * nv: dil]
                 assert win.size == nv
                 for g in range(G):
-                    V[g * ci_chunk + cil, tl] = bt @ win[3 * g: 3 * g + 6]
-            for wave in range(4):
+                    V[g * ci_chunk + cil, tile] = bt @ win[3 * g: 3 * g + 6]
+            for wave in range(nmt):
                 base = (wave * nchunks + c) * npair * 3
                 for s in range(kr // 2):
                     sp, s2 = s >> 1, s & 1
@@ -190,19 +197,20 @@ def test_dilated_kernel_index_algebra_reproduces_the_conv(k, dil, cin, L):
                         a = sub[:, e & 3]
                         for half in range(2):
                             y[wave, q] += np.outer(a[32 * half:32 * half + 32].astype(np.float64), V[2 * s + half, :, q].astype(np.float64))
-        o = np.einsum("ip,wprn->wrni", at, y)              # [wave][row][tile][i]
-        stage = np.full((4, 32, 256), np.nan)              # (the kernel walks it 8 rows at a time)
-        for tl in range(NT):
-            rc0 = tl // J
-            if rc0 >= dil:
-                continue
-            cb = rc0 + 4 * dil * (tl - rc0 * J)
-            for i in range(4):
-                stage[:, :, cb + i * dil] = o[:, :, tl, i]
-        for lane in range(64):
-            col = t0 + 4 * lane
-            if 4 * lane < ncol and col < L:
-                out[:, col:col + 4] = stage[:, :, 4 * lane:4 * lane + 4].reshape(128, 4)
+        o = np.einsum("ip,wprn->wrni", at, y)              # [row fragment][row][tile][i]
+        for sub in range(NB):                              # each matrix wave stages its own sub-block
+            stage = np.full((nmt, 32, 256), np.nan)        # (the kernel walks it 8 rows at a time)
+            for tl in range(NTS):
+                rc0 = tl // J
+                if rc0 >= dil:
+                    continue
+                cb = rc0 + 4 * dil * (tl - rc0 * J)
+                for i in range(4):
+                    stage[:, :, cb + i * dil] = o[:, :, sub * NTS + tl, i]
+            for lane in range(64):
+                col = t0 + sub * ncols + 4 * lane
+                if 4 * lane < ncols and col < L:
+                    out[:, col:col + 4] = stage[:, :, 4 * lane:4 * lane + 4].reshape(cout, 4)
     xa = np.where(x > 0, x, slope * x)
     xp = np.pad(xa, ((0, 0), (padd, padd)))
     ref = bias[:, None] + sum(w.numpy()[:, :, j].astype(np.float64) @ xp[:, j * dil:j * dil + L] for j in range(k))

@@ -95,7 +95,7 @@ def main():
     sd = synthetic_state_dict(CONVERTER_MODEL_CONFIG, 513, seed=1234)
     shapes = [(128, 11, 1)]
     if args.shapes:
-        shapes += [(C, K, d) for C in (128, 256) for K in (3, 7, 11) for d in (1, 3, 5)
+        shapes += [(C, K, d) for C in (128, 256, 64) for K in (3, 7, 11) for d in (1, 3, 5)
                    if (C, K, d) != (128, 11, 1) and wino.supported(C, C, K, d)]
     rows = []
     for C, K, d in shapes:
