@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "conv1d_mfma.h"
 #include "openvoice_amd.h"
@@ -77,7 +78,8 @@ __host__ __device__ inline size_t wino_pack_floats(int Cout, int Cin, int K, int
 
 // phase timers (DBG instances only: the dispatcher selects them when ov_conv1d_wino_params.dbg is set)
 #ifndef OVW_EXP
-#define OVW_EXP 0   // measurement builds only (scripts/exp_wino.sh): 1 = MFMAs replaced by one FMA; 2 = helper transform skipped
+#define OVW_EXP 0   // measurement builds only (scripts/exp_wino.sh): 1 = MFMAs replaced by one FMA; 2 = helper transform skipped;
+                    // 3 = no weight stream (the first fragments of an item are reused); 4 = no epilogue stores
 #endif
 #define OVW_MARK(q)                                                \
   if constexpr (DBG) {                                             \
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
         if (s2 == 0) {
           rec += 3;   // the sub-records after the last real pair are zeros written by the packer
 #pragma unroll
-          for (int j = 0; j < 3; ++j) a_nxt[j] = wbase[(size_t)(rec + j) * 64 + lane];
+          for (int j = 0; j < 3; ++j) a_nxt[j] = OVW_EXP == 3 ? a_cur[j] : wbase[(size_t)(rec + j) * 64 + lane];
         }
 #pragma unroll
         for (int qq = 0; qq < 3; ++qq) {
@@ -427,55 +429,78 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
     }
 
     // ---- epilogue: out = (At Y + res + add) * scale, 16 bytes per lane and row --------------------------------
+    // Stores and loads share one in-order counter (vmcnt): a wait for an operand load issued AFTER a store is a wait for
+    // that store's acknowledgement.  The operand rows are therefore requested one group AHEAD of the stores (two register
+    // sets), and launches without operands (every first conv of a pair) take a variant with no loads at all.
     {
       const float scale = p.scale;
       float* outb = p.out + (int64_t)ob * p.out_bstride;
       const float* resb = p.res ? p.res + (int64_t)ob * p.res_bstride : nullptr;
       const float* addb = p.add ? p.add + (int64_t)ob * p.add_bstride : nullptr;
       const uint32_t rbase = (uint32_t)omtile * 32u + 4u * (uint32_t)half;
+      auto at4 = [&](int f, int r) {
+        const float y0 = acc[0][f][r], y1 = acc[1][f][r], y2 = acc[2][f][r], y3 = acc[3][f][r], y4 = acc[4][f][r],
+                    y5 = acc[5][f][r];
+        const float s1 = y1 + y2, d1 = y1 - y2, s2 = y3 + y4, d2 = y3 - y4;
+        f32x4 o;
+        o[0] = (y0 + s1) + s2;
+        o[1] = __builtin_fmaf(2.f, d2, d1);
+        o[2] = __builtin_fmaf(4.f, s2, s1);
+        o[3] = __builtin_fmaf(8.f, d2, d1) + y5;
+        return o;
+      };
       if constexpr (DIL == 1) {
+        auto run = [&](auto has_res, auto has_add) {
+          constexpr bool HR = decltype(has_res)::value, HA = decltype(has_add)::value;
+          constexpr int NGRP = 16 * NF;                      // one accumulator row (4 columns) per group
+          // addressing: 64-bit row bases stay scalar ((32 mtile + row of the register) * LD), a lane carries ONE 32-bit
+          // offset per fragment (its half's 4 rows + its column): loads / stores take the saddr + voffset form
+          uint32_t voff[NF];
+          bool colok[NF];
 #pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        const uint32_t col = (uint32_t)otile * NCOL + (uint32_t)(wsub * NCOLS) + 128u * f + 4u * (uint32_t)n;
-        const bool colok = col < (uint32_t)L;               // L % 4 == 0: a lane's 4 columns are in or out together
-        const uint32_t ccol = colok ? col : 0u;
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {                     // 4 rows at a time: bounds the operand temporaries
-          f32x4 rv[4], av[4];
-          if (resb) {                                        // (one uniform branch per group: the loads go out together)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rv[j] = *reinterpret_cast<const f32x4*>(resb + (rbase + (uint32_t)(j + 8 * rg)) * LD + ccol);
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int f = 0; f < NF; ++f) {
+            const uint32_t col = (uint32_t)otile * NCOL + (uint32_t)(wsub * NCOLS) + 128u * f + 4u * (uint32_t)n;
+            colok[f] = col < (uint32_t)L;                    // L % 4 == 0: a lane's 4 columns are in or out together
+            voff[f] = 4u * (uint32_t)half * LD + (colok[f] ? col : 0u);
           }
-          if (addb) {
+          const size_t mrow = (size_t)omtile * 32u;
+          // operand ring: the rows of DEPTH - 1 groups are in flight while one is consumed (32 registers of operands)
+          constexpr int DEPTH = (HR && HA) ? 4 : 8;
+          f32x4 rv[HR ? DEPTH : 1], av[HA ? DEPTH : 1];
+          auto load = [&](int g) {                           // group g = (fragment, accumulator register r)
+            const int f = g / 16, r = g % 16;
+            const size_t rowb = (mrow + (size_t)((r & 3) + 8 * (r >> 2))) * LD;
+            if constexpr (HR) rv[g % DEPTH] = *reinterpret_cast<const f32x4*>(resb + rowb + voff[f]);
+            if constexpr (HA) av[g % DEPTH] = *reinterpret_cast<const f32x4*>(addb + rowb + voff[f]);
+          };
+          if constexpr (HR || HA) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) av[j] = *reinterpret_cast<const f32x4*>(addb + (rbase + (uint32_t)(j + 8 * rg)) * LD + ccol);
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) av[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < DEPTH - 1; ++g) load(g);
           }
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int r = 4 * rg + j;
-            const float y0 = acc[0][f][r], y1 = acc[1][f][r], y2 = acc[2][f][r], y3 = acc[3][f][r], y4 = acc[4][f][r],
-                        y5 = acc[5][f][r];
-            const float s1 = y1 + y2, d1 = y1 - y2, s2 = y3 + y4, d2 = y3 - y4;
-            f32x4 o;
-            o[0] = (y0 + s1) + s2;
-            o[1] = __builtin_fmaf(2.f, d2, d1);
-            o[2] = __builtin_fmaf(4.f, s2, s1);
-            o[3] = __builtin_fmaf(8.f, d2, d1) + y5;
-            o = ((o + rv[j]) + av[j]) * scale;
-            if (colok) *reinterpret_cast<f32x4*>(outb + (rbase + (uint32_t)(j + 8 * rg)) * LD + col) = o;
+          for (int g = 0; g < NGRP; ++g) {
+            if constexpr (HR || HA) {
+              if (g + DEPTH - 1 < NGRP) load(g + DEPTH - 1);
+            }
+            const int f = g / 16, r = g % 16;
+            f32x4 o = at4(f, r);
+            if constexpr (HR) o += rv[g % DEPTH];
+            if constexpr (HA) o += av[g % DEPTH];
+            o *= scale;
+            if (colok[f] && (OVW_EXP != 4 || o[0] == 12345.f))
+              *reinterpret_cast<f32x4*>(outb + (mrow + (size_t)((r & 3) + 8 * (r >> 2))) * LD + voff[f]) = o;
           }
-        }
-      }
-          } else {
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        if (resb && addb) run(T{}, T{});
+        else if (resb) run(T{}, F{});
+        else if (addb) run(F{}, T{});
+        else run(F{}, F{});
+      } else {
         float* ost = ostage + wave * (8 * OST);
         const uint32_t c0 = (uint32_t)otile * NCOL + (uint32_t)(wsub * NCOLS);   // first column of this wave's sub-block (multiple of 4)
-        // this lane's tiles: fragment f, tile 32 f + n -> columns rcl + DIL (4 jt + i) of the block, or none
+        // this lane's tiles: fragment f, tile 32 f + n -> columns rc + DIL (4 jt + i) of the sub-block, or none
         int cbase[NF];
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
@@ -485,53 +510,60 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
         const uint32_t col = c0 + 4u * (uint32_t)lane;         // the 16 bytes this lane stores of each row
         const bool colok = 4 * lane < NCOLS && col < (uint32_t)L;
         const uint32_t ccol = colok ? col : 0u;
+        auto run = [&](auto has_res, auto has_add) {
+          constexpr bool HR = decltype(has_res)::value, HA = decltype(has_add)::value;
+          // group = 2 output rows of the 8-row stage; 16 groups per item: g = 4 rg + 2 hh + (pair of the half)
+          constexpr int DEPTH = (HR && HA) ? 2 : 3;
+          f32x4 rv[HR ? DEPTH : 1][2], av[HA ? DEPTH : 1][2];
+          auto row0 = [&](int g) { return (uint32_t)omtile * 32u + 8u * (g / 4) + 2u * (g % 4); };   // rows 8 rg + 2 q, + 1
+          auto load = [&](int g) {
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
+            for (int j = 0; j < 2; ++j) {
+              if constexpr (HR) rv[g % DEPTH][j] = *reinterpret_cast<const f32x4*>(resb + (size_t)(row0(g) + j) * LD + ccol);
+              if constexpr (HA) av[g % DEPTH][j] = *reinterpret_cast<const f32x4*>(addb + (size_t)(row0(g) + j) * LD + ccol);
+            }
+          };
+          if constexpr (HR || HA) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int r = 4 * rg + j;
+            for (int g = 0; g < DEPTH - 1; ++g) load(g);
+          }
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-              const float y0 = acc[0][f][r], y1 = acc[1][f][r], y2 = acc[2][f][r], y3 = acc[3][f][r], y4 = acc[4][f][r],
-                          y5 = acc[5][f][r];
-              const float s1 = y1 + y2, d1 = y1 - y2, s2 = y3 + y4, d2 = y3 - y4;
-              if (cbase[f] >= 0) {
-                float* o = ost + (4 * half + j) * OST + cbase[f];
-                o[0] = (y0 + s1) + s2;
-                o[DIL] = __builtin_fmaf(2.f, d2, d1);
-                o[2 * DIL] = __builtin_fmaf(4.f, s2, s1);
-                o[3 * DIL] = __builtin_fmaf(8.f, d2, d1) + y5;
+          for (int rg = 0; rg < 4; ++rg) {
+            // the wave's rows 8 rg .. 8 rg + 7: lane (half, n) holds rows 4 half + j; (same wave writes and then reads the
+            // stage: LDS operations of a wave complete in order)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int f = 0; f < NF; ++f) {
+                const f32x4 o = at4(f, 4 * rg + j);
+                if (cbase[f] >= 0) {
+                  float* od = ost + (4 * half + j) * OST + cbase[f];
+                  od[0] = o[0]; od[DIL] = o[1]; od[2 * DIL] = o[2]; od[3 * DIL] = o[3];
+                }
+              }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                      // stage rows 2 q, 2 q + 1 = output rows 8 rg + 2 q, + 1
+              const int g = 4 * rg + q;
+              if constexpr (HR || HA) {
+                if (g + DEPTH - 1 < 16) load(g + DEPTH - 1);
+              }
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                f32x4 o = *reinterpret_cast<const f32x4*>(ost + (2 * q + j) * OST + 4 * lane);
+                if constexpr (HR) o += rv[g % DEPTH][j];
+                if constexpr (HA) o += av[g % DEPTH][j];
+                o *= scale;
+                if (colok) *reinterpret_cast<f32x4*>(outb + (size_t)(row0(g) + j) * LD + col) = o;
               }
             }
           }
-          // (same wave wrote and now reads: LDS operations of a wave complete in order)
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {                     // rows 4 hh + j of the stage = output rows 4 hh + 8 rg + j
-            f32x4 rv[4], av[4], ov[4];
-            const uint32_t r0 = (uint32_t)omtile * 32u + 4u * hh + 8u * rg;
-            if (resb) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) rv[j] = *reinterpret_cast<const f32x4*>(resb + (r0 + j) * LD + ccol);
-            } else {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) rv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            if (addb) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) av[j] = *reinterpret_cast<const f32x4*>(addb + (r0 + j) * LD + ccol);
-            } else {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) av[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ov[j] = *reinterpret_cast<const f32x4*>(ost + (4 * hh + j) * OST + 4 * (lane & 63));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const f32x4 o = ((ov[j] + rv[j]) + av[j]) * scale;
-              if (colok) *reinterpret_cast<f32x4*>(outb + (r0 + j) * LD + col) = o;
-            }
-          }
-        }
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        if (resb && addb) run(T{}, T{});
+        else if (resb) run(T{}, F{});
+        else if (addb) run(F{}, T{});
+        else run(F{}, F{});
       }
     }
     OVW_MARK(2)
@@ -575,8 +607,10 @@ int wino_dispatch_k11(const ov_conv1d_wino_params* p, int nf, hipStream_t stream
 #define OVW_DISPATCH_MW(KK, MWV)                                                                                        \
   {                                                                                                                      \
     constexpr int CI = ovkw::wino_ci(KK, MWV);                                                                           \
-    if (p->dil == 1 && nf == 1 && MWV == 4)                                                                              \
-      return dbg ? wino_launch<KK, 1, CI, 1, 4, true>(p, st) : wino_launch<KK, 1, CI, 1, 4, false>(p, st);                \
+    if constexpr (MWV == 4) {                                                                                            \
+      if (p->dil == 1 && nf == 1)                                                                                        \
+        return dbg ? wino_launch<KK, 1, CI, 1, 4, true>(p, st) : wino_launch<KK, 1, CI, 1, 4, false>(p, st);              \
+    }                                                                                                                    \
     if (p->dil == 1) return dbg ? wino_launch<KK, 1, CI, 2, MWV, true>(p, st) : wino_launch<KK, 1, CI, 2, MWV, false>(p, st); \
     if (p->dil == 3) return dbg ? wino_launch<KK, 3, CI, 2, MWV, true>(p, st) : wino_launch<KK, 3, CI, 2, MWV, false>(p, st); \
     if (p->dil == 5) return dbg ? wino_launch<KK, 5, CI, 2, MWV, true>(p, st) : wino_launch<KK, 5, CI, 2, MWV, false>(p, st); \

@@ -9,7 +9,7 @@ n=${1:?variant}
 make -j8 >/dev/null
 mkdir -p build_wexp$n
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -Wno-unused-result -Wno-pass-failed \
-  -DOVW_EXP=$n -c conv1d_wino.hip -o build_wexp$n/conv1d_wino.o
-objs=$(ls build/*.o | grep -v conv1d_wino)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs build_wexp$n/conv1d_wino.o -o ../libopenvoice_amd_wexp$n.so
+  -DOVW_EXP=$n -c conv1d_wino_k11.hip -o build_wexp$n/conv1d_wino_k11.o
+objs=$(ls build/*.o | grep -v conv1d_wino_k11)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs build_wexp$n/conv1d_wino_k11.o -o ../libopenvoice_amd_wexp$n.so
 echo ../libopenvoice_amd_wexp$n.so
