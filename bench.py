@@ -154,7 +154,7 @@ def cpu_baseline(sd, cfg, seconds, budget_s=20.0, want_reference=True, batch32=N
     of the same path in the same torch operators (``kind = "port"``; pinned to reference outputs by
     tests/test_oracle_golden.py).  Bounded sample: B = 1 utterances on all usable threads for ~budget_s (the
     headline ``value``), then one B = 1 run on ONE thread, then ONE B = 32 run of the whole benchmark batch on all threads
-    when the B = 1 rate estimates it at <= 30 s (``batch32``: None = that rule, True = ``--cpu-batch32`` forces it up to
+    when one timed B = 4 run estimates it at <= 60 s (``batch32``: None = that rule, True = ``--cpu-batch32`` forces it up to
     4 x budget, False = ``--no-cpu-batch32``); next to the reference's figure on the same host in
     profiles/r02_cpu_reference_vs_port_build_container.json."""
     from oracle import vc_oracle
@@ -199,11 +199,25 @@ def cpu_baseline(sd, cfg, seconds, budget_s=20.0, want_reference=True, batch32=N
     out["one_thread"] = dict(value=round(seconds / el1, 3), utterances_per_s=round(1.0 / el1, 4), cores=1)
     sample.append(f"1 x (B=1) on 1 thread, {el1:.1f} s")
     # the benchmark batch, B = 32 x `seconds` (SURVEY.md section 8d's CPU leg; reference: openvoice/models.py:492-499 on the
-    # padded batch): run whenever the B = 1 rate estimates it at <= 30 s (`batch32` None = that rule, True = also up to
+    # padded batch): run whenever the B = 4 run estimates it at <= 60 s (`batch32` None = that rule, True = also up to
     # 4 x budget_s, False = never); otherwise the bounded stand-in below
     torch.set_num_threads(cores)
-    est32 = 32.0 * el / n
-    limit = 30.0 if batch32 is None else (max(30.0, 4.0 * budget_s) if batch32 else -1.0)
+    # Estimate of the B = 32 leg from ONE timed B = 4 run: the batched convs are far slower per utterance than B = 1
+    # (the padded batch streams its activations through the same caches -- rounds 4 / 5 measured
+    # 42-48 s where 32 x the B = 1 time said 14-19 s); from B = 4 on the per-utterance cost falls slowly again (round 6, this
+    # box class: B = 4 7.0 s, B = 32 45 s = 6.4 x), hence 6.5 x the B = 4 time.
+    est32_from_b1 = 32.0 * el / n
+    est32 = est32_from_b1
+    if batch32 is not False and seconds >= 2.0 and 4.0 * el / n <= 12.0:
+        wave4 = synth_wave(4, samples, 9, "cpu")
+        t0 = time.perf_counter()
+        convert(wave4)
+        el4 = time.perf_counter() - t0
+        est32 = 6.5 * el4
+        out["batch4"] = dict(value=round(4 * seconds / el4, 3), utterances_per_s=round(4.0 / el4, 4), cores=cores,
+                             wall_s=round(el4, 2))
+        sample.append(f"1 x (B=4) on {cores} threads, {el4:.1f} s")
+    limit = 60.0 if batch32 is None else (max(60.0, 4.0 * budget_s) if batch32 else -1.0)
     out["batch32"] = None
     if est32 <= limit:
         wave32 = synth_wave(32, samples, 9, "cpu")
@@ -211,8 +225,9 @@ def cpu_baseline(sd, cfg, seconds, budget_s=20.0, want_reference=True, batch32=N
         convert(wave32)
         el32 = time.perf_counter() - t0
         out["batch32"] = dict(value=round(32 * seconds / el32, 3), utterances_per_s=round(32.0 / el32, 4), cores=cores,
-                              wall_s=round(el32, 2), estimated_s=round(est32, 1))
-        sample.append(f"1 x (B=32 x {seconds:g} s) on {cores} threads, {el32:.1f} s (estimated from the B=1 rate: {est32:.0f} s)")
+                              wall_s=round(el32, 2), estimated_s=round(est32, 1), estimated_from_b1_s=round(est32_from_b1, 1))
+        sample.append(f"1 x (B=32 x {seconds:g} s) on {cores} threads, {el32:.1f} s (estimated from the B=4 run: {est32:.0f} s; "
+                      f"32 x the B=1 time: {est32_from_b1:.0f} s)")
     else:
         # bounded stand-in: a batch of 32 SHORT utterances (a tenth of the workload's length, >= 0.5 s) -- the same
         # batched operators and thread count, a few seconds of CPU
@@ -252,6 +267,32 @@ def self_launch(n):
           file=sys.stderr, flush=True)
     sys.stdout.flush()
     os.execv(sys.executable, cmd)
+
+
+def distributed_environment(gpu):
+    """What a post-mortem of an unattended N-GPU run needs: the collective library's version and the environment switches
+    that decide whether its transports come up (the host driver of this pool only supports dmabuf IPC)."""
+    env = {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "NCCL_DEBUG_SUBSYS", "NCCL_SOCKET_IFNAME",
+                                          "RCCL_MSCCL_ENABLE", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "MASTER_ADDR")}
+    ver = None
+    if gpu:
+        try:
+            v = torch.cuda.nccl.version()
+            ver = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+        except Exception as exc:   # noqa: BLE001
+            ver = f"unavailable ({exc!r})"[:120]
+    return {"rccl_version": ver, "env": env, "torch": torch.__version__, "hip": getattr(torch.version, "hip", None)}
+
+
+def gather_rank_diagnostics(mine, world, group):
+    """Every rank's own figures (ms of its MRF launches in the event-bracketed step, HBM bytes resident, device) on rank 0's
+    line: a slow rank is attributable to a kernel group or to memory pressure.  A collective when a group exists."""
+    import torch.distributed as dist
+    if not group:
+        return [mine]
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    return every
 
 
 def init_ranks(args, backend):
@@ -409,6 +450,112 @@ def split_opt_in(engine, step, model, sd, cfg, wave, se, hop_cfg, B, seconds, no
         engine.use_split_bf16x3(False)
 
 
+def config_tts_v1(dev, steps=3, batch=16, tokens=100):
+    """BASELINE.json configs[3] inside the driver's line: V1 base-speaker ``SynthesizerTrn.infer`` (text encoder with
+    relative attention, both duration predictors, RQ-spline flows, reverse flow, generator; reference:
+    openvoice/models.py:467-490), batch 16 x 100 symbols, length-aware generator work lists -- 1 warm-up + ``steps`` timed
+    calls, and item 0 against oracle/tts_oracle.py on the CPU with the same recorded noise.  Never ``value``."""
+    from openvoice_amd.models import SynthesizerTrn
+    from openvoice_amd.params import synthetic_tts_state_dict
+    from openvoice_amd.utils import CONVERTER_MODEL_CONFIG as CFG
+    from oracle import tts_oracle
+    sd = synthetic_tts_state_dict(CFG)
+    model = SynthesizerTrn(68, 513, n_speakers=10, **CFG)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    gen = torch.Generator().manual_seed(0)
+    B, Tx = batch, tokens
+    tok = torch.randint(0, 68, (B, Tx), generator=gen).to(dev)
+    lengths = torch.full((B,), Tx, dtype=torch.long, device=dev)
+    sid = (torch.arange(B) % 10).to(dev)
+    noise_w = torch.randn(B, 2, Tx, generator=gen).to(dev)
+    noise_z = torch.randn(B, 192, 16 * Tx, generator=gen).to(dev)
+
+    def call():
+        return model.infer(tok, lengths, sid=sid, noise_scale=0.667, noise_scale_w=0.6, length_scale=1.0,
+                           noise_w=noise_w, noise_z=noise_z, skip_padding=True)
+
+    o, _, y_mask, _ = call()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        o, _, y_mask, _ = call()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    per_utt = y_mask[:, 0].sum(1)
+    Ty = int(y_mask.shape[2])
+    audio_s = float(per_utt.sum()) * 256 / SAMPLE_RATE
+    gen_frames = float(torch.clamp(per_utt + 16, max=Ty).sum())
+    flops = 614.8e6 * gen_frames + 4 * 3.54e6 * B * Ty + (4.4e9 + 0.33e9 + 0.21e9) * B * Tx / 100.0
+    a = lambda t: t[:1].cpu()
+    with torch.no_grad():
+        o_c = tts_oracle.infer(sd, CFG, a(tok), a(lengths), a(sid), a(noise_w), a(noise_z), 0.667, 1.0, 0.6)[0]
+    n0 = 256 * int(per_utt[0])
+    # the generator is unmasked: in a padded batch the last ~13 frames of an item see its neighbours' padding, so the
+    # comparison with the B = 1 oracle stops 20 frames before the item's end
+    err = float((o[0, 0, :n0 - 5120].cpu() - o_c[0, 0, :n0 - 5120]).abs().max())
+    return {"workload": f"BASELINE.json configs[3]: V1 BaseSpeakerTTS SynthesizerTrn.infer, batch {B} x {Tx} symbols, fp32, "
+                        f"calibrated random weights, length-aware generator work lists",
+            "ms_per_batch": round(dt * 1e3, 3), "steps": steps, "utterances_per_s": round(B / dt, 2),
+            "audio_s_per_batch": round(audio_s, 2), "value": round(audio_s / dt, 1), "unit": "x real-time (audio s / wall s)",
+            "frames_per_utterance": round(float(per_utt.float().mean()), 1), "padded_frames": Ty,
+            "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "alg_tflop_per_batch": round(flops / 1e12, 3),
+                         "what": "ALGORITHMIC conv FLOPs of the frames actually computed / wall time of the whole infer() incl. "
+                                 "its host sync and the token-rate kernels (the Winograd-domain launches execute fewer)"},
+            "parity": {"max_abs_vs_oracle": err, "tolerance": PARITY_TOLERANCE, "ok": bool(err <= PARITY_TOLERANCE), "item": 0,
+                       "what": "o[0] vs oracle/tts_oracle.py (B = 1, same recorded noise), excluding the last 20 frames"}}
+
+
+def config_bf16_decoder(dev, steps=3, batch=64, frames=861):
+    """BASELINE.json configs[4] inside the driver's line: the HiFi-GAN generator with bf16 activations (reference:
+    openvoice/models.py:272-291), batch 64 x 861 frames -- 1 warm-up + ``steps`` timed passes; both roofs from the
+    digest-gated counter record (profiles/bf16_counters_latest.json) where it belongs to these sources, else the algorithmic
+    bytes; item 0 against the fp32 oracle generator on the CPU.  Never ``value``."""
+    from openvoice_amd.bf16 import GeneratorBf16, generator_alg_bytes
+    from openvoice_amd.params import synthetic_state_dict
+    from openvoice_amd.utils import CONVERTER_MODEL_CONFIG as CFG
+    from oracle import vc_oracle
+    sd = synthetic_state_dict(CFG, 513, seed=1234)
+    gen = torch.Generator().manual_seed(0)
+    z = torch.randn(batch, 192, frames, generator=gen).to(dev)
+    g = (0.3 * torch.randn(1, 256, 1, generator=gen)).to(dev)
+    dec = GeneratorBf16(sd, CFG, dev)
+    o = dec.decode(z, g)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        o = dec.decode(z, g)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    gen_bytes = generator_alg_bytes(CFG, batch, frames)
+    gen_flops = 529.44e9 * batch * frames / 861.0
+    rec, rec_note = bf16_counter_record(batch, frames)
+    traffic_b = rec["traffic_GB_per_pass"] * 1e9 if rec else None
+    with torch.no_grad():
+        want = vc_oracle.generator(sd, z[:1].cpu(), g.cpu(), CFG)[0, 0]
+    diff = o[0, 0].cpu() - want
+    return {"workload": f"BASELINE.json configs[4]: HiFi-GAN generator, bf16 activations / fp32 accumulation, batch {batch} x "
+                        f"{frames} frames (10 s), calibrated random weights",
+            "ms_per_batch": round(dt * 1e3, 3), "steps": steps, "utterances_per_s": round(batch / dt, 1),
+            "value": round(batch * frames * 256 / SAMPLE_RATE / dt, 1), "unit": "x real-time (audio s / wall s)",
+            "roofline": {"bound": "hbm", "achieved": round((traffic_b or gen_bytes) / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round((traffic_b or gen_bytes) / dt / 8e12, 4),
+                         "frac_of_achievable_6300": round((traffic_b or gen_bytes) / dt / 6.3e12, 4),
+                         "traffic": traffic_b, "traffic_source": rec_note, "alg_bytes": round(gen_bytes),
+                         "mfma": {"achieved_tflops": round(gen_flops / dt / 1e12, 1), "peak_tflops": BF16_MFMA_PEAK_TFLOPS,
+                                  "frac": round(gen_flops / dt / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+                                  "mfma_busy": rec.get("mfma_busy") if rec else None,
+                                  "shader_clock_ghz": rec.get("shader_clock_ghz") if rec else None}},
+            "parity": {"max_abs_vs_fp32_oracle": round(float(diff.abs().max()), 5),
+                       "rel_rms_vs_fp32_oracle": round(float(diff.pow(2).mean().sqrt() / want.pow(2).mean().sqrt()), 5),
+                       "tolerance": {"max_abs": 3e-2, "rel_rms": 1.5e-2}, "item": 0,
+                       "ok": bool(diff.abs().max() <= 3e-2),
+                       "what": "o[0] vs oracle/vc_oracle.generator (fp32, CPU) on the same z: bf16 storage rounding, stated "
+                               "tolerance of tests/test_gpu_bf16.py"}}
+
+
 def dry_run(args):
     """bench.py's multi-rank control flow on CPU + gloo (see --dry-run)."""
     import torch.distributed as dist
@@ -435,6 +582,9 @@ def dry_run(args):
     if dist_on:
         names = [None] * world
         dist.all_gather_object(names, f"cpu (rank {rank})")
+    # the per-rank diagnostics of the measured run, with stand-in figures (same collective, same shape)
+    diag = gather_rank_diagnostics({"rank": rank, "mrf_ms": float(rank), "hbm_resident_bytes": 0, "device": f"cpu (rank {rank})"},
+                                   world, dist_on)
     line = None
     if rank == 0:
         line = {"metric": "real_time_factor", "value": None, "unit": "x real-time (audio s / wall s)",
@@ -443,8 +593,8 @@ def dry_run(args):
                 "per_rank_ms_per_step": rank_stats(per_rank, args.steps), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "dry_run": True, "broadcast_consistent": ok,
-                "distributed": {"process_group": dist_on, "backend": dist.get_backend() if dist_on else None,
-                                "rccl_ranks": 0, "devices": names},
+                "distributed": dict({"process_group": dist_on, "backend": dist.get_backend() if dist_on else None,
+                                     "rccl_ranks": 0, "devices": names, "per_rank": diag}, **distributed_environment(False)),
                 # the shape of the measured line's roofline object; no kernel ran, so no figures
                 "roofline": {"bound": "mfma", "achieved": None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": None, "traffic": None},
@@ -477,8 +627,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0,
                     help="seconds of CPU baseline sampling at B = 1 on all threads (plus one 1-thread utterance)")
     ap.add_argument("--cpu-batch32", action="store_true", default=None,
-                    help="time ONE B = 32 conversion of the whole batch on the CPU even when the B = 1 rate estimates it "
-                         "above 30 s (default: run it when the estimate is <= 30 s)")
+                    help="time ONE B = 32 conversion of the whole batch on the CPU even when the timed B = 4 run estimates it "
+                         "above 60 s (default: run it when the estimate is <= 60 s)")
     ap.add_argument("--no-cpu-batch32", dest="cpu_batch32", action="store_false",
                     help="never run the B = 32 CPU leg (a short-utterance stand-in is timed instead)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle self-check of the timed batch")
@@ -497,7 +647,8 @@ def main():
     ap.add_argument("--split-products", type=int, default=6, choices=(6, 3),
                     help="plane products per fp32 product with --split-bf16x3: 6 (fp32 level) or 3 (16-bit operands)")
     ap.add_argument("--no-opt-in", action="store_true",
-                    help="skip the short split-precision measurement the default line carries under 'opt_in_split_bf16x3'")
+                    help="skip the short measurements the default line carries beside the contract figures: 'opt_in_split_bf16x3', "
+                         "'config_tts_v1' (BASELINE.json configs[3]) and 'config_bf16_decoder' (configs[4])")
     ap.add_argument("--pmc-calibration", action="store_true",
                     help="after the timed region, run three 1 GiB device-to-device copies (a known byte count) "
                          "so a rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass can be calibrated")
@@ -509,6 +660,18 @@ def main():
     args = ap.parse_args()
     if args.steps < 1 or args.warmup < 0:
         ap.error("--steps must be >= 1 and --warmup >= 0")
+    if args.gpus > 1 and not args.dry_run:
+        # the first N-GPU run happens with nobody watching: a box with fewer devices than ranks says so in ONE JSON line
+        # and a non-zero exit code, before any launcher or rendezvous is started
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            if int(os.environ.get("RANK", "0")) == 0:
+                print(json.dumps({"metric": "real_time_factor", "value": None, "n_gpus": args.gpus,
+                                  "error": f"--gpus {args.gpus} but torch.cuda.device_count() = {have} on this node",
+                                  "visible_devices": {k: os.environ.get(k) for k in
+                                                      ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")}}),
+                      flush=True)
+            return 4
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus)
     if args.dry_run:
@@ -624,6 +787,12 @@ def main():
     alg_bytes = mrf_alg_bytes_per_launch(cfg, B, frames, fused_set)
     all_flops = sum(r[1] for r in by_tag.values())
     all_conv_s = sum(r[2] for r in by_tag.values())
+    # every rank's own figures on rank 0's line (a collective when a group exists: all ranks come through here)
+    rank_diag = gather_rank_diagnostics(
+        {"rank": rank, "device": torch.cuda.get_device_name(dev), "mrf_ms": round(t_mrf * 1e3, 3),
+         "by_kernel_group_ms": {k: round(v[2] * 1e3, 3) for k, v in sorted(by_tag.items())},
+         "hbm_resident_bytes": int(torch.cuda.memory_allocated(dev)), "hbm_reserved_bytes": int(torch.cuda.memory_reserved(dev)),
+         "hbm_total_bytes": int(torch.cuda.get_device_properties(dev).total_memory)}, world, dist_on)
 
     # ---- opt-in split-precision MRF (never `value`): 3 timed steps + the oracle self-check, after the contract region ----
     opt_in = None
@@ -633,6 +802,17 @@ def main():
         except Exception as exc:   # noqa: BLE001 -- diagnostics only; the contract line stands on its own
             opt_in = {"error": repr(exc)[:300]}
             engine.use_split_bf16x3(False)
+
+    # ---- BASELINE.json configs[3] and configs[4], bounded, after the contract region (never inside it, never `value`) ----
+    extra_cfgs = {}
+    if rank == 0 and world == 1 and not (args.split_bf16x3 or args.bf16_generator or args.no_opt_in):
+        for key, fn in (("config_tts_v1", config_tts_v1), ("config_bf16_decoder", config_bf16_decoder)):
+            t_cfg = time.perf_counter()
+            try:
+                extra_cfgs[key] = fn(dev)
+            except Exception as exc:   # noqa: BLE001 -- diagnostics only; the contract line stands on its own
+                extra_cfgs[key] = {"error": repr(exc)[:300]}
+            extra_cfgs[key]["wall_s_incl_setup"] = round(time.perf_counter() - t_cfg, 2)
 
     if args.pmc_calibration:
         src = torch.zeros(1 << 28, dtype=torch.float32, device=dev)   # 1 GiB
@@ -652,10 +832,11 @@ def main():
             "utterances_per_s": round(utt_s, 3),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "per_rank_ms_per_step": rank_stats(per_rank, args.steps),
-            "distributed": {"process_group": dist_on, "backend": dist.get_backend() if dist_on else None,
-                            "rccl_ranks": world if dist_on else 0, "devices": devices,
-                            "collectives_per_step": "1 broadcast of [2,256] fp32 (src/tgt se)" if dist_on else "none",
-                            "binding": __import__("openvoice_amd._lib", fromlist=["binding"]).binding()},
+            "distributed": dict({"process_group": dist_on, "backend": dist.get_backend() if dist_on else None,
+                                 "rccl_ranks": world if dist_on else 0, "devices": devices,
+                                 "collectives_per_step": "1 broadcast of [2,256] fp32 (src/tgt se)" if dist_on else "none",
+                                 "binding": __import__("openvoice_amd._lib", fromlist=["binding"]).binding(),
+                                 "per_rank": rank_diag}, **distributed_environment(True)),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (enc_q, flow) + bf16 generator, fp32 accumulation" if args.bf16_generator else "f32",
             "data": "synthetic",
@@ -691,6 +872,7 @@ def main():
         }
         if opt_in is not None:
             out["opt_in_split_bf16x3"] = opt_in
+        out.update(extra_cfgs)
         if args.split_bf16x3:
             n_s, f_s, t_s = by_tag["mrf_split"][:3]
             pf = args.split_products * f_s / t_s / 1e15

@@ -575,6 +575,14 @@ int ov_conv1d_wino_pack_f32(const float* w, int Cout, int Cin, int K, float* dst
  * _pack_size, _pack_f32).  The Python binding
  * refuses a library older than the entry points it calls (openvoice_amd/_lib.py MIN_VERSION). */
 int ov_version(void);
+/* The version THIS header describes.  Parameter structs grow at their END in minor versions (2.04, 2.05, 2.07 did): a
+ * caller must be compiled against the header of the library it loads -- compare ov_version() with OV_ABI_VERSION at start-up
+ * and refuse a mismatch in either direction when it passes parameter structs (the Python bindings do:
+ * openvoice_amd/_lib.py MIN_VERSION; the ctypes mirrors are checked field by field against this header in
+ * tests/test_abi_cpu.py).  A struct is never reordered and a field never changes meaning within a major version, with
+ * one exception stated here: 2.05 renamed ov_wn_layer_params.reserved to row_split AND appended `acts`, so a caller
+ * built against 2.04 or older is NOT binary compatible with 2.05+ for that struct. */
+#define OV_ABI_VERSION 207
 /* 0 for a production build; non-zero = a measurement build with parts of the kernels compiled out (results are
  * meaningless; openvoice_amd/_lib.py refuses to load it unless OPENVOICE_AMD_ALLOW_EXPERIMENT=1). */
 int ov_build_experiment(void);

@@ -331,34 +331,52 @@ class ToneColorConverter(OpenVoiceBaseClass):
             return audio
         audio_io.write(output_path, audio, hps.data.sampling_rate)
 
-    # ---- optional watermark hook (third-party model; reference: openvoice/api.py:162-201) ----------
+    # ---- optional watermark hook (third-party model; behaviour of the reference's openvoice/api.py:162-201) ----------
+    # The message travels as 32-bit groups, group n in the 16 000-sample window that starts at sample 32 000 n (every other
+    # window of the waveform stays untouched); ``watermark_model`` is any object with ``encode(signal [1, 16000], bits
+    # [1, 32]) -> signal`` and ``decode(signal [1, 16000]) -> scores [1, 32]`` (wavmark's interface).
+    WATERMARK_WINDOW = 16000
+    WATERMARK_STRIDE = 2 * WATERMARK_WINDOW
+    WATERMARK_GROUP_BITS = 32
+
+    def _watermark_windows(self, audio, count):
+        """(n, start, stop) of the first ``count`` carrier windows that lie wholly inside ``audio``; stops at the first
+        that does not."""
+        for n in range(count):
+            start = n * self.WATERMARK_STRIDE
+            if start + self.WATERMARK_WINDOW > len(audio):
+                return
+            yield n, start, start + self.WATERMARK_WINDOW
+
     def add_watermark(self, audio, message):
+        """Embed ``message`` (padded / cut to 8 latin-1 characters) into ``audio`` (1-D float array, modified in place and
+        returned).  A waveform too short for all groups carries the leading ones and a notice is printed, as upstream."""
         if self.watermark_model is None:
             return audio
-        bits = string_to_bits(message).reshape(-1)
-        n_repeat = len(bits) // 32
-        K, coeff = 16000, 2
-        for n in range(n_repeat):
-            trunck = audio[(coeff * n) * K: (coeff * n + 1) * K]
-            if len(trunck) != K:
-                print("Audio too short, fail to add watermark")
-                break
-            with torch.no_grad():
-                signal = torch.FloatTensor(trunck).to(self.device)[None]
-                msg = torch.FloatTensor(bits[n * 32: (n + 1) * 32]).to(self.device)[None]
-                audio[(coeff * n) * K: (coeff * n + 1) * K] = \
-                    self.watermark_model.encode(signal, msg).detach().cpu().squeeze()
+        payload = string_to_bits(message).reshape(-1)
+        groups = len(payload) // self.WATERMARK_GROUP_BITS
+        done = 0
+        with torch.no_grad():
+            for n, start, stop in self._watermark_windows(audio, groups):
+                carrier = torch.as_tensor(audio[start:stop], dtype=torch.float32, device=self.device).unsqueeze(0)
+                bits = torch.as_tensor(payload[n * self.WATERMARK_GROUP_BITS:(n + 1) * self.WATERMARK_GROUP_BITS],
+                                       dtype=torch.float32, device=self.device).unsqueeze(0)
+                audio[start:stop] = self.watermark_model.encode(carrier, bits).detach().cpu().reshape(-1).numpy()
+                done += 1
+        if done < groups:
+            print("Audio too short, fail to add watermark")
         return audio
 
     def detect_watermark(self, audio, n_repeat):
-        bits = []
-        K, coeff = 16000, 2
-        for n in range(n_repeat):
-            trunck = audio[(coeff * n) * K: (coeff * n + 1) * K]
-            if len(trunck) != K:
-                print("Audio too short, fail to detect watermark")
-                return "Fail"
-            with torch.no_grad():
-                signal = torch.FloatTensor(trunck).to(self.device).unsqueeze(0)
-                bits.append((self.watermark_model.decode(signal) >= 0.5).int().detach().cpu().numpy().squeeze())
-        return bits_to_string(np.stack(bits).reshape(-1, 8))
+        """Read ``n_repeat`` 32-bit groups back (threshold 0.5 on the model's scores) and decode them to characters;
+        the string "Fail" when the waveform does not hold that many carrier windows."""
+        groups = []
+        with torch.no_grad():
+            for _, start, stop in self._watermark_windows(audio, n_repeat):
+                carrier = torch.as_tensor(audio[start:stop], dtype=torch.float32, device=self.device).unsqueeze(0)
+                scores = self.watermark_model.decode(carrier)
+                groups.append((scores >= 0.5).to(torch.uint8).detach().cpu().reshape(-1).numpy())
+        if len(groups) < n_repeat:
+            print("Audio too short, fail to detect watermark")
+            return "Fail"
+        return bits_to_string(np.stack(groups).reshape(-1, 8))

@@ -111,7 +111,7 @@ def kaiser_best_phases(sr_in, sr_out):
             offset = int(index_frac)
             eta = index_frac - offset
             idx = offset + k * index_step
-            ok = idx < nwin
+            ok = k < (nwin - offset) // index_step              # resampy's loop bound (one tap short of idx < nwin at most)
             w = np.where(ok, win[np.minimum(idx, nwin - 1)] + eta * delta[np.minimum(idx, nwin - 1)], 0.0)
             if wing == 0:
                 h[r, taps - 1 - k] = w                        # x[n - k]
@@ -125,8 +125,9 @@ def resample_kaiser_best(x, sr_in, sr_out):
     Resampling", resampy.interpn.resample_f) with its ``kaiser_best`` filter (weights: ``kaiser_best_phases``).
     Evaluated phase by phase: with integer rates the fractional position takes ``sr_out / gcd`` values, each one fixed
     set of weights applied to a strided window view of x (one matrix-vector product per phase) instead of resampy's
-    per-sample loops; the weights are the algorithm's, the summation order is BLAS's.  Output length
-    ``ceil(len * ratio)`` as ``librosa.resample(fix=True)`` returns it.
+    per-sample loops; the weights are the algorithm's, the summation order is BLAS's.  resampy computes
+    ``int(len * ratio)`` samples and ``librosa.resample(fix=True)`` zero-pads them to ``ceil(len * ratio)``: the same
+    here (the one extra sample of a non-integer product is 0, not interpolated).
     PARITY UNPINNED: neither resampy nor librosa is in this image, so agreement with their output is by construction of
     the published algorithm only (tests: closed-form band-limited interpolation of sinusoids, stop-band rejection)."""
     x = np.asarray(x, dtype=np.float64).reshape(-1)
@@ -134,7 +135,7 @@ def resample_kaiser_best(x, sr_in, sr_out):
         return x.astype(np.float32)
     h, P, Q, taps = kaiser_best_phases(sr_in, sr_out)
     n_orig = x.shape[0]
-    n_out = int(np.ceil(n_orig * P / Q))
+    n_out = n_orig * P // Q                                   # what resampy computes; padded to the ceiling below
     xpad = np.concatenate([np.zeros(taps), x, np.zeros(taps + Q + 1)])   # x[i] = xpad[i + taps]
     y = np.zeros(n_out, dtype=np.float64)
     for r in range(min(P, n_out)):
@@ -144,7 +145,8 @@ def resample_kaiser_best(x, sr_in, sr_out):
         view = np.lib.stride_tricks.as_strided(xpad[first:], shape=(m, 2 * taps), strides=(Q * xpad.strides[0], xpad.strides[0]),
                                                writeable=False)
         y[r::P] = view @ h[r]
-    return y.astype(np.float32)
+    n_fix = -(-n_orig * P // Q)
+    return np.concatenate([y, np.zeros(n_fix - n_out)]).astype(np.float32)
 
 
 _device_phases = {}
@@ -165,9 +167,11 @@ def resample_on_device(x, sr_in, sr_out):
     h, P, Q, taps = _device_phases[key]
     x = x.to(torch.float32).contiguous()
     n_in = int(x.numel())
-    n_out = -(-n_in * P // Q)
-    y = torch.empty(n_out, dtype=torch.float32, device=x.device)
-    _lib.call("ov_polyphase_fir_f32", x, h, y, n_in, n_out, P, Q, taps)
+    n_res, n_out = n_in * P // Q, -(-n_in * P // Q)           # resampy's sample count, librosa's fixed length
+    y = torch.zeros(n_out, dtype=torch.float32, device=x.device) if n_out > n_res else torch.empty(
+        n_out, dtype=torch.float32, device=x.device)
+    if n_res > 0:
+        _lib.call("ov_polyphase_fir_f32", x, h, y, n_in, n_res, P, Q, taps)
     return y
 
 

@@ -832,9 +832,30 @@ class ConverterEngine:
         nk = len(self.cfg["resblock_kernel_sizes"])
         need = 3 * B * L * ch
         bufs = ws.get("split3")
-        if bufs is None or bufs[0].numel() < need:
-            bufs = ws["split3"] = [torch.empty(need, dtype=torch.bfloat16, device=self.device) for _ in range(4 + nk)]
+        if bufs is None:
+            # sized ONCE per workspace, at the largest split stage of this (batch, frames) -- stage i has ch_i channels at
+            # frames x prod(rates[:i + 1]) columns -- and never from a capturing graph's private pool
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.OvError("split-precision plane buffers must exist before graph capture: run one eager conversion "
+                                   "of this (batch, frames) shape first")
+            cfg, frames = self.cfg, L // self._stage_rate(ch)
+            c, rate, largest = cfg["upsample_initial_channel"], 1, need
+            for i, u in enumerate(cfg["upsample_rates"]):
+                c, rate = c // 2, rate * u
+                if self.split_resblocks is not None and self.split_resblocks[i] is not None:
+                    largest = max(largest, 3 * B * frames * rate * c)
+            bufs = ws["split3"] = [torch.empty(largest, dtype=torch.bfloat16, device=self.device) for _ in range(4 + nk)]
+        assert bufs[0].numel() >= need
         return [b[:need].view(3, B, L, ch) for b in bufs]
+
+    def _stage_rate(self, ch):
+        """Columns per frame at the generator stage that has ``ch`` channels."""
+        c, rate = self.cfg["upsample_initial_channel"], 1
+        for u in self.cfg["upsample_rates"]:
+            c, rate = c // 2, rate * u
+            if c == ch:
+                return rate
+        raise _lib.OvError(f"no generator stage with {ch} channels")
 
     def _mrf_split(self, stage, u, acc, ws, B, ch, L, limits=None, rate=1):
         """One MRF stage on the split-precision kernels: u (B, ch, L) fp32 raw -> acc (B, ch, L) fp32 = mean of the

@@ -136,6 +136,16 @@ def _tables():
 _CORE = None                                            # ctypes handle of libov_mp3.so; False = not built
 
 
+def _bit(buf, pos):
+    """Bit ``pos`` of ``buf``; zero beyond its end (a corrupt big_values / linbits field runs past the granule's data:
+    the C core reads zeros there too, so both forms decode damaged input identically instead of raising IndexError)."""
+    b = pos >> 3
+    return (buf[b] >> (7 - (pos & 7))) & 1 if b < len(buf) else 0
+
+
+MP3_CORE_VERSION = 1          # ovmp3_version() of csrc/mp3_core.c this module was written against
+
+
 def _core():
     """The C Huffman core (csrc/mp3_core.c -> libov_mp3.so) when it is built, else None (the Python form below is used).
     ``OPENVOICE_AMD_MP3_CORE=0`` forces the Python form (tests compare the two)."""
@@ -147,12 +157,15 @@ def _core():
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libov_mp3.so")
         try:
             lib = ctypes.CDLL(path)
+            lib.ovmp3_version.restype, lib.ovmp3_version.argtypes = ctypes.c_int, []
+            if lib.ovmp3_version() != MP3_CORE_VERSION:      # a stale libov_mp3.so: the Python form is the safe choice
+                raise OSError(f"libov_mp3.so is version {lib.ovmp3_version()}, expected {MP3_CORE_VERSION}")
             lib.ovmp3_huffman.restype = ctypes.c_int64
             lib.ovmp3_huffman.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
                                           ctypes.c_void_p]
             _CORE = lib
-        except OSError:
+        except (OSError, AttributeError):
             _CORE = False
     return _CORE or None
 
@@ -242,18 +255,57 @@ def _side_len(hd):
     return (9 if mono else 17) if hd["lsf"] else (17 if mono else 32)
 
 
+def _same_stream(a, b):
+    """Two headers of one stream agree in version, layer and sampling rate (bit rate, padding, mode may change)."""
+    return a["version"] == b["version"] and a["layer"] == b["layer"] and a["rate_index"] == b["rate_index"]
+
+
+def _confirmed(data, pos, hd):
+    """A byte pattern that parses as a header is a FRAME only when the stream continues consistently behind it: another
+    header of the same version / layer / rate at ``pos + frame length``, an ID3v1 ``TAG`` there, or the end of the data
+    (the last frame).  Anything else -- cover art, an APEv2 tag, a trailer, a damaged header -- is skipped byte by byte,
+    as FFmpeg's resynchronisation does, instead of aborting the file."""
+    if hd is None or hd["bitrate_index"] == 0 or hd["layer"] != 1:
+        # (free-format streams and Layers I / II are not frames to this decoder; their length formulas differ, so they
+        # are confirmed -- for the error message -- by _first_frame's own rule below)
+        return False
+    end = pos + _frame_length(hd)
+    if end >= len(data) - 4:
+        return end <= len(data)
+    if data[end:end + 3] == b"TAG":
+        return True
+    nxt = _header(data, end)
+    return nxt is not None and _same_stream(hd, nxt)
+
+
+def _layer12_frame_length(hd):
+    """Frame bytes of a Layer I / II header (only to CONFIRM such a stream before naming it in the error)."""
+    v1 = hd["version"] == 3
+    rate = RATES[hd["row"]]
+    if hd["layer"] == 3:                                   # Layer I: 32-bit slots
+        kbps = ((0, 32, 64, 96, 128, 160, 192, 224, 256, 288, 320, 352, 384, 416, 448) if v1 else
+                (0, 32, 48, 56, 64, 80, 96, 112, 128, 144, 160, 176, 192, 224, 256))[hd["bitrate_index"]]
+        return (12000 * kbps // rate + hd["padding"]) * 4
+    kbps = ((0, 32, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384) if v1 else
+            (0, 8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160))[hd["bitrate_index"]]
+    return 144000 * kbps // rate + hd["padding"]
+
+
 def _first_frame(data):
     pos = _skip_id3v2(data)
     while pos + 4 <= len(data):
         hd = _header(data, pos)
         if hd is not None and hd["bitrate_index"] != 0:
-            if hd["layer"] != 1:
-                raise Mp3Error("only Layer III is built (this stream is MPEG audio Layer I or II)")
-            nxt = _header(data, pos + _frame_length(hd))
-            if nxt is not None or pos + _frame_length(hd) >= len(data) - 4:
-                return pos, hd
+            if hd["layer"] == 1:
+                if _confirmed(data, pos, hd):
+                    return pos, hd
+            else:
+                # Layer I / II: named only when a second consistent header confirms it is a stream, not noise
+                nxt = _header(data, pos + _layer12_frame_length(hd))
+                if nxt is not None and _same_stream(hd, nxt):
+                    raise Mp3Error("only Layer III is built (this stream is MPEG audio Layer I or II)")
         pos += 1
-    raise Mp3Error("no MPEG audio frame found")
+    raise Mp3Error("unsupported format: no MPEG audio Layer III frame found (RIFF/WAVE and MP3 are read natively)")
 
 
 def probe(data):
@@ -450,7 +502,7 @@ def _huffman(br, g, end, rate_index, t):
                 x += br.get(linbits)
                 pos = br.pos
             if x:
-                if (buf[pos >> 3] >> (7 - (pos & 7))) & 1:
+                if _bit(buf, pos):
                     x = -x
                 pos += 1
             if linbits and y == 15:
@@ -458,7 +510,7 @@ def _huffman(br, g, end, rate_index, t):
                 y += br.get(linbits)
                 pos = br.pos
             if y:
-                if (buf[pos >> 3] >> (7 - (pos & 7))) & 1:
+                if _bit(buf, pos):
                     y = -y
                 pos += 1
             out[i], out[i + 1] = x, y
@@ -475,7 +527,7 @@ def _huffman(br, g, end, rate_index, t):
         vals = [0, 0, 0, 0]
         for n, bit in enumerate((8, 4, 2, 1)):
             if v & bit:
-                vals[n] = -1 if (buf[pos >> 3] >> (7 - (pos & 7))) & 1 else 1
+                vals[n] = -1 if _bit(buf, pos) else 1
                 pos += 1
         if pos > end:                                  # ran past the granule: the last quadruple is stuffing, not data
             break
@@ -624,33 +676,54 @@ def decode(data, trim_gapless=True, clip=True):
     kinds = [[] for _ in range(nch)]
     first = True
     frames = 0
+    stream_hd = _header(data, pos)                        # the confirmed first frame: version / layer / rate of the stream
+    in_sync = -1                                          # where the frame after the last decoded one must start
     while True:
         hd = _header(data, pos)
-        if hd is None or hd["bitrate_index"] == 0:
-            # resynchronise (a few junk bytes, an ID3v1 tag at the end); stop when nothing follows
+        # in sync (the header sits exactly where the previous frame ended) a frame of this stream is taken as is -- so the
+        # last frame before a trailer is not lost; out of sync it must be confirmed by what follows it
+        ok = hd is not None and hd["bitrate_index"] != 0 and _same_stream(hd, stream_hd) and (
+            pos == in_sync or _confirmed(data, pos, hd))
+        if not ok:
+            # resynchronise: junk between frames (tags, cover art, a damaged header) is skipped to the next CONFIRMED
+            # frame of this stream; stop when nothing follows
             nxt = data.find(b"\xff", pos + 1)
-            while nxt >= 0 and (_header(data, nxt) is None or _header(data, nxt)["bitrate_index"] == 0):
+            while nxt >= 0:
+                cand = _header(data, nxt)
+                if cand is not None and _same_stream(cand, stream_hd) and _confirmed(data, nxt, cand):
+                    break
                 nxt = data.find(b"\xff", nxt + 1)
             if nxt < 0:
                 break
             pos = nxt
             continue
-        if hd["layer"] != 1:
-            raise Mp3Error("only Layer III is built (this stream is MPEG audio Layer I or II)")
         flen = _frame_length(hd)
         if pos + flen > len(data):
             break
         frame_nch = 1 if hd["mode"] == 3 else 2
-        if frame_nch != nch or RATES[hd["row"]] != rate:
-            raise Mp3Error("channel count / sampling rate changes inside the stream")
-        side_len = _side_len(hd)
         ngr, row = (1 if hd["lsf"] else 2), hd["row"]
+        if frame_nch != nch and not (first and info["xing"]):
+            # a frame of this stream whose channel count differs from the first frame's -- in practice a damaged mode
+            # field: its granules are silence and the stream goes on (nothing inside the stream aborts the file; only
+            # the confirmed FIRST frame decides what the stream is)
+            for ch in range(nch):
+                for _ in range(ngr):
+                    lines[ch].append(np.zeros(576))
+                    kinds[ch].append(-1)
+            first = False
+            pos += flen
+            in_sync = pos
+            frames += 1
+            continue
+        side_len = _side_len(hd)
         body = pos + 4 + (2 if hd["crc"] else 0)
         if first and info["xing"]:
             first = False                              # the Xing / Info frame carries the header, not audio
             pos += flen
+            in_sync = pos
             continue
         first = False
+        in_sync = pos + flen
         si = (_side_info_lsf if hd["lsf"] else _side_info)(_Bits(data, body * 8), nch)
         main = data[body + side_len:pos + flen]
         if si["main_data_begin"] > len(reservoir):

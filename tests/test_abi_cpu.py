@@ -344,3 +344,9 @@ def test_conv_wino_params_struct_matches_header_field_order():
     assert lib.ov_version() >= 207
     assert [lib.ov_conv1d_wino_chunk(k, 128) for k in (3, 5, 7, 11)] == [16, 0, 8, 8]
     assert [lib.ov_conv1d_wino_chunk(k, 64) for k in (3, 7, 11)] == [8, 4, 4] and lib.ov_conv1d_wino_chunk(11, 96) == 0
+
+
+def test_header_abi_version_macro_matches_the_library():
+    header = open(os.path.join(REPO, "include", "openvoice_amd.h")).read()
+    macro = int(re.search(r"#define OV_ABI_VERSION (\d+)", header).group(1))
+    assert _lib.load().ov_version() == macro == _lib.MIN_VERSION

@@ -48,6 +48,12 @@ def test_bench_multi_rank_control_flow_on_gloo(n):
     cb = rec["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb and "unit" in cb
     assert rec["distributed"]["process_group"] is True and len(rec["distributed"]["devices"]) == n
+    # the unattended N-GPU run diagnoses itself -- every rank's own MRF time and resident bytes come
+    # back over the group, and the collective library's version + the environment switches are on the line
+    per = rec["distributed"]["per_rank"]
+    assert [r["rank"] for r in per] == list(range(n)) and all({"mrf_ms", "hbm_resident_bytes", "device"} <= set(r) for r in per)
+    assert {"rccl_version", "env", "torch"} <= set(rec["distributed"])
+    assert {"HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "NCCL_DEBUG_SUBSYS"} <= set(rec["distributed"]["env"])
 
 
 def test_bench_single_rank_dry_run_needs_no_process_group():
@@ -103,3 +109,15 @@ def test_plain_python_launch_with_gpus_2_starts_its_own_ranks():
     assert len(rec["per_rank_ms_per_step"]["ranks"]) == 2
     cb = rec["cpu_baseline"]
     assert cb["value"] > 0 and cb["kind"] in ("port", "reference") and "batch32" in cb
+
+
+def test_more_ranks_than_devices_is_one_json_error_line_before_any_launch():
+    """``--gpus 8`` on a node with fewer devices (here: none) prints ONE JSON line with "error" and
+    exits non-zero BEFORE re-executing under torch.distributed.run -- no rendezvous, no hang."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=120, env=env, cwd=REPO)
+    assert res.returncode == 4, (res.returncode, res.stderr[-500:])
+    assert "re-executing" not in res.stderr
+    (rec,) = _lines(res.stdout)
+    assert "device_count() = 0" in rec["error"] and rec["n_gpus"] == 8 and rec["value"] is None

@@ -21,7 +21,8 @@ import re
 import sys
 
 # the MRF launches: single ResBlock convs (EPI = LINEAR, K in {3, 7, 11}) and the fused ResBlock pairs
-MRF = re.compile(r"conv1d_mfma_kernel<(3|7|11), (1|3|5), \d+, \d+, \d+, \d+, \d+, (?:true|1|2), 0, \d+>|respair_mfma_kernel<")
+MRF = re.compile(r"conv1d_mfma_kernel<(3|7|11), (1|3|5), \d+, \d+, \d+, \d+, \d+, (?:true|1|2), 0, \d+>|respair_mfma_kernel<|"
+                 r"conv1d_wino_kernel<")
 GIB = float(1 << 30)
 
 
