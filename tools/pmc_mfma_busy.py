@@ -25,7 +25,14 @@ EPI = {0: "linear", 1: "gate", 2: "resskip", 3: "couple", 4: "posterior", 5: "co
        17: "convT s2"}
 
 
+WINO = re.compile(r"conv1d_wino_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false|0|1)>")
+
+
 def family(name):
+    w = WINO.search(name)
+    if w:
+        k, dil, ci, nf, mw = (int(x) for x in w.groups()[:5])
+        return f"winograd k={k} d={dil} rows {32 * mw} frags {nf} chunk {ci}"
     m = CONV.search(name)
     if not m:
         return name.split("(")[0][-60:]
