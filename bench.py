@@ -856,8 +856,9 @@ def main():
                          "winograd": {"launches_per_step": wino_n,
                                       "share_of_mrf_alg_flops": round(wino_alg / f_mrf, 4) if f_mrf else None,
                                       "ms_per_step": round(wino_s * 1e3, 3),
-                                      "which": "ResBlock convs with C % 128 == 0, dilations 1 / 3 / 5 (ov_conv1d_wino_f32: nested "
-                                               "F(4,3), fp32 MFMA); every other conv runs the direct implicit GEMM"}
+                                      "which": "ResBlock convs with C >= 64 (k = 3 / 7 / 11, dilations 1 / 3 / 5) and the dilation-1 "
+                                               "k = 11 convs at C = 32 (ov_conv1d_wino_f32: nested F(4,3), fp32 MFMA; "
+                                               "engine.wino_policy); every other conv runs the direct implicit GEMM"}
                          if wino_n else None,
                          "kernel": "ovkw::conv1d_wino_kernel (Winograd-domain, where it has an instance) + ovk::conv1d_mfma_kernel "
                                    "(+ ovk::respair_mfma_kernel where a ResBlock pair is one launch) on the MRF ResBlock convs",

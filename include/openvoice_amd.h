@@ -527,7 +527,8 @@ int ov_split3_to_f32(const uint16_t* a, const uint16_t* b, const uint16_t* c, in
  * output and (co, ci): 1.5 (K = 3), 4.5 (K = 7), 6 (K = 11) instead of K.  The transforms round where the direct conv
  * does not: against float64 the result carries ~4x the rounding error of ov_conv1d_f32 (tests/test_gpu_wino.py).
  * Tensors are fp32 [B][C][L], rows x_ld / out_ld floats apart (0 = L); L, x_ld, out_ld multiples of 4 and every
- * pointer 16-byte aligned; Cin % ov_conv1d_wino_chunk(K, Cout) == 0, Cout % 64 == 0 and <= 512; out must not alias x
+ * pointer 16-byte aligned; Cin % ov_conv1d_wino_chunk(K, Cout) == 0, Cout <= 512 and a multiple of 64 (K = 3 / 7 / 11) or
+ * of 32 (K = 11); out must not alias x
  * (it may be the very tensor passed as res or add -- the MRF running sum is accumulated in place). */
 typedef struct ov_conv1d_wino_params {
   const float* x;        /* [B][Cin][L] */
@@ -557,7 +558,7 @@ int ov_conv1d_wino_f32(const ov_conv1d_wino_params* p, ov_stream_t stream);
 /* 1 when (Cin, Cout, K, dil) has an instance, else 0 (callers then use ov_conv1d_f32). */
 int ov_conv1d_wino_supported(int Cin, int Cout, int K, int dil);
 /* Input channels per LDS fill of the instance for K taps and Cout rows (Cout % 128 == 0: four 32-row fragments per
- * workgroup; Cout % 64 == 0: two); the packed stream is ordered by it; 0 = no instance. */
+ * workgroup; Cout % 64 == 0: two; Cout % 32 == 0: one, K = 11 only); the packed stream is ordered by it; 0 = no instance. */
 int ov_conv1d_wino_chunk(int K, int Cout);
 /* Floats of the packed transform-domain weights; 0 when the shape has no instance. */
 size_t ov_conv1d_wino_pack_size(int Cout, int Cin, int K);
@@ -572,7 +573,8 @@ int ov_conv1d_wino_pack_f32(const float* w, int Cout, int Cin, int K, float* dst
  * 2.03: ov_conv1d_split3 (+ _pack_size, _pack, _supported), ov_split3_from_f32, ov_split3_to_f32.  2.04:
  * ov_conv1d_split3_params.col_limit / col_limit_scale.  2.05: ov_wn_layer_params.acts / row_split (the field that
  * was `reserved`; the struct grew by one pointer at its end).  2.06: ov_polyphase_fir_f32.  2.07: ov_conv1d_wino_f32 (+ _supported, _chunk,
- * _pack_size, _pack_f32).  The Python binding
+ * _pack_size, _pack_f32).  2.08: ov_conv1d_wino_f32 instances for Cout % 32 == 0 at K = 11 (one 32-row fragment per
+ * workgroup; ov_conv1d_wino_chunk(11, 32) = 2 where 2.07 returned 0).  The Python binding
  * refuses a library older than the entry points it calls (openvoice_amd/_lib.py MIN_VERSION). */
 int ov_version(void);
 /* The version THIS header describes.  Parameter structs grow at their END in minor versions (2.04, 2.05, 2.07 did): a
@@ -582,7 +584,7 @@ int ov_version(void);
  * tests/test_abi_cpu.py).  A struct is never reordered and a field never changes meaning within a major version, with
  * one exception stated here: 2.05 renamed ov_wn_layer_params.reserved to row_split AND appended `acts`, so a caller
  * built against 2.04 or older is NOT binary compatible with 2.05+ for that struct. */
-#define OV_ABI_VERSION 207
+#define OV_ABI_VERSION 208
 /* 0 for a production build; non-zero = a measurement build with parts of the kernels compiled out (results are
  * meaningless; openvoice_amd/_lib.py refuses to load it unless OPENVOICE_AMD_ALLOW_EXPERIMENT=1). */
 int ov_build_experiment(void);

@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OPENVOICE_AMD_LIB") or os.path.join(_HERE, "libopenvoice_amd.so")
 
 OV_OK = 0
-MIN_VERSION = 207     # ov_version() of the newest entry point this package calls (include/openvoice_amd.h)
+MIN_VERSION = 208     # ov_version() of the newest entry point this package calls (include/openvoice_amd.h)
 OV_ERRORS = {-1: "OV_E_BADARG", -2: "OV_E_UNSUPPORTED", -3: "OV_E_ALIGN", -4: "OV_E_LAUNCH"}
 
 EPI_LINEAR, EPI_GATE, EPI_RESSKIP, EPI_COUPLE, EPI_POSTERIOR, EPI_CONVT, EPI_MAGNITUDE = range(7)

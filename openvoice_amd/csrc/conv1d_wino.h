@@ -15,10 +15,11 @@
 // One workgroup = 4 MATRIX waves (wave w owns output rows 32w .. 32w + 31 of a 128-row M-block x 32 tiles = 128
 // columns: 6 accumulator fragments = 96 VGPRs) + 2 HELPER waves; 2 workgroups per CU.  Input channels are walked in
 // chunks of CI.  Per chunk the helpers (a) stage the raw rows (leaky ReLU applied, zero outside [0, L)) from HBM
-// through registers into LDS, one chunk ahead, and (b) transform the previous raw chunk into V[k = g*CI + ci][tile][6]
-// (5 ds_read_b128 -> 48 VALU -> 12 ds_write_b64 per (ci, tile) at K = 11), double buffered; ONE s_barrier per chunk.
-// A matrix wave reads its B operands as three conflict-free ds_read_b64 per k-step (two points each) and streams its A
-// operands (U, fragment order, 3 KiB per k-step pair) from L2 one pair ahead; the epilogue applies At, adds bias /
+// through registers into LDS, one chunk ahead, channel PAIRS interleaved (raw[pair][column][2]), and (b) transform the
+// previous raw chunk into V[k-step = g * CI / 2 + pair][tile][channel of the pair][6], two channels per lane in packed
+// fp32 (10 ds_read_b128 -> 48 v_pk_* -> 24 ds_write2_b32 per (pair, tile) at K = 11), double buffered; ONE s_barrier per
+// chunk.  A matrix wave reads its B operands as three conflict-free ds_read_b64 per k-step (two points each) and streams
+// its A operands (U, fragment order, 3 KiB per k-step pair) from L2 one pair ahead; the epilogue applies At, adds bias /
 // residual / MRF running sum, scales, and stores 16 bytes per lane and row (a lane's 4 outputs are consecutive columns).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -34,6 +35,24 @@ namespace ovkw {
 using ovk::f32x16;
 using ovk::f32x2;
 using ovk::f32x4;
+
+// LDS byte address of a __shared__ object (what the DS instructions written as inline assembly take)
+__device__ __forceinline__ uint32_t lds_addr(const void* ptr) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)ptr;
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_write_b32(uint32_t addr, float v) {
+  static_assert(OFF >= 0 && OFF < 65536, "DS immediate offset");
+  asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 constexpr int REC = 256;        // floats per 1 KiB weight sub-record
 constexpr int MAX_COUT = 512;   // rows of the bias vector kept in LDS
@@ -95,7 +114,10 @@ __host__ __device__ inline size_t wino_pack_floats(int Cout, int Cin, int K, int
 // MW = matrix waves along M.  MW = 4: the four waves own the four 32-row fragments of a 128-row M-block and share one
 // column block.  MW = 2 (Cout a multiple of 64 only: the C = 64 stage): two 32-row fragments x TWO adjacent column
 // sub-blocks per workgroup (wave w: rows 32 (w & 1), sub-block w >> 1), so the workgroup still runs four matrix waves on a
-// 64-row layer; the waves of a sub-block pair stream the same A fragments.
+// 64-row layer; the waves of a sub-block pair stream the same A fragments.  MW = 1 (Cout a multiple of 32: the C = 32 stage,
+// K = 11): ONE 32-row fragment x FOUR column sub-blocks (1 024 columns per workgroup), all four waves on the same A stream.
+// The helpers' work per MFMA doubles with every halving of the rows (the transform of a tile is shared by fewer row
+// fragments); what keeps them off the critical path is their instruction count -- see the helper section.
 template <int K, int DIL, int CI, int NF, int MW, bool DBG>
 __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_wino_kernel(const ov_conv1d_wino_params p) {
   using Ge = Geo<K>;
@@ -107,14 +129,16 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
   constexpr int NCOLS = DIL == 1 ? 4 * NTS : Gd::NCOL;   // output columns per sub-block
   constexpr int NCOL = NCOLS * NB;     // output columns per N-block
   constexpr int RW = (DIL == 1 ? NCOLS + 16 : Gd::RW) + (NB - 1) * NCOLS;   // floats per raw LDS row: column t0 - ORG + c at index c
-  static_assert(MW == 4 || (MW == 2 && NF == 2), "two-row-fragment workgroups run two fragments per wave");
+  static_assert(MW == 4 || ((MW == 2 || MW == 1) && NF == 2), "two- and one-row-fragment workgroups run two fragments per wave");
   constexpr int ORG = DIL == 1 ? 8 : Gd::PADA;
   constexpr int RW4 = RW / 4;
   constexpr int NHELP = 2 * NF;        // helper waves
   static_assert(DIL == 1 || NF == 2, "dilated instances run two fragments per wave");
   static_assert(KR % 4 == 0 && CI % 2 == 0, "k-rows in whole k-step pairs");
-  constexpr int RAWBUF = CI * RW;        // floats per raw buffer
-  constexpr int VBUF = KR * NT * 6;      // floats per V buffer
+  constexpr int NPR = CI / 2;            // input-channel pairs per chunk (a pair = one k-step of each group)
+  constexpr int NITEM = NPR * RW4;       // staging items per chunk: (channel pair, 4 columns) = two 16-byte vectors
+  constexpr int RAWBUF = CI * RW;        // floats per raw buffer: raw[pair][raw index][channel of the pair]
+  constexpr int VBUF = KR * NT * 6;      // floats per V buffer: V[k-row = g * CI + channel][tile][6]
   __shared__ __attribute__((aligned(16))) float raw[2 * RAWBUF];
   __shared__ __attribute__((aligned(16))) float Vs[2 * VBUF];
   __shared__ __attribute__((aligned(16))) float bias_s[MAX_COUT];   // read back 16 bytes at a time at every item start
@@ -194,35 +218,70 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
   const bool is_helper = wave >= 4;
   if (is_helper) {
     // ================================ helper waves ================================================
-    // Above the matrix waves in the issue arbiter: a helper's ~200 instructions per chunk are a few per cent of its
-    // SIMD's cycles, but at equal priority each of them queued behind a 64-cycle MFMA of the two matrix waves it shares
-    // the SIMD with (phase timers, profiles/r06_s3: the transform alone took 63 % of a chunk period).
+    // A helper shares its SIMD with a matrix wave that always has an MFMA waiting for the pipe, i.e. a standing claim on
+    // the vector-ALU issue slot: every VALU instruction of a helper waits for a gap (~40 cycles each at priority 3, ~64
+    // without: phase timers, profiles/r06_s15).  What a helper costs is therefore its VALU INSTRUCTION COUNT, and the
+    // code below is written against that: two input channels per lane in packed fp32 (v_pk_fma / v_pk_add / v_pk_mul_f32
+    // -- the raw rows are channel-pair interleaved in LDS so that one ds_read_b128 delivers two columns of both channels
+    // as aligned register pairs), ds_write2_b32 for everything stored (two registers that need not be neighbours, two
+    // immediate offsets: no moves to build vectors), staging addresses as scalar base + loop-invariant lane offset.
     __builtin_amdgcn_s_setprio(3);
     const float slope = p.in_slope;
     const uint32_t ldx = (uint32_t)p.x_ld;
     const int hl = (wave - 4) * 64 + lane;
-    constexpr int NITEM = CI * RW4;                          // 16-byte staging vectors per chunk
     constexpr int NLOAD = (NITEM + 64 * NHELP - 1) / (64 * NHELP);
-    f32x4 stg[NLOAD];
-    int nval[NLOAD];
+    // TWO register sets: the vectors of chunk c travel in set c & 1 and are requested a whole chunk period before they are
+    // written to LDS -- with one set, request and use sat in the same period, and a chunk could not be shorter than an
+    // HBM round trip under load (~2.5 us: the floor of every instance whose k-loop is shorter, profiles/r06_s16)
+    f32x4 sa[2][NLOAD], sb[2][NLOAD];    // the staged vector of the pair's first / second channel
+    uint32_t sbyte[NLOAD];               // byte offset of (row 2 pr, raw index 4 c4) from (first row of the chunk, raw index 0)
+    int scol[NLOAD];                     // 4 c4
+    uint32_t hasbits = 0, okbits[2] = {0, 0};
+    bool edge[2] = {false, false};
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      const int idx = i * (64 * NHELP) + hl;
+      const int pr = idx / RW4, c4 = idx - pr * RW4;
+      const bool has = idx < NITEM;
+      hasbits |= (has ? 1u : 0u) << i;
+      scol[i] = 4 * c4;
+      sbyte[i] = has ? 4u * (2u * (uint32_t)pr * ldx + 4u * (uint32_t)c4) : 0u;
+    }
+    const uint32_t raw_lds = lds_addr(raw) + 32u * (uint32_t)hl;   // this lane's item of staging round 0: 8 floats per item
+    const uint32_t v_lds = lds_addr(Vs);
     int lwid = wid0, lchunk = 0, lpos = 0;                   // position of the staging stream
     int lb, ltile, lmblk;
     decode(lwid, lb, ltile, lmblk);
 
-    auto issue_loads = [&]() {
+    auto issue_loads = [&](auto setc) {
+      constexpr int S = decltype(setc)::value;
       const bool live = lpos < nstream;
-      const int t0 = ltile * NCOL;
-      const float* __restrict__ xb = p.x + (int64_t)lb * p.x_bstride;
+      const int tb = ltile * NCOL - ORG;                     // column of raw index 0 (a multiple of 4)
+      const float* __restrict__ xrow = p.x + (int64_t)lb * p.x_bstride + (int64_t)(lchunk * CI) * ldx;
+      // interior blocks (all but the first and last of an utterance): every vector lies inside [0, L) -- no lane arithmetic
+      edge[S] = !(live && tb >= 0 && tb + RW <= L);
+      if (!edge[S]) {
+        const char* b0 = reinterpret_cast<const char*>(xrow + tb);
+        const char* b1 = reinterpret_cast<const char*>(xrow + tb + ldx);
 #pragma unroll
-      for (int i = 0; i < NLOAD; ++i) {
-        const int idx = i * (64 * NHELP) + hl;
-        const int row = idx / RW4, c4 = idx - row * RW4;
-        const int ci = lchunk * CI + row;
-        const int t = t0 - ORG + 4 * c4;                     // multiple of 4: a vector is wholly inside or outside
-        const bool ok = live && idx < NITEM && t >= 0 && t < L;
-        const uint32_t goff = ok ? (uint32_t)ci * ldx + (uint32_t)t : 0u;
-        nval[i] = ok ? min(L - t, 4) : 0;
-        stg[i] = *reinterpret_cast<const f32x4*>(xb + goff);
+        for (int i = 0; i < NLOAD; ++i) {
+          sa[S][i] = *reinterpret_cast<const f32x4*>(b0 + sbyte[i]);
+          sb[S][i] = *reinterpret_cast<const f32x4*>(b1 + sbyte[i]);
+        }
+      } else {
+        const char* b0 = reinterpret_cast<const char*>(xrow);
+        const char* b1 = reinterpret_cast<const char*>(xrow + ldx);
+        uint32_t okb = 0;
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+          const int t = tb + scol[i];                        // multiple of 4: a vector is wholly inside or outside
+          const bool ok = live && ((hasbits >> i) & 1u) && t >= 0 && t < L;
+          const uint32_t off = ok ? sbyte[i] + 4u * (uint32_t)tb : 0u;
+          okb |= (ok ? 1u : 0u) << i;
+          sa[S][i] = *reinterpret_cast<const f32x4*>(b0 + off);
+          sb[S][i] = *reinterpret_cast<const f32x4*>(b1 + off);
+        }
+        okbits[S] = okb;
       }
       ++lpos;
       if (++lchunk == nchunks) {
@@ -231,89 +290,132 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
         if (lwid < wend) decode(lwid, lb, ltile, lmblk);
       }
     };
-    auto write_raw = [&](int buf) {
-      float* dst = raw + buf * RAWBUF;
+    // leaky ReLU as max(v, slope v) (0 < slope <= 1: the same value as v > 0 ? v : slope v for every v, NaN included)
+    auto act2 = [&](f32x2 v) {
+      const f32x2 sv = v * f32x2{slope, slope};
+      f32x2 r;
+      asm("v_max_f32 %0, %1, %2" : "=v"(r[0]) : "v"(v[0]), "v"(sv[0]));
+      asm("v_max_f32 %0, %1, %2" : "=v"(r[1]) : "v"(v[1]), "v"(sv[1]));
+      return r;
+    };
+    auto write_raw = [&](int buf, auto setc) {
+      constexpr int S = decltype(setc)::value;
+      const uint32_t base = raw_lds + (uint32_t)buf * (RAWBUF * 4);
 #pragma unroll
       for (int i = 0; i < NLOAD; ++i) {
-        const int idx = i * (64 * NHELP) + hl;
-        if (idx < NITEM) {
-          f32x4 v = stg[i];
-          const int n = nval[i];
-          v[0] = n > 0 ? ovk::lrelu(v[0], slope) : 0.f;
-          v[1] = n > 1 ? ovk::lrelu(v[1], slope) : 0.f;
-          v[2] = n > 2 ? ovk::lrelu(v[2], slope) : 0.f;
-          v[3] = n > 3 ? ovk::lrelu(v[3], slope) : 0.f;
-          *reinterpret_cast<f32x4*>(dst + 4 * idx) = v;       // row * RW + 4 * c4 == 4 * idx
+        if ((hasbits >> i) & 1u) {
+          f32x2 a01 = {sa[S][i][0], sa[S][i][1]}, a23 = {sa[S][i][2], sa[S][i][3]};
+          f32x2 b01 = {sb[S][i][0], sb[S][i][1]}, b23 = {sb[S][i][2], sb[S][i][3]};
+          if (slope != 1.f) {
+            a01 = act2(a01); a23 = act2(a23); b01 = act2(b01); b23 = act2(b23);
+          }
+          if (edge[S] && !((okbits[S] >> i) & 1u)) a01 = a23 = b01 = b23 = f32x2{0.f, 0.f};
+          const uint32_t ad = base + (uint32_t)i * (64 * NHELP * 32);   // raw[pair][4 c4 + e][channel]: item idx at 8 idx floats
+          asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(ad), "v"(a01[0]), "v"(b01[0]) : "memory");
+          asm volatile("ds_write2_b32 %0, %1, %2 offset0:2 offset1:3" ::"v"(ad), "v"(a01[1]), "v"(b01[1]) : "memory");
+          asm volatile("ds_write2_b32 %0, %1, %2 offset0:4 offset1:5" ::"v"(ad), "v"(a23[0]), "v"(b23[0]) : "memory");
+          asm volatile("ds_write2_b32 %0, %1, %2 offset0:6 offset1:7" ::"v"(ad), "v"(a23[1]), "v"(b23[1]) : "memory");
         }
       }
     };
-    // raw[buf] -> V[buf]: item = (ci_local, tile); V[(g * CI + ci_local) * NT + tile][6]
+    // raw[buf] -> V[buf]: item = (channel pair, tile); V[k-row = g * CI + 2 pair + channel][tile][6]
+    constexpr int ROUNDS = NPR * NT / (64 * NHELP);
+    static_assert(NPR * NT % (64 * NHELP) == 0, "whole rounds of helper lanes");
+    uint32_t tsrc[ROUNDS], tdst[ROUNDS];   // loop-invariant byte offsets of a lane's items: raw window, V record of group 0
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int idx = r * (64 * NHELP) + hl;
+      const int tile = idx & (NT - 1), pr = idx / NT;        // tile of the N-block = sub-block * NTS + tile of the sub-block
+      if constexpr (DIL == 1) {
+        tsrc[r] = 8u * (uint32_t)(pr * RW + Ge::WSTART + 4 * tile);
+      } else {
+        // tile -> (residue class, tile of the class); the left-over tiles duplicate tile 0 (never stored)
+        const int sub = tile / NTS, tl = tile - sub * NTS;
+        const int rc0 = tl / Gd::J, rc = rc0 < DIL ? rc0 : 0, jt = rc0 < DIL ? tl - rc0 * Gd::J : 0;
+        tsrc[r] = 8u * (uint32_t)(pr * RW + (Gd::PADA - Gd::PADD) + sub * NCOLS + rc + 4 * DIL * jt);
+      }
+      tdst[r] = 24u * (uint32_t)(2 * pr * NT + tile);
+    }
     auto transform = [&](int buf) {
-      const float* src = raw + buf * RAWBUF;
-      float* dst = Vs + buf * VBUF;
-      constexpr int ROUNDS = CI * NT / (64 * NHELP);
-      static_assert(CI * NT % (64 * NHELP) == 0, "whole rounds of helper lanes");
+      const char* src = reinterpret_cast<const char*>(raw) + buf * (RAWBUF * 4);
+      const uint32_t dst = v_lds + (uint32_t)buf * (VBUF * 4);
 #pragma unroll
       for (int r = 0; r < ROUNDS; ++r) {
-        const int idx = r * (64 * NHELP) + hl;
-        const int tile = idx & (NT - 1), cil = idx / NT;     // tile of the N-block = sub-block * NTS + tile of the sub-block
         constexpr int NWIN = DIL == 1 ? 4 * Ge::NB128 : Gd::NV;
-        float win[NWIN];
+        f32x2 win[NWIN];                                     // (channel 2 pr, channel 2 pr + 1) at NWIN consecutive inputs
         if constexpr (DIL == 1) {
 #pragma unroll
-          for (int q = 0; q < Ge::NB128; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src + cil * RW + Ge::WSTART + 4 * tile + 4 * q);
-            win[4 * q] = v[0]; win[4 * q + 1] = v[1]; win[4 * q + 2] = v[2]; win[4 * q + 3] = v[3];
+          for (int q = 0; q < 2 * Ge::NB128; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + tsrc[r] + 16 * q);
+            win[2 * q] = f32x2{v[0], v[1]};
+            win[2 * q + 1] = f32x2{v[2], v[3]};
           }
         } else {
-          // tile -> (residue class, tile of the class); the left-over tiles duplicate tile 0 (never stored)
-          const int sub = tile / NTS, tl = tile - sub * NTS;
-          const int rc0 = tl / Gd::J, rc = rc0 < DIL ? rc0 : 0, jt = rc0 < DIL ? tl - rc0 * Gd::J : 0;
-          const float* s0 = src + cil * RW + (Gd::PADA - Gd::PADD) + sub * NCOLS + rc + 4 * DIL * jt;
 #pragma unroll
-          for (int u = 0; u < Gd::NV; ++u) win[u] = s0[DIL * u];
+          for (int u = 0; u < Gd::NV; ++u) win[u] = *reinterpret_cast<const f32x2*>(src + tsrc[r] + 8 * DIL * u);
         }
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const int o = (DIL == 1 ? Ge::OFF0 - Ge::WSTART : 0) + 3 * g;
-          const float d0 = win[o], d1 = win[o + 1], d2 = win[o + 2], d3 = win[o + 3], d4 = win[o + 4], d5 = win[o + 5];
-          // Bt d, points 0, 1, -1, 2, -2, infinity
-          const float t1 = __builtin_fmaf(-4.f, d2, d4), t2 = __builtin_fmaf(-4.f, d1, d3);
-          const float t3 = d4 - d2, t4 = d3 - d1;
-          f32x2 v01, v23, v45;
-          v01[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
-          v01[1] = t1 + t2;
-          v23[0] = t1 - t2;
-          v23[1] = __builtin_fmaf(2.f, t4, t3);
-          v45[0] = __builtin_fmaf(-2.f, t4, t3);
-          v45[1] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
-          float* o6 = dst + ((g * CI + cil) * NT + tile) * 6;
-          *reinterpret_cast<f32x2*>(o6) = v01;
-          *reinterpret_cast<f32x2*>(o6 + 2) = v23;
-          *reinterpret_cast<f32x2*>(o6 + 4) = v45;
-        }
+        static_for<0, G>([&](auto gc) {
+          constexpr int g = decltype(gc)::value;
+          constexpr int o = (DIL == 1 ? Ge::OFF0 - Ge::WSTART : 0) + 3 * g;
+          const f32x2 d0 = win[o], d1 = win[o + 1], d2 = win[o + 2], d3 = win[o + 3], d4 = win[o + 4], d5 = win[o + 5];
+          // Bt d, points 0, 1, -1, 2, -2, infinity: 12 packed operations for the 12 values of the channel pair
+          const f32x2 c4 = {4.f, 4.f}, m4 = {-4.f, -4.f}, m5 = {-5.f, -5.f}, c2 = {2.f, 2.f}, m2 = {-2.f, -2.f};
+          const f32x2 t1 = __builtin_elementwise_fma(m4, d2, d4), t2 = __builtin_elementwise_fma(m4, d1, d3);
+          const f32x2 t3 = d4 - d2, t4 = d3 - d1;
+          const f32x2 v0 = __builtin_elementwise_fma(c4, d0, __builtin_elementwise_fma(m5, d2, d4));
+          const f32x2 v1 = t1 + t2;
+          const f32x2 v2 = t1 - t2;
+          const f32x2 v3 = __builtin_elementwise_fma(c2, t4, t3);
+          const f32x2 v4 = __builtin_elementwise_fma(m2, t4, t3);
+          const f32x2 v5 = __builtin_elementwise_fma(c4, d1, __builtin_elementwise_fma(m5, d3, d5));
+          // V[k-row g CI + 2 pr + channel][tile][6]: the records of the pair's channels are NT * 24 bytes apart; everything
+          // but the lane's item offset is an immediate (ds_write_b32 offsets reach 64 KiB)
+          constexpr int OA = g * CI * NT * 24, OB = OA + NT * 24;
+          const uint32_t ad = dst + tdst[r];
+          lds_write_b32<OA>(ad, v0[0]);      lds_write_b32<OB>(ad, v0[1]);
+          lds_write_b32<OA + 4>(ad, v1[0]);  lds_write_b32<OB + 4>(ad, v1[1]);
+          lds_write_b32<OA + 8>(ad, v2[0]);  lds_write_b32<OB + 8>(ad, v2[1]);
+          lds_write_b32<OA + 12>(ad, v3[0]); lds_write_b32<OB + 12>(ad, v3[1]);
+          lds_write_b32<OA + 16>(ad, v4[0]); lds_write_b32<OB + 16>(ad, v4[1]);
+          lds_write_b32<OA + 20>(ad, v5[0]); lds_write_b32<OB + 20>(ad, v5[1]);
+        });
       }
+    };
+    // the LDS stores above are inline assembly the compiler's counters do not see: drain them before every barrier
+    auto hand_over = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __syncthreads();
     };
 
     unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = DBG ? __builtin_readcyclecounter() : 0ull;
-    issue_loads();
-    write_raw(0);                 // chunk 0
-    issue_loads();                // chunk 1 in registers
-    __syncthreads();              // (A) raw[0] complete
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    issue_loads(S0{});
+    write_raw(0, S0{});           // chunk 0
+    issue_loads(S1{});            // chunk 1 in set 1
+    hand_over();                  // (A) raw[0] complete
     transform(0);
-    write_raw(1);
-    __syncthreads();              // (B) V[0], raw[1] complete
+    write_raw(1, S1{});
+    issue_loads(S0{});            // chunk 2 in set 0
+    hand_over();                  // (B) V[0], raw[1] complete
     OVW_MARK(4)
-    for (int i = 0; i < nstream; ++i) {
-      issue_loads();              // chunk i + 2 (nothing beyond the stream's end)
+    // period i (the matrix waves multiply V[i & 1]): request chunk i + 3 (set (i + 1) & 1), transform chunk i + 1, write
+    // chunk i + 2 (set i & 1, requested a period ago) to raw[i & 1]; nothing is requested beyond the stream's end
+    auto period = [&](int i, auto par) {
+      constexpr int P = decltype(par)::value;
+      issue_loads(std::integral_constant<int, 1 - P>{});
       OVW_MARK(0)
-      if (OVW_EXP != 2 && i + 1 < nstream) transform((i + 1) & 1);
+      if (OVW_EXP != 2 && i + 1 < nstream) transform(1 - P);
       OVW_MARK(1)
-      write_raw(i & 1);
+      write_raw(P, par);
       OVW_MARK(2)
-      __syncthreads();            // V[(i + 1) & 1] and raw[i & 1] handed over; V[i & 1] free again
+      hand_over();                // V[(i + 1) & 1] and raw[i & 1] handed over; V[i & 1] free again
       OVW_MARK(3)
+    };
+    for (int i = 0; i < nstream; i += 2) {
+      period(i, S0{});
+      if (i + 1 < nstream) period(i + 1, S1{});
     }
     if constexpr (DBG) {
       if (lane == 0) {
@@ -332,7 +434,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
   const uint32_t LD = (uint32_t)p.out_ld;
   int wid = wid0, b, tile, mblk;
   decode(wid, b, tile, mblk);
-  const int wrow = MW == 4 ? wave : (wave & 1), wsub = MW == 4 ? 0 : (wave >> 1);
+  const int wrow = MW == 4 ? wave : (MW == 2 ? (wave & 1) : 0), wsub = MW == 4 ? 0 : (MW == 2 ? (wave >> 1) : wave);
   int mtile = mblk * MW + wrow;
   // sub-record index of the first k-step pair of (mtile, chunk 0); the stream of an item is contiguous
   uint32_t rec = (uint32_t)mtile * (uint32_t)nchunks * (uint32_t)(NPAIR * 3);
@@ -595,9 +697,12 @@ int wino_launch(const ov_conv1d_wino_params* p, hipStream_t stream) {
 }
 
 // Input channels per LDS fill: by kernel size and by the rows a workgroup covers (128: four row fragments; 64: two row
-// fragments x two column sub-blocks, i.e. twice the V tile per channel) -- the packed weight stream is ordered by it.
-constexpr int wino_ci(int K, int mw = 4) { return K == 3 ? (mw == 4 ? 16 : 8) : (K == 7 || K == 11) ? (mw == 4 ? 8 : 4) : 0; }
-constexpr int wino_mw(int Cout) { return Cout % 128 == 0 ? 4 : (Cout % 64 == 0 ? 2 : 0); }
+// fragments x two column sub-blocks, i.e. twice the V tile per channel; 32: one row fragment x four sub-blocks, K = 11
+// only -- at K = 7 a chunk of two channels would be an odd number of k-steps) -- the packed weight stream is ordered by it.
+constexpr int wino_ci(int K, int mw = 4) {
+  return mw == 1 ? (K == 11 ? 2 : 0) : K == 3 ? (mw == 4 ? 16 : 8) : (K == 7 || K == 11) ? (mw == 4 ? 8 : 4) : 0;
+}
+constexpr int wino_mw(int Cout) { return Cout % 128 == 0 ? 4 : (Cout % 64 == 0 ? 2 : (Cout % 32 == 0 ? 1 : 0)); }
 
 // One translation unit per kernel size (conv1d_wino_k3 / k7 / k11.hip) so that the instances compile in parallel.
 int wino_dispatch_k3(const ov_conv1d_wino_params* p, int nf, hipStream_t stream);
@@ -621,7 +726,9 @@ int wino_dispatch_k11(const ov_conv1d_wino_params* p, int nf, hipStream_t stream
     const bool dbg = p->dbg != nullptr;                                                                                  \
     if (ovkw::wino_mw(p->Cout) == 4) OVW_DISPATCH_MW(KK, 4)                                                              \
     if (nf != 2) return OV_E_UNSUPPORTED;                                                                                \
-    OVW_DISPATCH_MW(KK, 2)                                                                                               \
+    if (ovkw::wino_mw(p->Cout) == 2) OVW_DISPATCH_MW(KK, 2)                                                              \
+    if constexpr (ovkw::wino_ci(KK, 1) != 0) OVW_DISPATCH_MW(KK, 1)                                                      \
+    return OV_E_UNSUPPORTED;                                                                                             \
   }
 
 }  // namespace ovkw

@@ -293,8 +293,17 @@ def pair_supported(C, K, dil):
 # Where the fused pair beats its two launches on MI355X (profiles/r02_s5_pair_vs_two_launches.txt, B = 32 x 10 s):
 # C = 32, k = 3: 0.91 vs 1.09 ms; C = 32, k = 7: 1.75 vs 1.85; C = 64, k = 3: 1.60 vs 1.64.  The MFMA-bound shapes
 # (C = 32 k = 11, C = 64 k = 7) run 4-9 % SLOWER fused (32 accumulator registers per wave instead of 64: less matrix
-# work per LDS operand) and stay on the two-launch path.
-PAIR_POLICY = {(32, 3), (32, 7), (64, 3)}
+# work per LDS operand) and stay on the two-launch path.  Round 6: at C = 64, k = 3 two Winograd-domain launches (0.56 +
+# 0.73 ms, profiles/r06_s17) beat the fused direct pair (1.62 ms), so that shape left the policy.
+PAIR_POLICY = {(32, 3), (32, 7)}
+
+
+def wino_policy(C, K, dil):
+    """Where a Winograd-domain launch (csrc/conv1d_wino.h) beats the direct conv it replaces (profiles/r06_s17, B = 32 x
+    10 s): every instance at C >= 64; at C = 32 (K = 11, one 32-row fragment per workgroup: the input transform is shared by
+    a single row fragment and its helper waves set the pace) the dilation-1 convs only (1.03 vs 1.21 ms; the dilated
+    instances tie with the direct kernel and lose in the residual form)."""
+    return C >= 64 or dil == 1
 
 
 def wn_fused_row_order(hidden):
@@ -465,9 +474,9 @@ class ConverterEngine:
                 pairs = []
                 for n, d in enumerate(rd):
                     w1 = w2 = None
-                    if _wino.supported(ch, ch, rk, d):
+                    if _wino.supported(ch, ch, rk, d) and wino_policy(ch, rk, d):
                         w1 = _wino.PackedConvWino(effective_weight(sd, f"{rb}.convs1.{n}"), sd[f"{rb}.convs1.{n}.bias"], dev, dil=d)
-                    if _wino.supported(ch, ch, rk, 1):
+                    if _wino.supported(ch, ch, rk, 1) and wino_policy(ch, rk, 1):
                         w2 = _wino.PackedConvWino(effective_weight(sd, f"{rb}.convs2.{n}"), sd[f"{rb}.convs2.{n}.bias"], dev, dil=1)
                     pairs.append((w1, w2))
                 stage.append(pairs)
@@ -510,7 +519,7 @@ class ConverterEngine:
         self.fuse_wn = True      # WaveNet layers as one launch each (ov_wn_layer_f32) where the shape has an instance
         self.wn_row_split = 0    # 0: the launcher splits a layer's rows over two launches for one or two utterances; 1: never
         self.fuse_pairs = True   # ResBlock pairs of the HBM-bound stages as one launch each (PAIR_POLICY)
-        # ResBlock convs of the MFMA-bound stages (C a multiple of 128) in the Winograd domain (ov_conv1d_wino_f32):
+        # ResBlock convs in the Winograd domain where wino_policy() says so (ov_conv1d_wino_f32):
         # fp32 arithmetic, 6 G / (4 K) of the direct form's multiplies, ~4x its rounding error
         self.use_winograd = True
         # opt-in fast generator: bf16 activations, fp32 accumulation (waveform within
@@ -979,7 +988,7 @@ class ConverterEngine:
                 cur = u
                 fused = self.fuse_pairs and L % 4 == 0 and all(
                     (ch, c1.K) in PAIR_POLICY and pair_supported(ch, c1.K, c1.dil) for c1, _ in pairs)
-                # Winograd-domain convs where an instance exists (C a multiple of 128); they carry the same
+                # Winograd-domain convs where an instance exists and wino_policy() picks it; they carry the same
                 # length-aware work lists (skip_padding) as the direct kernels
                 wn = self.wino_resblocks[i][j] if (self.use_winograd and L % 4 == 0) else None
                 for n, (c1, c2) in enumerate(pairs):

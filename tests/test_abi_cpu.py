@@ -341,9 +341,12 @@ def test_conv_wino_params_struct_matches_header_field_order():
     assert ctypes.sizeof(_lib.ConvWinoParams) == 6 * 8 + 4 * 8 + 10 * 4 + 2 * 4 + 8 + 8 + 2 * 4
     lib = _lib.load()
     assert lib.ov_conv1d_wino_f32(None, None) == -1
-    assert lib.ov_version() >= 207
+    assert lib.ov_version() >= 208
     assert [lib.ov_conv1d_wino_chunk(k, 128) for k in (3, 5, 7, 11)] == [16, 0, 8, 8]
-    assert [lib.ov_conv1d_wino_chunk(k, 64) for k in (3, 7, 11)] == [8, 4, 4] and lib.ov_conv1d_wino_chunk(11, 96) == 0
+    assert [lib.ov_conv1d_wino_chunk(k, 64) for k in (3, 7, 11)] == [8, 4, 4]
+    # one 32-row fragment per workgroup: K = 11 only (a two-channel chunk of K = 7 would be an odd number of k-steps)
+    assert [lib.ov_conv1d_wino_chunk(k, 32) for k in (3, 7, 11)] == [0, 0, 2] and lib.ov_conv1d_wino_chunk(11, 96) == 2
+    assert lib.ov_conv1d_wino_chunk(11, 48) == 0
 
 
 def test_header_abi_version_macro_matches_the_library():

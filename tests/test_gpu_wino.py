@@ -29,11 +29,11 @@ def _f64(x, w, b, K, slope, dil=1):
 
 
 @pytest.mark.parametrize("frags", [1, 2])
-@pytest.mark.parametrize("C,K", [(128, 11), (128, 7), (128, 3), (256, 11), (256, 3), (64, 11), (64, 7), (64, 3)])
-@pytest.mark.parametrize("B,L", [(2, 1000), (1, 128), (3, 132), (1, 4), (2, 260), (2, 516)])
+@pytest.mark.parametrize("C,K", [(128, 11), (128, 7), (128, 3), (256, 11), (256, 3), (64, 11), (64, 7), (64, 3), (32, 11), (96, 11)])
+@pytest.mark.parametrize("B,L", [(2, 1000), (1, 128), (3, 132), (1, 4), (2, 260), (2, 516), (2, 2060)])
 def test_wino_matches_float64_and_direct(C, K, B, L, frags):
-    if C == 64 and frags == 1:
-        pytest.skip("64-row layers run two fragments per wave")
+    if C < 128 and frags == 1:
+        pytest.skip("64- and 32-row layers run two fragments per wave")
     from openvoice_amd import wino
     from openvoice_amd.engine import launch_conv
     w, b, x, direct, wn, _ = _setup(C, K, B, L, seed=C + K + L)
@@ -49,8 +49,8 @@ def test_wino_matches_float64_and_direct(C, K, B, L, frags):
 
 
 @pytest.mark.parametrize("dil", [3, 5])
-@pytest.mark.parametrize("C,K", [(128, 11), (128, 7), (128, 3), (256, 11), (256, 7), (64, 11), (64, 7), (64, 3)])
-@pytest.mark.parametrize("B,L", [(2, 1000), (1, 252), (3, 244), (1, 4), (2, 512)])
+@pytest.mark.parametrize("C,K", [(128, 11), (128, 7), (128, 3), (256, 11), (256, 7), (64, 11), (64, 7), (64, 3), (32, 11)])
+@pytest.mark.parametrize("B,L", [(2, 1000), (1, 252), (3, 244), (1, 4), (2, 512), (2, 2000)])
 def test_dilated_wino_matches_float64_and_direct(C, K, B, L, dil):
     from openvoice_amd import wino
     from openvoice_amd.engine import launch_conv
@@ -83,11 +83,12 @@ def test_dilated_wino_forced_workgroup_counts_and_in_place_running_sum(dil):
         assert torch.equal(out, ref)
 
 
-@pytest.mark.parametrize("K,dil", [(11, 1), (7, 5), (3, 3)])
-def test_wino_64_row_layer_limits_and_workgroup_counts(K, dil):
-    """The two-row-fragment workgroup (two column sub-blocks): forced workgroup counts and a length-aware work list."""
+@pytest.mark.parametrize("C,K,dil", [(64, 11, 1), (64, 7, 5), (64, 3, 3), (32, 11, 1), (32, 11, 3), (32, 11, 5)])
+def test_wino_64_and_32_row_layer_limits_and_workgroup_counts(C, K, dil):
+    """The two- / one-row-fragment workgroups (two / four column sub-blocks): forced workgroup counts and a length-aware
+    work list."""
     from openvoice_amd import wino
-    C, B, L = 64, 3, 2100
+    B, L = 3, 2100 if C == 64 else 4300
     w, b, x, _, wn, _ = _setup(C, K, B, L, seed=77 + K, dil=dil)
     ref = torch.empty(B, C, L, device=DEV)
     wino.launch_conv_wino(wn, x, C * L, ref, C * L, B, L, in_slope=0.1)
@@ -96,7 +97,7 @@ def test_wino_64_row_layer_limits_and_workgroup_counts(K, dil):
         out = torch.full((B, C, L), float("nan"), device=DEV)
         wino.launch_conv_wino(wn, x, C * L, out, C * L, B, L, in_slope=0.1, nwg=nwg)
         assert torch.equal(out, ref)
-    ncol = 2 * (256 if dil == 1 else 4 * (64 // dil) * dil)
+    ncol = (128 // C) * (256 if dil == 1 else 4 * (64 // dil) * dil)
     lim = torch.tensor([0, ncol + 3, 5000], dtype=torch.int32, device=DEV)
     out = torch.full((B, C, L), float("nan"), device=DEV)
     wino.launch_conv_wino(wn, x, C * L, out, C * L, B, L, in_slope=0.1, col_limit=lim, col_limit_scale=1)
@@ -146,7 +147,8 @@ def test_wino_refuses_what_it_cannot_run():
         wino.launch_conv_wino(wn, x, 128 * 256, x, 128 * 256, 1, 256)            # out aliases x
     with pytest.raises(_lib.OvError):
         wino.launch_conv_wino(wn, x, 128 * 254, out, 128 * 254, 1, 254)          # L % 4
-    assert wino.supported(128, 128, 11, 3) and not wino.supported(128, 128, 11, 2) and not wino.supported(32, 32, 11, 1)
+    assert wino.supported(128, 128, 11, 3) and not wino.supported(128, 128, 11, 2) and not wino.supported(32, 32, 7, 1)
+    assert wino.supported(32, 32, 11, 1) and not wino.supported(48, 48, 11, 1)
 
 
 @pytest.mark.parametrize("K,dil", [(11, 1), (7, 3), (3, 5)])

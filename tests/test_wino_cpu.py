@@ -1,6 +1,6 @@
 """Host side of the Winograd-domain fp32 conv (csrc/conv1d_wino.h): the F(4, 3) matrices satisfy the
 minimal-filtering identity, the weight packer's sub-record order is what the kernel's matrix waves index, and the
-kernel's whole index algebra -- raw LDS rows, the per-tile input window, V[k-row][tile][6], A / B fragment lanes, the
+kernel's whole index algebra -- channel-pair interleaved raw LDS rows, the per-tile input window, V[k-step][tile][k-row][6], A / B fragment lanes, the
 accumulator layout and the 16-byte stores -- emulated lane by lane reproduces a float64 conv.  No GPU needed to get an
 offset wrong.  reference: openvoice/modules.py:296-309."""
 import numpy as np
@@ -40,7 +40,7 @@ def pack(w):
     return dst.numpy()
 
 
-@pytest.mark.parametrize("cout,cin,k", [(128, 32, 3), (128, 16, 7), (256, 24, 11), (64, 64, 11), (64, 16, 3)])
+@pytest.mark.parametrize("cout,cin,k", [(128, 32, 3), (128, 16, 7), (256, 24, 11), (64, 64, 11), (64, 16, 3), (32, 32, 11), (96, 6, 11)])
 def test_weight_packer_sub_record_order(cout, cin, k):
     lib = _lib.load()
     ci = lib.ov_conv1d_wino_chunk(k, cout)
@@ -66,9 +66,11 @@ def test_weight_packer_sub_record_order(cout, cin, k):
     assert lib.ov_conv1d_wino_supported(128, 128, 11, 1) == 1 and lib.ov_conv1d_wino_supported(128, 128, 11, 2) == 0
     assert lib.ov_conv1d_wino_supported(128, 128, 11, 5) == 1 and lib.ov_conv1d_wino_supported(256, 256, 3, 3) == 1
     assert lib.ov_conv1d_wino_supported(64, 64, 7, 1) == 1 and lib.ov_conv1d_wino_supported(32, 32, 7, 1) == 0
+    assert lib.ov_conv1d_wino_supported(32, 32, 11, 1) == 1 and lib.ov_conv1d_wino_supported(32, 32, 11, 5) == 1
 
 
-@pytest.mark.parametrize("k,cin,L,cout", [(11, 16, 260, 128), (7, 8, 128, 128), (3, 32, 132, 128), (11, 8, 520, 64), (3, 16, 260, 64)])
+@pytest.mark.parametrize("k,cin,L,cout", [(11, 16, 260, 128), (7, 8, 128, 128), (3, 32, 132, 128), (11, 8, 520, 64), (3, 16, 260, 64),
+                                          (11, 4, 260, 32)])
 def test_kernel_index_algebra_reproduces_the_conv(k, cin, L, cout):
     """One M-block (128 rows), the helper / matrix wave arithmetic of conv1d_wino_kernel replayed with numpy indexing
     exactly as the kernel forms its addresses (fp32 transforms, float64 accumulation so that only indices are on trial)."""
@@ -92,21 +94,28 @@ def test_kernel_index_algebra_reproduces_the_conv(k, cin, L, cout):
         y = np.zeros((nmt, 6, 32, 32))                    # [row fragment][p][row in fragment][tile n]
         y[:, 1] = bias.reshape(nmt, 32)[:, :, None]
         for c in range(nchunks):
-            raw = np.zeros((ci_chunk, RW), dtype=np.float32)
-            for idx in range(ci_chunk * RW // 4):         # staging vectors
-                row, c4 = divmod(idx, RW // 4)
+            # LDS images exactly as the kernel lays them out: raw[pair][raw index][channel of the pair] (item idx = one
+            # 4-column vector of BOTH channels at 8 idx floats), V[k-step = g * CI / 2 + pair][tile][channel of the pair][6]
+            npr = ci_chunk // 2
+            raw = np.zeros(ci_chunk * RW, dtype=np.float32)
+            for idx in range(npr * RW // 4):              # staging items
+                pr, c4 = divmod(idx, RW // 4)
                 t = t0 - 8 + 4 * c4
                 for e in range(4):
-                    if 0 <= t + e < L:
-                        v = x[c * ci_chunk + row, t + e]
-                        raw[row, 4 * c4 + e] = v if v > 0 else v * slope
-            V = np.zeros((kr, NT, 6), dtype=np.float32)
-            for idx in range(ci_chunk * NT):              # transform items
-                tl, cil = idx & 31, idx >> 5
-                win = raw[cil, wstart + 4 * tl: wstart + 4 * tl + 4 * nb128]
-                for g in range(G):
-                    o = off0 - wstart + 3 * g
-                    V[g * ci_chunk + cil, tl] = bt @ win[o:o + 6]
+                    for ch in range(2):
+                        if 0 <= t + e < L:
+                            v = x[c * ci_chunk + 2 * pr + ch, t + e]
+                            raw[8 * idx + 2 * e + ch] = v if v > 0 else v * slope
+            V = np.zeros(kr * NT * 6, dtype=np.float32)
+            for idx in range(npr * NT):                   # transform items
+                tl, pr = idx & 31, idx >> 5
+                src = 2 * (pr * RW + wstart + 4 * tl)     # float offset of the window (kernel: tsrc / 4)
+                for ch in range(2):
+                    win = raw[src + ch: src + ch + 8 * nb128: 2]
+                    for g in range(G):
+                        o = off0 - wstart + 3 * g
+                        dst = 12 * ((g * npr + pr) * NT + tl) + 6 * ch
+                        V[dst:dst + 6] = bt @ win[o:o + 6]
             for wave in range(nmt):                        # matrix waves: sub-records -> A fragments, V -> B fragments
                 mt = wave
                 base = (mt * nchunks + c) * npair * 3
@@ -116,8 +125,8 @@ def test_kernel_index_algebra_reproduces_the_conv(k, cin, L, cout):
                         e = s2 * 6 + q
                         sub = packed[(base + sp * 3 + (e >> 2)) * 256:(base + sp * 3 + (e >> 2) + 1) * 256].reshape(64, 4)
                         a = sub[:, e & 3]                  # lane -> A[row = lane & 31][k = lane >> 5]
-                        for half in range(2):
-                            b = V[2 * s + half, :, q]      # lane (half, n) -> B[k = half][n]
+                        for half in range(2):              # lane (half, n) -> B[k = half][n] at (s NT + n) 12 + 6 half + q
+                            b = V[12 * s * NT + 6 * half + q: 12 * (s + 1) * NT: 12]
                             y[wave, q] += np.outer(a[32 * half:32 * half + 32].astype(np.float64), b.astype(np.float64))
         o = np.einsum("ip,wprn->wrni", at, y)              # [wave][row][tile n][i]
         for wave in range(nmt):
@@ -132,7 +141,7 @@ def test_kernel_index_algebra_reproduces_the_conv(k, cin, L, cout):
 
 
 @pytest.mark.parametrize("k,dil,cin,L,cout", [(11, 3, 8, 300, 128), (11, 5, 8, 244, 128), (7, 5, 8, 100, 128), (3, 3, 16, 256, 128),
-                                              (11, 3, 4, 600, 64), (7, 5, 8, 488, 64)])
+                                              (11, 3, 4, 600, 64), (7, 5, 8, 488, 64), (11, 5, 4, 1000, 32), (11, 3, 2, 2100, 32)])
 def test_dilated_kernel_index_algebra_reproduces_the_conv(k, dil, cin, L, cout):
     """Dilated instances (two fragments per wave): tile n = rc * J + jt holds the outputs rc + dil (4 jt + i) of a
     4 J dil-column block; raw rows start PADA columns before the block; a tile reads 3 (G - 1) + 6 inputs dil apart; the
@@ -142,7 +151,7 @@ def test_dilated_kernel_index_algebra_reproduces_the_conv(k, dil, cin, L, cout):
     ci_chunk = lib.ov_conv1d_wino_chunk(k, cout)
     G = (k + 2) // 3
     NTS = 64                       # tiles per sub-block (one matrix wave's two fragments)
-    NB = 4 // (cout // 32) if cout == 64 else 1     # sub-blocks per workgroup: 2 on a 64-row layer
+    NB = {32: 4, 64: 2}.get(cout, 1)   # sub-blocks per workgroup: 2 on a 64-row layer, 4 on a 32-row layer
     NT = NTS * NB
     J = NTS // dil
     ncols = 4 * J * dil            # columns per sub-block
@@ -168,25 +177,29 @@ def test_dilated_kernel_index_algebra_reproduces_the_conv(k, dil, cin, L, cout):
         y = np.zeros((nmt, 6, 32, NT))
         y[:, 1] = bias.reshape(nmt, 32)[:, :, None]
         for c in range(nchunks):
-            raw = np.zeros((ci_chunk, rw), dtype=np.float32)
-            for idx in range(ci_chunk * rw // 4):
-                row, c4 = divmod(idx, rw // 4)
+            npr = ci_chunk // 2
+            raw = np.zeros(ci_chunk * rw, dtype=np.float32)   # raw[pair][raw index][channel of the pair]
+            for idx in range(npr * rw // 4):
+                pr, c4 = divmod(idx, rw // 4)
                 t = t0 - pada + 4 * c4
                 for e in range(4):
-                    if 0 <= t + e < L:
-                        v = x[c * ci_chunk + row, t + e]
-                        raw[row, 4 * c4 + e] = v if v > 0 else v * slope
-            V = np.zeros((kr, NT, 6), dtype=np.float32)
-            for idx in range(ci_chunk * NT):
-                tile, cil = idx & (NT - 1), idx // NT
+                    for ch in range(2):
+                        if 0 <= t + e < L:
+                            v = x[c * ci_chunk + 2 * pr + ch, t + e]
+                            raw[8 * idx + 2 * e + ch] = v if v > 0 else v * slope
+            V = np.zeros(kr * NT * 6, dtype=np.float32)       # V[k-step][tile][channel of the pair][6]
+            for idx in range(npr * NT):
+                tile, pr = idx & (NT - 1), idx // NT
                 sub, tl = divmod(tile, NTS)
                 rc0 = tl // J
                 rc, jt = (rc0, tl - rc0 * J) if rc0 < dil else (0, 0)
-                s0 = (pada - padd) + sub * ncols + rc + 4 * dil * jt
-                win = raw[cil, s0: s0 + dil * nv: dil]
-                assert win.size == nv
-                for g in range(G):
-                    V[g * ci_chunk + cil, tile] = bt @ win[3 * g: 3 * g + 6]
+                s0 = 2 * (pr * rw + (pada - padd) + sub * ncols + rc + 4 * dil * jt)
+                for ch in range(2):
+                    win = raw[s0 + ch: s0 + ch + 2 * dil * nv: 2 * dil]
+                    assert win.size == nv
+                    for g in range(G):
+                        dst = 12 * ((g * npr + pr) * NT + tile) + 6 * ch
+                        V[dst:dst + 6] = bt @ win[3 * g: 3 * g + 6]
             for wave in range(nmt):
                 base = (wave * nchunks + c) * npair * 3
                 for s in range(kr // 2):
@@ -196,7 +209,8 @@ def test_dilated_kernel_index_algebra_reproduces_the_conv(k, dil, cin, L, cout):
                         sub = packed[(base + sp * 3 + (e >> 2)) * 256:(base + sp * 3 + (e >> 2) + 1) * 256].reshape(64, 4)
                         a = sub[:, e & 3]
                         for half in range(2):
-                            y[wave, q] += np.outer(a[32 * half:32 * half + 32].astype(np.float64), V[2 * s + half, :, q].astype(np.float64))
+                            b = V[12 * s * NT + 6 * half + q: 12 * (s + 1) * NT: 12]
+                            y[wave, q] += np.outer(a[32 * half:32 * half + 32].astype(np.float64), b.astype(np.float64))
         o = np.einsum("ip,wprn->wrni", at, y)              # [row fragment][row][tile][i]
         for sub in range(NB):                              # each matrix wave stages its own sub-block
             stage = np.full((nmt, 32, 256), np.nan)        # (the kernel walks it 8 rows at a time)

@@ -95,11 +95,11 @@ def main():
     sd = synthetic_state_dict(CONVERTER_MODEL_CONFIG, 513, seed=1234)
     shapes = [(128, 11, 1)]
     if args.shapes:
-        shapes += [(C, K, d) for C in (128, 256, 64) for K in (3, 7, 11) for d in (1, 3, 5)
+        shapes += [(C, K, d) for C in (128, 256, 64, 32) for K in (3, 7, 11) for d in (1, 3, 5)
                    if (C, K, d) != (128, 11, 1) and wino.supported(C, C, K, d)]
     rows = []
     for C, K, d in shapes:
-        L = args.frames * {256: 8, 128: 64, 64: 128}[C]
+        L = args.frames * {256: 8, 128: 64, 64: 128, 32: 256}[C]
         row = one_shape(sd, C, K, d, args.batch, L, args.reps, with_res=args.res, frags=args.frags)
         rows.append(row)
         c, s = row["calibrated"], row["stress_gain4"]

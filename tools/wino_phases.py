@@ -23,14 +23,16 @@ def main():
     ap.add_argument("--C", type=int, default=128)
     ap.add_argument("--K", type=int, default=11)
     ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--L", type=int, default=55104)
+    ap.add_argument("--L", type=int, default=0, help="columns (default: the generator stage of C at 861 frames)")
+    ap.add_argument("--dil", type=int, default=1)
     ap.add_argument("--res", action="store_true")
     ap.add_argument("--frags", type=int, default=0)
     args = ap.parse_args()
-    C, K, B, L = args.C, args.K, args.batch, args.L
+    C, K, B = args.C, args.K, args.batch
+    L = args.L or 861 * {256: 8, 128: 64, 64: 128, 32: 256}[C]
     gen = torch.Generator().manual_seed(0)
     w = torch.randn(C, C, K, generator=gen) * (C * K) ** -0.5
-    layer = wino.PackedConvWino(w, torch.zeros(C), DEV)
+    layer = wino.PackedConvWino(w, torch.zeros(C), DEV, dil=args.dil)
     x = torch.randn(B, C, L, generator=gen).to(DEV)
     out = torch.empty_like(x)
     res = torch.randn(B, C, L, generator=gen).to(DEV) if args.res else None
@@ -50,9 +52,10 @@ def main():
     chunks = d[:, :, 7:8].clamp_min(1)
     per = (d / chunks).mean(0)             # [6 waves][8]
     G = (K + 2) // 3
-    ci = {3: 16, 7: 8, 11: 8}[K]
+    from openvoice_amd import _lib
+    ci = _lib.call("ov_conv1d_wino_chunk", K, C)
     mfma_cycles = ci * G // 2 * 6 * 64 * nf
-    rec = {"tool": "wino_phases", "C": C, "K": K, "B": B, "L": L, "res": args.res, "frags": nf, "ms": ms,
+    rec = {"tool": "wino_phases", "C": C, "K": K, "dil": args.dil, "B": B, "L": L, "res": args.res, "frags": nf, "ms": ms,
            "mfma_issue_cycles_per_chunk": mfma_cycles, "workgroups": int(live.sum().item()),
            "matrix_ticks_per_chunk": {k: round(per[:4, i].mean().item()) for i, k in enumerate(["k_loops", "barrier", "epilogue", "item_setup"])},
            "helper_ticks_per_chunk": {k: round(per[4:4 + nh, i].mean().item()) for i, k in enumerate(["stage_issue", "transform", "raw_write", "barrier"])}}
