@@ -306,6 +306,22 @@ def wino_policy(C, K, dil):
     return C >= 64 or dil == 1
 
 
+# A Winograd launch deals (utterance, column block, row block) items to ONE workgroup per CU; below about half of the
+# chip's CUs in items the direct kernel's small tiles fill the machine better (profiles/r06_s20, r06_s21: generator stage 0,
+# C = 256, 6 888 columns -- batch 1: 54 items, Winograd 0.45-0.6x the direct conv; batch 2: 108 items, 0.8-1.0x; batch 3:
+# 162 items, ahead; batch 4: 216 items, 1.4-1.7x as at batch 32; every other stage has >= 216 items at batch 1 and runs
+# 1.1-1.65x faster).  Batch 1 with the rule: 7.50 -> 6.18 ms.
+WINO_MIN_ITEMS = 136
+
+
+def wino_items(cout, dil, B, L):
+    """Work items of one ov_conv1d_wino_f32 launch (csrc/conv1d_wino.h: 256 columns per matrix wave at dilation 1,
+    4 * (64 // dil) * dil at dilation dil; 4 / MW column sub-blocks per workgroup)."""
+    mw = 4 if cout % 128 == 0 else (2 if cout % 64 == 0 else 1)
+    ncol = (256 if dil == 1 else 4 * (64 // dil) * dil) * (4 // mw)
+    return B * ((L + ncol - 1) // ncol) * (cout // (32 * mw))
+
+
 def wn_fused_row_order(hidden):
     """Gate row order of the fused WaveNet-layer kernel (``ov_wn_layer_f32``, include/openvoice_amd.h): 16-row block
     q holds, at rows 4j + {0, 1, 2, 3}, the tanh rows of channels 8q + j and 8q + j + 4, then their sigmoid rows, so
@@ -1003,6 +1019,10 @@ class ConverterEngine:
                         self._pair(c1, c2, cur, dst, bs, B, L, add, scale, **lim(rate))
                     else:
                         w1, w2 = wn[n] if wn is not None else (None, None)
+                        if w1 is not None and wino_items(ch, w1.dil, B, L) < WINO_MIN_ITEMS:
+                            w1 = None           # too few items for one workgroup per CU: the direct kernel's small tiles
+                        if w2 is not None and wino_items(ch, 1, B, L) < WINO_MIN_ITEMS:
+                            w2 = None
                         if w1 is not None:
                             self._wino(w1, cur, t1_, bs, B, L, **lim(rate))
                         else:

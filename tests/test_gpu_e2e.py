@@ -110,7 +110,10 @@ def test_benchmark_size_properties_round_trip_and_batch_independence(synth_sd):
     so checked through properties that do not depend on size:
       * the flow is a bijection: with sid_src == sid_tgt, forward then reverse must return z (z_hat == z);
       * utterances are independent (the sharding argument of the multi-GPU path): item b of the batch-32 run
-        is bit-identical to a batch-1 run of the same item;
+        equals a batch-1 run of the same item -- bit for bit within one kernel family (``use_winograd = False``: the
+        direct convs), and within 1e-4 (measured ~1e-5) under the default launch policy, which picks the conv ALGORITHM
+        by launch size (engine.WINO_MIN_ITEMS: generator stage 0 runs the direct kernel at batch 1-2, the Winograd-domain
+        kernel from batch 3 on), as the reference's own backend does;
       * re-running the same batch is bit-identical (no races, no uninitialised reads);
       * masks: positions >= length are exactly zero in z and z_hat."""
     B, T = 32, 861
@@ -133,7 +136,18 @@ def test_benchmark_size_properties_round_trip_and_batch_independence(synth_sd):
     assert torch.equal(o1, o2), "same batch twice must be bit-identical"
     for b in (0, 5, 31):
         ob = model.voice_conversion(spec[b:b + 1], lengths[b:b + 1].to(DEV), g, g, tau=0.3, noise=noise[b:b + 1])[0]
-        assert torch.equal(ob[0], o1[b]), f"item {b}: batch-32 and batch-1 results differ"
+        err_b = (ob[0] - o1[b]).abs().max().item()
+        assert err_b <= 1e-4, f"item {b}: batch-32 and batch-1 results differ by {err_b}"
+    eng = model.engine()
+    eng.use_winograd = False
+    try:
+        od = model.voice_conversion(spec, lengths.to(DEV), g, g, tau=0.3, noise=noise)[0]
+        assert (od - o1).abs().max().item() <= 1e-4        # the two conv algorithms agree far inside the path's 1e-3
+        for b in (0, 31):
+            ob = model.voice_conversion(spec[b:b + 1], lengths[b:b + 1].to(DEV), g, g, tau=0.3, noise=noise[b:b + 1])[0]
+            assert torch.equal(ob[0], od[b]), f"item {b}: batch-32 and batch-1 results of the direct kernels differ"
+    finally:
+        eng.use_winograd = True
 
 
 def test_tone_color_converter_api_end_to_end_from_files(tmp_path, synth_sd):

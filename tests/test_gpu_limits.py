@@ -188,7 +188,9 @@ def test_large_batches_at_and_beyond_the_prefix_table(synth_sd):
         for b in (0, 1, B // 2, B - 1):
             n = int(lengths[b])
             one = model.voice_conversion(spec[b:b + 1, :, :], lengths[b:b + 1], g, g, tau=0.3, noise=noise[b:b + 1])[0]
-            assert torch.equal(o[b, :, :256 * n], one[0, :, :256 * n]), (B, b)
+            # (not bit for bit: the launch policy picks the conv algorithm by launch size, engine.WINO_MIN_ITEMS -- a
+            # batch-1 conversion of 40 frames runs the direct kernels where the batch of 256 runs the Winograd-domain ones)
+            assert (o[b, :, :256 * n] - one[0, :, :256 * n]).abs().max().item() <= 1e-4, (B, b)
             if B <= 256:
                 assert (o[b, :, 256 * n:] == 0).all()
 
