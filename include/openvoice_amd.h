@@ -519,7 +519,7 @@ int ov_split3_to_f32(const uint16_t* a, const uint16_t* b, const uint16_t* c, in
 /* ---- Winograd-domain fp32 Conv1d (round 6; openvoice_amd/csrc/conv1d_wino.h) --------------------------------------
  * The stride-1 'same' convs of ResBlock1, reference openvoice/modules.py:296-306 -- xt = c1(lrelu(x)), xt = c2(lrelu(xt)),
  * x = xt + x -- and the MRF sum / mean of models.py:280-286, with fewer executed multiplies than the direct form:
- *   out = (conv1d(lrelu(x, in_slope), w, dilation dil) + bias [+ res] [+ add]) * scale
+ *   out = lrelu((conv1d(lrelu(x, in_slope), w, dilation dil) + bias [+ res] [+ add]) * scale, out_slope)
  * evaluated as ceil(K/3) shifted 3-tap groups by the minimal-filtering algorithm F(4, 3) (interpolation points 0, +-1, +-2,
  * infinity): weights transformed once in float64 at pack time, input tiles transformed in fp32 on the way into LDS, the
  * products of all groups and input channels accumulated in the transform domain on v_mfma_f32_32x32x2_f32 (six GEMMs,
@@ -552,7 +552,9 @@ typedef struct ov_conv1d_wino_params {
                           * column blocks that start at or beyond col_limit[b] * col_limit_scale are neither computed
                           * nor written, what is computed is bit-identical to the full launch; B <= 256, else ignored */
   int32_t col_limit_scale;
-  int32_t reserved0;
+  float out_slope;       /* leaky-ReLU slope applied to the RESULT before it is stored (the first conv of a ResBlock pair hands
+                          * its consumer an activated tensor, which then stages it with in_slope = 1); 0 or 1 = none; only
+                          * without res / add.  (2.09: this field was `reserved0`.) */
 } ov_conv1d_wino_params;
 int ov_conv1d_wino_f32(const ov_conv1d_wino_params* p, ov_stream_t stream);
 /* 1 when (Cin, Cout, K, dil) has an instance, else 0 (callers then use ov_conv1d_f32). */
@@ -574,7 +576,8 @@ int ov_conv1d_wino_pack_f32(const float* w, int Cout, int Cin, int K, float* dst
  * ov_conv1d_split3_params.col_limit / col_limit_scale.  2.05: ov_wn_layer_params.acts / row_split (the field that
  * was `reserved`; the struct grew by one pointer at its end).  2.06: ov_polyphase_fir_f32.  2.07: ov_conv1d_wino_f32 (+ _supported, _chunk,
  * _pack_size, _pack_f32).  2.08: ov_conv1d_wino_f32 instances for Cout % 32 == 0 at K = 11 (one 32-row fragment per
- * workgroup; ov_conv1d_wino_chunk(11, 32) = 2 where 2.07 returned 0).  The Python binding
+ * workgroup; ov_conv1d_wino_chunk(11, 32) = 2 where 2.07 returned 0).  2.09: ov_conv1d_wino_params.out_slope (the field that
+ * was `reserved0`: same size and offset, 0 = none).  The Python binding
  * refuses a library older than the entry points it calls (openvoice_amd/_lib.py MIN_VERSION). */
 int ov_version(void);
 /* The version THIS header describes.  Parameter structs grow at their END in minor versions (2.04, 2.05, 2.07 did): a
@@ -584,7 +587,7 @@ int ov_version(void);
  * tests/test_abi_cpu.py).  A struct is never reordered and a field never changes meaning within a major version, with
  * one exception stated here: 2.05 renamed ov_wn_layer_params.reserved to row_split AND appended `acts`, so a caller
  * built against 2.04 or older is NOT binary compatible with 2.05+ for that struct. */
-#define OV_ABI_VERSION 208
+#define OV_ABI_VERSION 209
 /* 0 for a production build; non-zero = a measurement build with parts of the kernels compiled out (results are
  * meaningless; openvoice_amd/_lib.py refuses to load it unless OPENVOICE_AMD_ALLOW_EXPERIMENT=1). */
 int ov_build_experiment(void);

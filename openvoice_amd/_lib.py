@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OPENVOICE_AMD_LIB") or os.path.join(_HERE, "libopenvoice_amd.so")
 
 OV_OK = 0
-MIN_VERSION = 208     # ov_version() of the newest entry point this package calls (include/openvoice_amd.h)
+MIN_VERSION = 209     # ov_version() of the newest entry point this package calls (include/openvoice_amd.h)
 OV_ERRORS = {-1: "OV_E_BADARG", -2: "OV_E_UNSUPPORTED", -3: "OV_E_ALIGN", -4: "OV_E_LAUNCH"}
 
 EPI_LINEAR, EPI_GATE, EPI_RESSKIP, EPI_COUPLE, EPI_POSTERIOR, EPI_CONVT, EPI_MAGNITUDE = range(7)
@@ -109,7 +109,7 @@ class ConvWinoParams(ctypes.Structure):
                 ("x_ld", ctypes.c_int32), ("out_ld", ctypes.c_int32), ("K", ctypes.c_int32), ("dil", ctypes.c_int32),
                 ("nwg", ctypes.c_int32), ("frags", ctypes.c_int32),
                 ("in_slope", ctypes.c_float), ("scale", ctypes.c_float), ("dbg", _fp),
-                ("col_limit", _fp), ("col_limit_scale", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
+                ("col_limit", _fp), ("col_limit_scale", ctypes.c_int32), ("out_slope", ctypes.c_float)]
 
 
 class WnLayerParams(ctypes.Structure):

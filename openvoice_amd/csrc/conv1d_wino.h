@@ -41,10 +41,21 @@ __device__ __forceinline__ uint32_t lds_addr(const void* ptr) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)ptr;
 }
 
+// Workgroup barrier for data exchanged through LDS only: __syncthreads() also waits for every outstanding GLOBAL load of
+// the wave (vmcnt(0): the release fence of a workgroup-scope barrier) -- for a matrix wave that is its weight prefetch (an L2
+// round trip issued a k-step earlier), for a helper the staging vectors it requested two chunks ahead on purpose.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int OFF>
 __device__ __forceinline__ void lds_write_b32(uint32_t addr, float v) {
   static_assert(OFF >= 0 && OFF < 65536, "DS immediate offset");
   asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+// two dwords from two registers that need not be neighbours, at addr + 256 O0 and addr + 256 O1 bytes
+template <int O0, int O1>
+__device__ __forceinline__ void lds_write2st64_b32(uint32_t addr, float a, float b) {
+  static_assert(O0 >= 0 && O0 < 256 && O1 >= 0 && O1 < 256, "DS write2st64 offsets are 8-bit, in units of 64 dwords");
+  asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(a), "v"(b), "n"(O0), "n"(O1) : "memory");
 }
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -98,7 +109,8 @@ __host__ __device__ inline size_t wino_pack_floats(int Cout, int Cin, int K, int
 // phase timers (DBG instances only: the dispatcher selects them when ov_conv1d_wino_params.dbg is set)
 #ifndef OVW_EXP
 #define OVW_EXP 0   // measurement builds only (scripts/exp_wino.sh): 1 = MFMAs replaced by one FMA; 2 = helper transform skipped;
-                    // 3 = no weight stream (the first fragments of an item are reused); 4 = no epilogue stores
+                    // 3 = no weight stream (the first fragments of an item are reused); 4 = no epilogue stores; 5 = no B-operand
+                    // reads inside the k-loop (the chunk's first operands are reused); 6 = helpers idle (barriers only)
 #endif
 #define OVW_MARK(q)                                                \
   if constexpr (DBG) {                                             \
@@ -321,7 +333,11 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
     // raw[buf] -> V[buf]: item = (channel pair, tile); V[k-row = g * CI + 2 pair + channel][tile][6]
     constexpr int ROUNDS = NPR * NT / (64 * NHELP);
     static_assert(NPR * NT % (64 * NHELP) == 0, "whole rounds of helper lanes");
-    uint32_t tsrc[ROUNDS], tdst[ROUNDS];   // loop-invariant byte offsets of a lane's items: raw window, V record of group 0
+    // loop-invariant byte offsets of a lane's items: the raw window, and -- per V buffer and point -- the LDS address of the
+    // pair's first channel's record of group 0 (12 registers per round that a helper has to spare: the stores below then
+    // need no address arithmetic at all)
+    uint32_t tsrc[ROUNDS], vadr[2][ROUNDS][6];
+    static_assert((NT * 24) % 256 == 0 && (CI * NT * 24) % 256 == 0, "channel / group record distances in 256-byte units");
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
       const int idx = r * (64 * NHELP) + hl;
@@ -334,11 +350,14 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
         const int rc0 = tl / Gd::J, rc = rc0 < DIL ? rc0 : 0, jt = rc0 < DIL ? tl - rc0 * Gd::J : 0;
         tsrc[r] = 8u * (uint32_t)(pr * RW + (Gd::PADA - Gd::PADD) + sub * NCOLS + rc + 4 * DIL * jt);
       }
-      tdst[r] = 24u * (uint32_t)(2 * pr * NT + tile);
+#pragma unroll
+      for (int bf = 0; bf < 2; ++bf)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) vadr[bf][r][q] = v_lds + (uint32_t)bf * (VBUF * 4) + 24u * (uint32_t)(2 * pr * NT + tile) + 4u * q;
     }
-    auto transform = [&](int buf) {
+    auto transform = [&](auto bufc) {
+      constexpr int buf = decltype(bufc)::value;
       const char* src = reinterpret_cast<const char*>(raw) + buf * (RAWBUF * 4);
-      const uint32_t dst = v_lds + (uint32_t)buf * (VBUF * 4);
 #pragma unroll
       for (int r = 0; r < ROUNDS; ++r) {
         constexpr int NWIN = DIL == 1 ? 4 * Ge::NB128 : Gd::NV;
@@ -368,24 +387,24 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
           const f32x2 v3 = __builtin_elementwise_fma(c2, t4, t3);
           const f32x2 v4 = __builtin_elementwise_fma(m2, t4, t3);
           const f32x2 v5 = __builtin_elementwise_fma(c4, d1, __builtin_elementwise_fma(m5, d3, d5));
-          // V[k-row g CI + 2 pr + channel][tile][6]: the records of the pair's channels are NT * 24 bytes apart; everything
-          // but the lane's item offset is an immediate (ds_write_b32 offsets reach 64 KiB)
-          constexpr int OA = g * CI * NT * 24, OB = OA + NT * 24;
-          const uint32_t ad = dst + tdst[r];
-          lds_write_b32<OA>(ad, v0[0]);      lds_write_b32<OB>(ad, v0[1]);
-          lds_write_b32<OA + 4>(ad, v1[0]);  lds_write_b32<OB + 4>(ad, v1[1]);
-          lds_write_b32<OA + 8>(ad, v2[0]);  lds_write_b32<OB + 8>(ad, v2[1]);
-          lds_write_b32<OA + 12>(ad, v3[0]); lds_write_b32<OB + 12>(ad, v3[1]);
-          lds_write_b32<OA + 16>(ad, v4[0]); lds_write_b32<OB + 16>(ad, v4[1]);
-          lds_write_b32<OA + 20>(ad, v5[0]); lds_write_b32<OB + 20>(ad, v5[1]);
+          // V[k-row g CI + 2 pr + channel][tile][6]: the records of the pair's channels are NT * 24 bytes apart, those of
+          // consecutive groups CI * NT * 24 -- both whole multiples of 256 bytes, i.e. the two offsets of a
+          // ds_write2st64_b32: ONE store per point writes both channels' values from their (non-adjacent) registers
+          constexpr int OA = g * CI * NT * 24 / 256, OB = OA + NT * 24 / 256;
+          if constexpr (buf == 0) {
+            lds_write2st64_b32<OA, OB>(vadr[0][r][0], v0[0], v0[1]); lds_write2st64_b32<OA, OB>(vadr[0][r][1], v1[0], v1[1]);
+            lds_write2st64_b32<OA, OB>(vadr[0][r][2], v2[0], v2[1]); lds_write2st64_b32<OA, OB>(vadr[0][r][3], v3[0], v3[1]);
+            lds_write2st64_b32<OA, OB>(vadr[0][r][4], v4[0], v4[1]); lds_write2st64_b32<OA, OB>(vadr[0][r][5], v5[0], v5[1]);
+          } else {
+            lds_write2st64_b32<OA, OB>(vadr[1][r][0], v0[0], v0[1]); lds_write2st64_b32<OA, OB>(vadr[1][r][1], v1[0], v1[1]);
+            lds_write2st64_b32<OA, OB>(vadr[1][r][2], v2[0], v2[1]); lds_write2st64_b32<OA, OB>(vadr[1][r][3], v3[0], v3[1]);
+            lds_write2st64_b32<OA, OB>(vadr[1][r][4], v4[0], v4[1]); lds_write2st64_b32<OA, OB>(vadr[1][r][5], v5[0], v5[1]);
+          }
         });
       }
     };
     // the LDS stores above are inline assembly the compiler's counters do not see: drain them before every barrier
-    auto hand_over = [&]() {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __syncthreads();
-    };
+    auto hand_over = [&]() { lds_barrier(); };
 
     unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = DBG ? __builtin_readcyclecounter() : 0ull;
@@ -395,7 +414,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
     write_raw(0, S0{});           // chunk 0
     issue_loads(S1{});            // chunk 1 in set 1
     hand_over();                  // (A) raw[0] complete
-    transform(0);
+    transform(std::integral_constant<int, 0>{});
     write_raw(1, S1{});
     issue_loads(S0{});            // chunk 2 in set 0
     hand_over();                  // (B) V[0], raw[1] complete
@@ -404,11 +423,11 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
     // chunk i + 2 (set i & 1, requested a period ago) to raw[i & 1]; nothing is requested beyond the stream's end
     auto period = [&](int i, auto par) {
       constexpr int P = decltype(par)::value;
-      issue_loads(std::integral_constant<int, 1 - P>{});
+      if (OVW_EXP != 6) issue_loads(std::integral_constant<int, 1 - P>{});
       OVW_MARK(0)
-      if (OVW_EXP != 2 && i + 1 < nstream) transform(1 - P);
+      if (OVW_EXP != 2 && OVW_EXP != 6 && i + 1 < nstream) transform(std::integral_constant<int, 1 - P>{});
       OVW_MARK(1)
-      write_raw(P, par);
+      if (OVW_EXP != 6) write_raw(P, par);
       OVW_MARK(2)
       hand_over();                // V[(i + 1) & 1] and raw[i & 1] handed over; V[i & 1] free again
       OVW_MARK(3)
@@ -467,18 +486,31 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
     }
 
     OVW_MARK(3)
+    // B operands: ONE register set, refilled in place -- the two points of pair qq are read for the next k-step (of this chunk
+    // or step 0 of the item's next one) right after the MFMAs that consumed them have issued (4 NF MFMAs = 256 NF cycles later
+    // they are needed again).  Filled here for the item's first chunk (the set is not kept across the epilogue: its twelve
+    // registers are part of the operand ring there).
+    f32x2 bq[NF][3];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int qq = 0; qq < 3; ++qq) bq[f][qq] = *reinterpret_cast<const f32x2*>(Vs + (it & 1) * VBUF + voffB + f * (32 * 6) + 2 * qq);
     for (int chunk = 0; chunk < nchunks; ++chunk, ++it) {
       const float* vb = Vs + (it & 1) * VBUF + voffB;
-      // B operands: ONE register set, refilled in place -- the two points of pair qq are read for k-step s + 1 right after
-      // the MFMAs of k-step s that consumed them have issued (4 NF MFMAs = 256 NF cycles later they are needed again)
-      f32x2 bq[NF][3];
-#pragma unroll
-      for (int f = 0; f < NF; ++f)
-#pragma unroll
-        for (int qq = 0; qq < 3; ++qq) bq[f][qq] = *reinterpret_cast<const f32x2*>(vb + f * (32 * 6) + 2 * qq);
+      const float* vbn = Vs + ((it + 1) & 1) * VBUF + voffB;   // the item's next chunk
+      const bool more_chunks = chunk + 1 < nchunks;
 #pragma unroll
       for (int s = 0; s < NSTEP; ++s) {
         const int s2 = s & 1;
+        if (s == NSTEP - 1) {
+          // The chunk hand-over sits BEFORE the last k-step, not after it: that step's B operands are in registers already
+          // (nothing reads V[it & 1] from LDS any more), so the helpers may start overwriting it, and the first operands of
+          // the next chunk are read behind this step's MFMAs instead of in a bubble after the barrier -- measured with idle
+          // helpers a chunk cost its MFMA issue time + ~1 100 cycles whatever its length (profiles/r06_s24)
+          OVW_MARK(0)
+          lds_barrier();
+          OVW_MARK(1)
+        }
         if (s2 == 0) {
           rec += 3;   // the sub-records after the last real pair are zeros written by the packer
 #pragma unroll
@@ -500,10 +532,10 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
             }
           }
           __builtin_amdgcn_sched_barrier(0);
-          if (s + 1 < NSTEP) {
+          if (OVW_EXP != 5 && (s + 1 < NSTEP || more_chunks)) {
 #pragma unroll
             for (int f = 0; f < NF; ++f)
-              bq[f][qq] = *reinterpret_cast<const f32x2*>(vb + (s + 1) * (2 * NT * 6) + f * (32 * 6) + 2 * qq);
+              bq[f][qq] = *reinterpret_cast<const f32x2*>((s + 1 < NSTEP ? vb + (s + 1) * (2 * NT * 6) : vbn) + f * (32 * 6) + 2 * qq);
           }
         }
         if (s2 == 1) {
@@ -511,9 +543,6 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
           for (int j = 0; j < 3; ++j) a_cur[j] = a_nxt[j];
         }
       }
-      OVW_MARK(0)
-      __syncthreads();
-      OVW_MARK(1)
     }
 
     // next work item: its first weight pair and bias are in flight while this item's epilogue runs
@@ -536,6 +565,8 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
     // sets), and launches without operands (every first conv of a pair) take a variant with no loads at all.
     {
       const float scale = p.scale;
+      const float oslope = p.out_slope;
+      const bool act_out = oslope < 1.f;      // (launcher: 0 < out_slope <= 1, < 1 only without res / add)
       float* outb = p.out + (int64_t)ob * p.out_bstride;
       const float* resb = p.res ? p.res + (int64_t)ob * p.res_bstride : nullptr;
       const float* addb = p.add ? p.add + (int64_t)ob * p.add_bstride : nullptr;
@@ -566,7 +597,9 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
             voff[f] = 4u * (uint32_t)half * LD + (colok[f] ? col : 0u);
           }
           const size_t mrow = (size_t)omtile * 32u;
-          // operand ring: the rows of DEPTH - 1 groups are in flight while one is consumed (32 registers of operands)
+          // operand ring: the rows of DEPTH - 1 groups are in flight while one is consumed (32 registers of operands).  A ramped
+          // ring that grows into the accumulator registers each consumed group frees was tried (round 6): hipcc does not
+          // reuse the freed elements of the 16-register accumulator tuples and spills 30-50 registers instead.
           constexpr int DEPTH = (HR && HA) ? 4 : 8;
           f32x4 rv[HR ? DEPTH : 1], av[HA ? DEPTH : 1];
           auto load = [&](int g) {                           // group g = (fragment, accumulator register r)
@@ -589,6 +622,12 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
             if constexpr (HR) o += rv[g % DEPTH];
             if constexpr (HA) o += av[g % DEPTH];
             o *= scale;
+            if constexpr (!HR && !HA) {
+              if (act_out) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = ovk::lrelu(o[e], oslope);
+              }
+            }
             if (colok[f] && (OVW_EXP != 4 || o[0] == 12345.f))
               *reinterpret_cast<f32x4*>(outb + (mrow + (size_t)((r & 3) + 8 * (r >> 2))) * LD + voff[f]) = o;
           }
@@ -655,6 +694,12 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
                 if constexpr (HR) o += rv[g % DEPTH][j];
                 if constexpr (HA) o += av[g % DEPTH][j];
                 o *= scale;
+                if constexpr (!HR && !HA) {
+                  if (act_out) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = ovk::lrelu(o[e], oslope);
+                  }
+                }
                 if (colok) *reinterpret_cast<f32x4*>(outb + (size_t)(row0(g) + j) * LD + col) = o;
               }
             }

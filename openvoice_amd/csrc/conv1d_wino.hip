@@ -66,6 +66,9 @@ int ov_conv1d_wino_f32(const ov_conv1d_wino_params* pin, ov_stream_t stream) {
   if (q.x_ld < q.L || q.out_ld < q.L) return OV_E_BADARG;
   if (!ov_conv1d_wino_supported(q.Cin, q.Cout, q.K, q.dil)) return OV_E_UNSUPPORTED;
   if (!(q.in_slope > 0.f && q.in_slope <= 1.f)) return OV_E_UNSUPPORTED;
+  if (q.out_slope == 0.f) q.out_slope = 1.f;
+  if (!(q.out_slope > 0.f && q.out_slope <= 1.f)) return OV_E_UNSUPPORTED;
+  if (q.out_slope != 1.f && (q.res || q.add)) return OV_E_UNSUPPORTED;   // the activated hand-over is the first conv's
   if (q.out == q.x) return OV_E_BADARG;   // (out may BE res or add: a lane reads exactly the 16 bytes it then writes)
   auto mis = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) != 0; };
   if (mis(q.x) || mis(q.w) || mis(q.out) || (q.res && mis(q.res)) || (q.add && mis(q.add)) || (q.L & 3) || (q.x_ld & 3) ||

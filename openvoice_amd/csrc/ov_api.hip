@@ -211,7 +211,7 @@ using namespace ovk;
 
 extern "C" {
 
-int ov_version(void) { return 208; }
+int ov_version(void) { return 209; }
 
 // 0 in every shippable build; the measurement builds of scripts/exp_sync.sh (OV_EXP = 1 / 2: staging loads and / or
 // barriers compiled out, numerically meaningless) report their number so that the Python binding can refuse them.

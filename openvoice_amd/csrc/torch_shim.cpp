@@ -353,11 +353,11 @@ void conv1d_split3(const OptTensor& x, const OptTensor& w, const OptTensor& bias
 }
 
 // ip = [B, Cin, Cout, L, x_ld, out_ld, K, dil, nwg, x_bstride, out_bstride, res_bstride, add_bstride, frags,
-//       col_limit_scale]; fp = [in_slope, scale]
+//       col_limit_scale]; fp = [in_slope, scale, out_slope]
 void conv1d_wino_f32(const OptTensor& x, const OptTensor& w, const OptTensor& bias, const OptTensor& out, const OptTensor& res,
                      const OptTensor& add, const OptTensor& dbg, const OptTensor& col_limit, at::IntArrayRef ip,
                      at::ArrayRef<double> fp) {
-  TORCH_CHECK(ip.size() == 15 && fp.size() == 2, "openvoice_amd::conv1d_wino_f32: 15 integer and 2 float parameters");
+  TORCH_CHECK(ip.size() == 15 && fp.size() == 3, "openvoice_amd::conv1d_wino_f32: 15 integer and 3 float parameters");
   Ctx c{"conv1d_wino_f32", false};
   ov_conv1d_wino_params p{};
   p.x = sptr<float>(x, c, 0); p.w = sptr<float>(w, c, 1); p.bias = sptr<float>(bias, c, 2);
@@ -367,7 +367,7 @@ void conv1d_wino_f32(const OptTensor& x, const OptTensor& w, const OptTensor& bi
   p.B = (int32_t)ip[0]; p.Cin = (int32_t)ip[1]; p.Cout = (int32_t)ip[2]; p.L = (int32_t)ip[3];
   p.x_ld = (int32_t)ip[4]; p.out_ld = (int32_t)ip[5]; p.K = (int32_t)ip[6]; p.dil = (int32_t)ip[7]; p.nwg = (int32_t)ip[8];
   p.x_bstride = ip[9]; p.out_bstride = ip[10]; p.res_bstride = ip[11]; p.add_bstride = ip[12]; p.frags = (int32_t)ip[13];
-  p.in_slope = (float)fp[0]; p.scale = (float)fp[1];
+  p.in_slope = (float)fp[0]; p.scale = (float)fp[1]; p.out_slope = (float)fp[2];
   DeviceScope scope(c);
   finish(ov_conv1d_wino_f32(&p, c.stream()), "ov_conv1d_wino_f32");
 }

@@ -565,11 +565,11 @@ class ConverterEngine:
             alg_flops = 2.0 * layer.rows * (kwargs.get("cin") or layer.cin) * layer.K * L * B
         self.profile.append((tag, alg_flops, e0, e1))
 
-    def _wino(self, layer, x, out, bs, B, L, res=None, add=None, scale=1.0, **lim):
+    def _wino(self, layer, x, out, bs, B, L, res=None, add=None, scale=1.0, in_slope=LRELU_SLOPE, out_slope=1.0, **lim):
         """One Winograd-domain ResBlock conv (leaky ReLU on the input, LINEAR epilogue); profiled under the MRF tag with its
         algorithmic FLOPs and, as a fifth field, the FLOPs the kernel EXECUTES (6 ceil(K/3) / (4 K) of them)."""
         from . import wino
-        kw = dict(in_slope=LRELU_SLOPE, scale=scale, res=res, res_bs=bs if res is not None else 0, add=add,
+        kw = dict(in_slope=in_slope, out_slope=out_slope, scale=scale, res=res, res_bs=bs if res is not None else 0, add=add,
                   add_bs=bs if add is not None else 0, **lim)
         if self.profile is None:
             wino.launch_conv_wino(layer, x, bs, out, bs, B, L, **kw)
@@ -1023,15 +1023,18 @@ class ConverterEngine:
                             w1 = None           # too few items for one workgroup per CU: the direct kernel's small tiles
                         if w2 is not None and wino_items(ch, 1, B, L) < WINO_MIN_ITEMS:
                             w2 = None
+                        # t1 is read by c2 only, which activates it: a Winograd c1 stores it activated (the same
+                        # values, modules.py:298-301) and c2 -- either kernel -- stages it as is
                         if w1 is not None:
-                            self._wino(w1, cur, t1_, bs, B, L, **lim(rate))
+                            self._wino(w1, cur, t1_, bs, B, L, out_slope=LRELU_SLOPE, **lim(rate))
                         else:
                             self._conv(c1, cur, 0, bs, t1_, 0, bs, B, L, in_slope=LRELU_SLOPE, tag="mrf", **lim(rate))
+                        c2_slope = 1.0 if w1 is not None else LRELU_SLOPE
                         dst = acc if last else ra_
                         if w2 is not None:
-                            self._wino(w2, t1_, dst, bs, B, L, res=cur, add=add, scale=scale, **lim(rate))
+                            self._wino(w2, t1_, dst, bs, B, L, res=cur, add=add, scale=scale, in_slope=c2_slope, **lim(rate))
                         else:
-                            self._conv(c2, t1_, 0, bs, dst, 0, bs, B, L, in_slope=LRELU_SLOPE, res=cur, res_bs=bs,
+                            self._conv(c2, t1_, 0, bs, dst, 0, bs, B, L, in_slope=c2_slope, res=cur, res_bs=bs,
                                        add=add, add_bs=bs, scale=scale, tag="mrf", **lim(rate))
                     cur = dst
 

@@ -41,14 +41,17 @@ class PackedConvWino:
 
 
 def launch_conv_wino(layer, x, x_bs, out, out_bs, B, L, in_slope=1.0, scale=1.0, res=None, res_bs=0, add=None, add_bs=0,
-                     x_ld=0, out_ld=0, nwg=0, dbg=None, frags=0, col_limit=None, col_limit_scale=1):
+                     x_ld=0, out_ld=0, nwg=0, dbg=None, frags=0, col_limit=None, col_limit_scale=1, out_slope=1.0):
     """One launch on torch's current stream of ``x``'s device; strides in elements (``*_ld`` 0 = dense rows).
     ``col_limit`` (int32 [B] on the device) x ``col_limit_scale`` = columns of each utterance that matter: column blocks
-    beyond are neither computed nor written (length-aware work list, as ``engine.launch_conv``)."""
+    beyond are neither computed nor written (length-aware work list, as ``engine.launch_conv``).  ``out_slope`` < 1 stores
+    lrelu(result, out_slope) (only without ``res`` / ``add``): the first conv of a ResBlock pair hands its consumer an
+    activated tensor, which then stages it with ``in_slope`` = 1 -- the same values, one leaky ReLU per element instead of one
+    per element and launch that reads it."""
     if _lib.use_torch_binding():
         _lib.torch_op("conv1d_wino_f32", x, layer.w, layer.bias, out, res, add, dbg, col_limit,
                       [B, layer.cin, layer.cout, L, x_ld, out_ld, layer.K, layer.dil, nwg, x_bs, out_bs, res_bs, add_bs, frags, col_limit_scale],
-                      [in_slope, scale])
+                      [in_slope, scale, out_slope])
         return
     p = _lib.ConvWinoParams()
     vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
@@ -56,7 +59,7 @@ def launch_conv_wino(layer, x, x_bs, out, out_bs, B, L, in_slope=1.0, scale=1.0,
     p.x_bstride, p.out_bstride, p.res_bstride, p.add_bstride = x_bs, out_bs, res_bs, add_bs
     p.B, p.Cin, p.Cout, p.L, p.x_ld, p.out_ld = B, layer.cin, layer.cout, L, x_ld, out_ld
     p.K, p.dil, p.nwg, p.frags = layer.K, layer.dil, nwg, frags
-    p.in_slope, p.scale = in_slope, scale
+    p.in_slope, p.scale, p.out_slope = in_slope, scale, out_slope
     p.dbg = vp(dbg)
     p.col_limit, p.col_limit_scale = vp(col_limit), col_limit_scale
     stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)

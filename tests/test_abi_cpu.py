@@ -341,7 +341,7 @@ def test_conv_wino_params_struct_matches_header_field_order():
     assert ctypes.sizeof(_lib.ConvWinoParams) == 6 * 8 + 4 * 8 + 10 * 4 + 2 * 4 + 8 + 8 + 2 * 4
     lib = _lib.load()
     assert lib.ov_conv1d_wino_f32(None, None) == -1
-    assert lib.ov_version() >= 208
+    assert lib.ov_version() >= 209
     assert [lib.ov_conv1d_wino_chunk(k, 128) for k in (3, 5, 7, 11)] == [16, 0, 8, 8]
     assert [lib.ov_conv1d_wino_chunk(k, 64) for k in (3, 7, 11)] == [8, 4, 4]
     # one 32-row fragment per workgroup: K = 11 only (a two-channel chunk of K = 7 would be an odd number of k-steps)

@@ -139,6 +139,29 @@ def test_wino_forced_workgroup_counts_are_bit_identical(nwg, frags):
     assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("C,K,dil", [(128, 11, 1), (128, 3, 5), (64, 7, 1), (64, 11, 3), (32, 11, 1)])
+def test_wino_activated_hand_over_equals_activating_on_load(C, K, dil):
+    """``out_slope``: the first conv of a ResBlock pair stores lrelu(t) and the second stages it with ``in_slope`` = 1 -- bit
+    for bit the tensors the pair produces when the second conv activates on load (openvoice/modules.py:298-301); refused
+    together with a residual."""
+    import torch.nn.functional as F
+    from openvoice_amd import _lib, wino
+    B, L = 2, 1100
+    w, b, x, _, wn, gen = _setup(C, K, B, L, seed=3 * C + K + dil, dil=dil)
+    w2 = torch.randn(C, C, K, generator=gen) * (C * K) ** -0.5
+    wn2 = wino.PackedConvWino(w2, torch.zeros(C), DEV, dil=1)
+    t_raw, t_act = torch.empty(B, C, L, device=DEV), torch.empty(B, C, L, device=DEV)
+    wino.launch_conv_wino(wn, x, C * L, t_raw, C * L, B, L, in_slope=0.1)
+    wino.launch_conv_wino(wn, x, C * L, t_act, C * L, B, L, in_slope=0.1, out_slope=0.1)
+    assert torch.equal(t_act, F.leaky_relu(t_raw, 0.1))
+    o_a, o_b = torch.empty(B, C, L, device=DEV), torch.empty(B, C, L, device=DEV)
+    wino.launch_conv_wino(wn2, t_raw, C * L, o_a, C * L, B, L, in_slope=0.1, res=x, res_bs=C * L)
+    wino.launch_conv_wino(wn2, t_act, C * L, o_b, C * L, B, L, in_slope=1.0, res=x, res_bs=C * L)
+    assert torch.equal(o_a, o_b)
+    with pytest.raises(_lib.OvError):
+        wino.launch_conv_wino(wn, x, C * L, t_act, C * L, B, L, in_slope=0.1, out_slope=0.1, res=x, res_bs=C * L)
+
+
 def test_wino_refuses_what_it_cannot_run():
     from openvoice_amd import _lib, wino
     w, b, x, _, wn, _ = _setup(128, 11, 1, 256, seed=1)
