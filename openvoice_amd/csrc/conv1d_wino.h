@@ -110,7 +110,8 @@ __host__ __device__ inline size_t wino_pack_floats(int Cout, int Cin, int K, int
 #ifndef OVW_EXP
 #define OVW_EXP 0   // measurement builds only (scripts/exp_wino.sh): 1 = MFMAs replaced by one FMA; 2 = helper transform skipped;
                     // 3 = no weight stream (the first fragments of an item are reused); 4 = no epilogue stores; 5 = no B-operand
-                    // reads inside the k-loop (the chunk's first operands are reused); 6 = helpers idle (barriers only)
+                    // reads inside the k-loop (the chunk's first operands are reused); 6 = helpers idle (barriers only); 7 = helpers idle and NO chunk barriers at all; 8 = 7 + 3 + 5
+                    // (the bare MFMA loop)
 #endif
 #define OVW_MARK(q)                                                \
   if constexpr (DBG) {                                             \
@@ -423,13 +424,13 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
     // chunk i + 2 (set i & 1, requested a period ago) to raw[i & 1]; nothing is requested beyond the stream's end
     auto period = [&](int i, auto par) {
       constexpr int P = decltype(par)::value;
-      if (OVW_EXP != 6) issue_loads(std::integral_constant<int, 1 - P>{});
+      if (OVW_EXP < 6) issue_loads(std::integral_constant<int, 1 - P>{});
       OVW_MARK(0)
-      if (OVW_EXP != 2 && OVW_EXP != 6 && i + 1 < nstream) transform(std::integral_constant<int, 1 - P>{});
+      if (OVW_EXP != 2 && OVW_EXP < 6 && i + 1 < nstream) transform(std::integral_constant<int, 1 - P>{});
       OVW_MARK(1)
-      if (OVW_EXP != 6) write_raw(P, par);
+      if (OVW_EXP < 6) write_raw(P, par);
       OVW_MARK(2)
-      hand_over();                // V[(i + 1) & 1] and raw[i & 1] handed over; V[i & 1] free again
+      if (OVW_EXP < 7) hand_over();                // V[(i + 1) & 1] and raw[i & 1] handed over; V[i & 1] free again
       OVW_MARK(3)
     };
     for (int i = 0; i < nstream; i += 2) {
@@ -457,6 +458,9 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
   int mtile = mblk * MW + wrow;
   // sub-record index of the first k-step pair of (mtile, chunk 0); the stream of an item is contiguous
   uint32_t rec = (uint32_t)mtile * (uint32_t)nchunks * (uint32_t)(NPAIR * 3);
+  // (A ring of three pairs -- requests two pairs ahead -- was built for K = 7, where a chunk is a whole number of ring
+  // revolutions: no gain with the helpers running, profiles/r06_s29; any form with several copies of the chunk body by ring
+  // phase makes hipcc spill 400-600 registers.)
   f32x4 a_cur[3], a_nxt[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) a_cur[j] = wbase[(size_t)(rec + j) * 64 + lane];
@@ -508,13 +512,13 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
           // the next chunk are read behind this step's MFMAs instead of in a bubble after the barrier -- measured with idle
           // helpers a chunk cost its MFMA issue time + ~1 100 cycles whatever its length (profiles/r06_s24)
           OVW_MARK(0)
-          lds_barrier();
+          if (OVW_EXP < 7) lds_barrier();
           OVW_MARK(1)
         }
         if (s2 == 0) {
           rec += 3;   // the sub-records after the last real pair are zeros written by the packer
 #pragma unroll
-          for (int j = 0; j < 3; ++j) a_nxt[j] = OVW_EXP == 3 ? a_cur[j] : wbase[(size_t)(rec + j) * 64 + lane];
+          for (int j = 0; j < 3; ++j) a_nxt[j] = (OVW_EXP == 3 || OVW_EXP == 8) ? a_cur[j] : wbase[(size_t)(rec + j) * 64 + lane];
         }
 #pragma unroll
         for (int qq = 0; qq < 3; ++qq) {
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
             }
           }
           __builtin_amdgcn_sched_barrier(0);
-          if (OVW_EXP != 5 && (s + 1 < NSTEP || more_chunks)) {
+          if (OVW_EXP != 5 && OVW_EXP != 8 && (s + 1 < NSTEP || more_chunks)) {
 #pragma unroll
             for (int f = 0; f < NF; ++f)
               bq[f][qq] = *reinterpret_cast<const f32x2*>((s + 1 < NSTEP ? vb + (s + 1) * (2 * NT * 6) : vbn) + f * (32 * 6) + 2 * qq);
