@@ -776,7 +776,7 @@ def main():
         gen_bytes = generator_alg_bytes(cfg, B, frames)
     else:
         n_mrf, f_mrf, t_mrf, x_mrf = by_tag["mrf"]
-    # priced on the FLOPs the matrix pipe executes: the Winograd-domain launches execute 6 ceil(K/3) / (4 K) of their
+    # priced on the FLOPs the matrix pipe executes: the Winograd-domain launches execute 6 / 16 / 23 of the 12 / 28 / 44 products of their
     # algorithmic FLOPs, so the fraction of the fp32 MFMA peak stays a utilisation (<= 1); what the same time would
     # mean for the direct form is `algorithmic_equivalent_tflops`
     achieved = x_mrf / t_mrf / 1e12

@@ -8,7 +8,11 @@
 //   V_p[g][ci][j]   = sum_m Bt[p][m] * act(x[ci][4j + 3g + m - PAD])  (inputs: VALU, on the way into LDS)
 //
 // i.e. six independent GEMMs (one per interpolation point p: 0, +-1, +-2, infinity) with M = co, N = tile index j,
-// K_gemm = (group, ci).  Executed MACs per 4 outputs and (co, ci): K = 3: 6 (direct 12), K = 7: 18 (28), K = 11: 24 (44).
+// K_gemm = (group, ci).  The 3 ceil(K/3) - K taps that pad the last group are exact zeros, and a zero tap at the END of a
+// group makes its point-infinity weight zero (G row (0, 0, 1)), one at the START of a group its point-0 weight (G row
+// (1/4, 0, 0)): those products are never issued.  K = 7 is laid out as (0 w0 w1)(w2 w3 w4)(w5 w6 0) -- one zero at each
+// end: two products dropped -- and K = 11 as (w0 w1 w2) ... (w9 w10 0): one dropped (wino_lead / wino_zero_product below).
+// Executed MACs per 4 outputs and (co, ci): K = 3: 6 (direct 12), K = 7: 16 (28), K = 11: 23 (44).
 // fp32 throughout; the transforms round where the direct form does not, so the result carries ~4x the direct kernel's
 // rounding error (measured against float64: profiles/r06_*), two orders of magnitude inside the path's 1e-3 bar.
 //
@@ -66,6 +70,23 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 constexpr int REC = 256;        // floats per 1 KiB weight sub-record
+
+// Zero taps in FRONT of the K real ones (the rest of the 3 ceil(K/3) - K padding taps follow them): the conv is computed as
+// a (K + lead + trail)-tap conv with 'same' padding (K - 1) / 2 + lead on the left.
+constexpr int wino_lead(int K) { return K == 7 ? 1 : 0; }
+constexpr int wino_trail(int K) { return (K + 2) / 3 * 3 - K - wino_lead(K); }
+// the product of group g at interpolation point pt (0: point 0, 5: infinity) is identically zero -- weight and all
+constexpr bool wino_zero_product(int K, int g, int pt) {
+  return (pt == 0 && g == 0 && wino_lead(K) >= 1) || (pt == 5 && g == (K + 2) / 3 - 1 && wino_trail(K) >= 1);
+}
+// products issued per 4 outputs and (co, ci)
+constexpr int wino_products(int K) {
+  int n = 0;
+  for (int g = 0; g < (K + 2) / 3; ++g)
+    for (int pt = 0; pt < 6; ++pt) n += wino_zero_product(K, g, pt) ? 0 : 1;
+  return n;
+}
+static_assert(wino_products(3) == 6 && wino_products(7) == 16 && wino_products(11) == 23, "executed products per tile");
 constexpr int MAX_COUT = 512;   // rows of the bias vector kept in LDS
 
 // Dilation DIL > 1 (the first conv of each ResBlock pair, reference openvoice/modules.py:228-251): an output at column
@@ -79,18 +100,18 @@ struct GeoD {
   static constexpr int NT = 32 * NF;
   static constexpr int J = NT / DIL;                             // tiles per residue class
   static constexpr int NCOL = 4 * J * DIL;                       // output columns per N-block
-  static constexpr int PADD = (K - 1) / 2 * DIL;                 // 'same' padding in columns
+  static constexpr int PADD = ((K - 1) / 2 + wino_lead(K)) * DIL;   // 'same' padding in columns (leading zero taps included)
   static constexpr int PADA = (PADD + 3) / 4 * 4;                // raw rows start at column t0 - PADA (16-byte aligned)
   static constexpr int NV = 3 * (G - 1) + 6;                     // inputs a tile reads, DIL apart
   static constexpr int RW = (PADA - PADD + DIL - 1 + DIL * (4 * (J - 1) + NV - 1) + 1 + 3) / 4 * 4;   // floats per raw row
   static_assert(DIL == 3 || DIL == 5, "dilated instances: 3 and 5");
 };
 
-// Geometry of a K-tap conv: group g holds taps 3g .. 3g + 2 (taps >= K are zero).
+// Geometry of a K-tap conv: group g holds taps 3g - lead .. 3g - lead + 2 (taps outside [0, K) are zero).
 template <int K>
 struct Geo {
   static constexpr int G = (K + 2) / 3;
-  static constexpr int PAD = (K - 1) / 2;
+  static constexpr int PAD = (K - 1) / 2 + wino_lead(K);
   static constexpr int OFF0 = 8 - PAD;                          // raw index of input m = 0 of (tile 0, group 0)
   static constexpr int WSTART = OFF0 / 4 * 4;                   // aligned start of a tile's input window
   static constexpr int WLEN = OFF0 - WSTART + 3 * (G - 1) + 6;  // floats of the window all groups read
@@ -382,24 +403,29 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
           const f32x2 c4 = {4.f, 4.f}, m4 = {-4.f, -4.f}, m5 = {-5.f, -5.f}, c2 = {2.f, 2.f}, m2 = {-2.f, -2.f};
           const f32x2 t1 = __builtin_elementwise_fma(m4, d2, d4), t2 = __builtin_elementwise_fma(m4, d1, d3);
           const f32x2 t3 = d4 - d2, t4 = d3 - d1;
-          const f32x2 v0 = __builtin_elementwise_fma(c4, d0, __builtin_elementwise_fma(m5, d2, d4));
+          // (a point whose product is identically zero -- wino_zero_product -- is neither computed nor stored: its V slot is
+          // never read into an MFMA)
+          constexpr bool Z0 = wino_zero_product(K, g, 0), Z5 = wino_zero_product(K, g, 5);
           const f32x2 v1 = t1 + t2;
           const f32x2 v2 = t1 - t2;
           const f32x2 v3 = __builtin_elementwise_fma(c2, t4, t3);
           const f32x2 v4 = __builtin_elementwise_fma(m2, t4, t3);
-          const f32x2 v5 = __builtin_elementwise_fma(c4, d1, __builtin_elementwise_fma(m5, d3, d5));
           // V[k-row g CI + 2 pr + channel][tile][6]: the records of the pair's channels are NT * 24 bytes apart, those of
           // consecutive groups CI * NT * 24 -- both whole multiples of 256 bytes, i.e. the two offsets of a
           // ds_write2st64_b32: ONE store per point writes both channels' values from their (non-adjacent) registers
           constexpr int OA = g * CI * NT * 24 / 256, OB = OA + NT * 24 / 256;
-          if constexpr (buf == 0) {
-            lds_write2st64_b32<OA, OB>(vadr[0][r][0], v0[0], v0[1]); lds_write2st64_b32<OA, OB>(vadr[0][r][1], v1[0], v1[1]);
-            lds_write2st64_b32<OA, OB>(vadr[0][r][2], v2[0], v2[1]); lds_write2st64_b32<OA, OB>(vadr[0][r][3], v3[0], v3[1]);
-            lds_write2st64_b32<OA, OB>(vadr[0][r][4], v4[0], v4[1]); lds_write2st64_b32<OA, OB>(vadr[0][r][5], v5[0], v5[1]);
-          } else {
-            lds_write2st64_b32<OA, OB>(vadr[1][r][0], v0[0], v0[1]); lds_write2st64_b32<OA, OB>(vadr[1][r][1], v1[0], v1[1]);
-            lds_write2st64_b32<OA, OB>(vadr[1][r][2], v2[0], v2[1]); lds_write2st64_b32<OA, OB>(vadr[1][r][3], v3[0], v3[1]);
-            lds_write2st64_b32<OA, OB>(vadr[1][r][4], v4[0], v4[1]); lds_write2st64_b32<OA, OB>(vadr[1][r][5], v5[0], v5[1]);
+          constexpr int bf = buf;
+          if constexpr (!Z0) {
+            const f32x2 v0 = __builtin_elementwise_fma(c4, d0, __builtin_elementwise_fma(m5, d2, d4));
+            lds_write2st64_b32<OA, OB>(vadr[bf][r][0], v0[0], v0[1]);
+          }
+          lds_write2st64_b32<OA, OB>(vadr[bf][r][1], v1[0], v1[1]);
+          lds_write2st64_b32<OA, OB>(vadr[bf][r][2], v2[0], v2[1]);
+          lds_write2st64_b32<OA, OB>(vadr[bf][r][3], v3[0], v3[1]);
+          lds_write2st64_b32<OA, OB>(vadr[bf][r][4], v4[0], v4[1]);
+          if constexpr (!Z5) {
+            const f32x2 v5 = __builtin_elementwise_fma(c4, d1, __builtin_elementwise_fma(m5, d3, d5));
+            lds_write2st64_b32<OA, OB>(vadr[bf][r][5], v5[0], v5[1]);
           }
         });
       }
@@ -526,6 +552,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
             const int q = 2 * qq + t, e = s2 * 6 + q;
+            if (wino_zero_product(K, 2 * s / CI, q)) continue;   // (s is a compile-time value: the loop is unrolled)
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
 #if OVW_EXP == 1   // measurement build: no MFMAs (what do the helpers cost when the matrix pipe is idle?)

@@ -45,8 +45,8 @@ int ov_conv1d_wino_pack_f32(const float* w, int Cout, int Cin, int K, float* dst
             const int co = 32 * mt + (lane & 31);
             double u = 0.0;
             for (int k = 0; k < 3; ++k) {
-              const int tap = 3 * g + k;
-              if (tap < K) u += kG[pt][k] * (double)w[((size_t)co * Cin + ci) * K + tap];
+              const int tap = 3 * g + k - wino_lead(K);   // (zero taps pad the K real ones on both sides: conv1d_wino.h)
+              if (tap >= 0 && tap < K) u += kG[pt][k] * (double)w[((size_t)co * Cin + ci) * K + tap];
             }
             const size_t sub = (((size_t)mt * nchunks + c) * NPAIR + sp) * 3 + e / 4;
             dst[sub * REC + (size_t)lane * 4 + e % 4] = (float)u;

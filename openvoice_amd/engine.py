@@ -567,7 +567,7 @@ class ConverterEngine:
 
     def _wino(self, layer, x, out, bs, B, L, res=None, add=None, scale=1.0, in_slope=LRELU_SLOPE, out_slope=1.0, **lim):
         """One Winograd-domain ResBlock conv (leaky ReLU on the input, LINEAR epilogue); profiled under the MRF tag with its
-        algorithmic FLOPs and, as a fifth field, the FLOPs the kernel EXECUTES (6 ceil(K/3) / (4 K) of them)."""
+        algorithmic FLOPs and, as a fifth field, the FLOPs the kernel EXECUTES (wino.PRODUCTS_PER_TILE[K] / (4 K) of them)."""
         from . import wino
         kw = dict(in_slope=in_slope, out_slope=out_slope, scale=scale, res=res, res_bs=bs if res is not None else 0, add=add,
                   add_bs=bs if add is not None else 0, **lim)
@@ -579,7 +579,7 @@ class ConverterEngine:
         wino.launch_conv_wino(layer, x, bs, out, bs, B, L, **kw)
         e1.record()
         alg = 2.0 * layer.cout * layer.cin * layer.K * L * B
-        self.profile.append(("mrf", alg, e0, e1, alg * 6 * ((layer.K + 2) // 3) / (4.0 * layer.K)))
+        self.profile.append(("mrf", alg, e0, e1, alg * wino.PRODUCTS_PER_TILE[layer.K] / (4.0 * layer.K)))
 
     def _pair(self, c1, c2, x, out, bs, B, L, add, scale, **lim):
         """One fused ResBlock1 iteration; profiled under the same tag as the two launches it replaces, with their

@@ -19,6 +19,15 @@ G = ((1 / 4, 0, 0), (-1 / 6, -1 / 6, -1 / 6), (-1 / 6, 1 / 6, -1 / 6), (1 / 24, 
 AT = ((1, 1, 1, 1, 1, 0), (0, 1, -1, 2, -2, 0), (0, 1, 1, 4, 4, 0), (0, 1, -1, 8, -8, 1))
 
 
+# Zero taps in front of the K real ones (csrc/conv1d_wino.h wino_lead): K = 7 is transformed as (0 w0 w1)(w2 w3 w4)(w5 w6 0),
+# K = 11 as (w0 w1 w2) ... (w9 w10 0).  A zero tap at the start of a group makes its point-0 weight zero, one at the end its
+# point-infinity weight: those products are never issued.
+LEAD_TAPS = {3: 0, 7: 1, 11: 0}
+# multiply-accumulates the kernel EXECUTES per 4 outputs and (co, ci): 6 per group minus the identically-zero products
+# (the direct form needs 4 K: 12 / 28 / 44)
+PRODUCTS_PER_TILE = {3: 6, 7: 16, 11: 23}
+
+
 def supported(cin, cout, K, dil):
     return bool(_lib.call("ov_conv1d_wino_supported", cin, cout, K, dil))
 

@@ -14,7 +14,7 @@ NT, RW = 32, 144
 
 def geo(K):
     G = (K + 2) // 3
-    pad = (K - 1) // 2
+    pad = (K - 1) // 2 + wino.LEAD_TAPS[K]      # 'same' padding of the zero-extended filter (csrc/conv1d_wino.h Geo<K>)
     off0 = 8 - pad
     wstart = off0 // 4 * 4
     wlen = off0 - wstart + 3 * (G - 1) + 6
@@ -50,8 +50,9 @@ def test_weight_packer_sub_record_order(cout, cin, k):
     npair = ci * G // 4
     assert packed.size == ((cout // 32) * (cin // ci) * npair * 3 + 3) * 256
     assert (packed[-768:] == 0).all()
+    lead = wino.LEAD_TAPS[k]                     # zero taps in front of the real ones (K = 7: one at each end)
     wp = np.zeros((cout, cin, 3 * G))
-    wp[:, :, :k] = w.numpy()
+    wp[:, :, lead:lead + k] = w.numpy()
     u = np.einsum("pk,ocgk->ocgp", np.array(wino.G), wp.reshape(cout, cin, G, 3)).astype(np.float32)   # [co][ci][g][p]
     rec = packed[:-768].reshape(cout // 32, cin // ci, npair, 3, 64, 4)
     rng = np.random.default_rng(3)
@@ -62,6 +63,13 @@ def test_weight_packer_sub_record_order(cout, cin, k):
         want = u[32 * mt + (lane & 31), c * ci + kk % ci, kk // ci, e % 6]
         # (float64 sums of three products rounded once: equal up to the summation order of the float64 terms)
         assert abs(float(rec[mt, c, sp, e // 4, lane, e % 4]) - float(want)) <= 2.0 ** -23 * abs(float(want))
+    # the products the kernel never issues are exact zeros in the stream: point 0 of a group that starts with a zero tap,
+    # point infinity of one that ends with one
+    zero = [(g, pt) for g in range(G) for pt in (0, 5)
+            if (pt == 0 and g == 0 and lead) or (pt == 5 and g == G - 1 and 3 * G - k - lead)]
+    assert len(zero) == 6 * G - wino.PRODUCTS_PER_TILE[k]
+    for g, pt in zero:
+        assert (u[:, :, g, pt] == 0).all()
     assert lib.ov_conv1d_wino_pack_size(100, 128, 3) == 0 and lib.ov_conv1d_wino_pack_size(128, 128, 5) == 0
     assert lib.ov_conv1d_wino_supported(128, 128, 11, 1) == 1 and lib.ov_conv1d_wino_supported(128, 128, 11, 2) == 0
     assert lib.ov_conv1d_wino_supported(128, 128, 11, 5) == 1 and lib.ov_conv1d_wino_supported(256, 256, 3, 3) == 1
@@ -116,6 +124,10 @@ def test_kernel_index_algebra_reproduces_the_conv(k, cin, L, cout):
                         o = off0 - wstart + 3 * g
                         dst = 12 * ((g * npr + pr) * NT + tl) + 6 * ch
                         V[dst:dst + 6] = bt @ win[o:o + 6]
+                        if g == 0 and wino.LEAD_TAPS[k]:
+                            V[dst] = np.nan                # the helpers do not store the points of products never issued
+                        if g == G - 1 and 3 * G - k - wino.LEAD_TAPS[k]:
+                            V[dst + 5] = np.nan
             for wave in range(nmt):                        # matrix waves: sub-records -> A fragments, V -> B fragments
                 mt = wave
                 base = (mt * nchunks + c) * npair * 3
@@ -123,6 +135,9 @@ def test_kernel_index_algebra_reproduces_the_conv(k, cin, L, cout):
                     sp, s2 = s >> 1, s & 1
                     for q in range(6):
                         e = s2 * 6 + q
+                        g = 2 * s // ci_chunk
+                        if (q == 0 and g == 0 and wino.LEAD_TAPS[k]) or (q == 5 and g == G - 1 and 3 * G - k - wino.LEAD_TAPS[k]):
+                            continue                       # identically zero: never issued (and its V slot never written)
                         sub = packed[(base + sp * 3 + (e >> 2)) * 256:(base + sp * 3 + (e >> 2) + 1) * 256].reshape(64, 4)
                         a = sub[:, e & 3]                  # lane -> A[row = lane & 31][k = lane >> 5]
                         for half in range(2):              # lane (half, n) -> B[k = half][n] at (s NT + n) 12 + 6 half + q
@@ -135,7 +150,8 @@ def test_kernel_index_algebra_reproduces_the_conv(k, cin, L, cout):
                 if col < L:
                     out[32 * wave:32 * wave + 32, col:col + 4] = o[wave, :, n, :]
     xa = np.where(x > 0, x, slope * x)
-    xp = np.pad(xa, ((0, 0), (pad, pad)))
+    cpad = (k - 1) // 2                                    # the conv's own 'same' padding (`pad` counts the leading zero taps too)
+    xp = np.pad(xa, ((0, 0), (cpad, cpad)))
     ref = bias[:, None] + sum(w.numpy()[:, :, j].astype(np.float64) @ xp[:, j:j + L] for j in range(k))
     assert np.abs(out - ref).max() < 2e-5, np.abs(out - ref).max()
 
@@ -156,7 +172,7 @@ def test_dilated_kernel_index_algebra_reproduces_the_conv(k, dil, cin, L, cout):
     J = NTS // dil
     ncols = 4 * J * dil            # columns per sub-block
     ncol = ncols * NB
-    padd = (k - 1) // 2 * dil
+    padd = ((k - 1) // 2 + wino.LEAD_TAPS[k]) * dil      # 'same' padding of the zero-extended filter (GeoD::PADD)
     pada = (padd + 3) // 4 * 4
     nv = 3 * (G - 1) + 6
     rw = (pada - padd + dil - 1 + dil * (4 * (J - 1) + nv - 1) + 1 + 3) // 4 * 4 + (NB - 1) * ncols
@@ -200,12 +216,19 @@ def test_dilated_kernel_index_algebra_reproduces_the_conv(k, dil, cin, L, cout):
                     for g in range(G):
                         dst = 12 * ((g * npr + pr) * NT + tile) + 6 * ch
                         V[dst:dst + 6] = bt @ win[3 * g: 3 * g + 6]
+                        if g == 0 and wino.LEAD_TAPS[k]:
+                            V[dst] = np.nan                # (points of products never issued are not stored)
+                        if g == G - 1 and 3 * G - k - wino.LEAD_TAPS[k]:
+                            V[dst + 5] = np.nan
             for wave in range(nmt):
                 base = (wave * nchunks + c) * npair * 3
                 for s in range(kr // 2):
                     sp, s2 = s >> 1, s & 1
                     for q in range(6):
                         e = s2 * 6 + q
+                        g = 2 * s // ci_chunk
+                        if (q == 0 and g == 0 and wino.LEAD_TAPS[k]) or (q == 5 and g == G - 1 and 3 * G - k - wino.LEAD_TAPS[k]):
+                            continue                       # identically zero: never issued (and its V slot never written)
                         sub = packed[(base + sp * 3 + (e >> 2)) * 256:(base + sp * 3 + (e >> 2) + 1) * 256].reshape(64, 4)
                         a = sub[:, e & 3]
                         for half in range(2):
@@ -226,7 +249,8 @@ def test_dilated_kernel_index_algebra_reproduces_the_conv(k, dil, cin, L, cout):
                 if 4 * lane < ncols and col < L:
                     out[:, col:col + 4] = stage[:, :, 4 * lane:4 * lane + 4].reshape(cout, 4)
     xa = np.where(x > 0, x, slope * x)
-    xp = np.pad(xa, ((0, 0), (padd, padd)))
+    cpad = (k - 1) // 2 * dil
+    xp = np.pad(xa, ((0, 0), (cpad, cpad)))
     ref = bias[:, None] + sum(w.numpy()[:, :, j].astype(np.float64) @ xp[:, j * dil:j * dil + L] for j in range(k))
     assert not np.isnan(out).any()
     assert np.abs(out - ref).max() < 2e-5, np.abs(out - ref).max()

@@ -27,7 +27,7 @@ from openvoice_amd.utils import CONVERTER_MODEL_CONFIG  # noqa: E402
 from tools.bench_split3 import f64_conv, ramp, timed  # noqa: E402
 
 DEV = "cuda:0"
-MACS_PER_4 = {3: 6, 7: 18, 11: 24}      # executed multiply-accumulates per 4 outputs and (co, ci)
+MACS_PER_4 = wino.PRODUCTS_PER_TILE      # executed multiply-accumulates per 4 outputs and (co, ci)
 
 
 def one_shape(sd, C, K, d, B, L, reps, err_items=2, with_res=False, frags=0):
