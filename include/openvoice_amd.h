@@ -524,7 +524,8 @@ int ov_split3_to_f32(const uint16_t* a, const uint16_t* b, const uint16_t* c, in
  * infinity): weights transformed once in float64 at pack time, input tiles transformed in fp32 on the way into LDS, the
  * products of all groups and input channels accumulated in the transform domain on v_mfma_f32_32x32x2_f32 (six GEMMs,
  * one per point), the inverse transform + operands in the epilogue.  fp32 arithmetic throughout; executed MACs per
- * output and (co, ci): 1.5 (K = 3), 4.5 (K = 7), 6 (K = 11) instead of K.  The transforms round where the direct conv
+ * output and (co, ci): 1.5 (K = 3), 4 (K = 7), 5.75 (K = 11) instead of K (the products of a group's zero padding taps at
+ * points 0 / infinity are identically zero and never issued: K = 7 is laid out with one zero tap at each end).  The transforms round where the direct conv
  * does not: against float64 the result carries ~4x the rounding error of ov_conv1d_f32 (tests/test_gpu_wino.py).
  * Tensors are fp32 [B][C][L], rows x_ld / out_ld floats apart (0 = L); L, x_ld, out_ld multiples of 4 and every
  * pointer 16-byte aligned; Cin % ov_conv1d_wino_chunk(K, Cout) == 0, Cout <= 512 and a multiple of 64 (K = 3 / 7 / 11) or
