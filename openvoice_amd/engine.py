@@ -313,6 +313,9 @@ def wino_policy(C, K, dil):
 # 1.1-1.65x faster).  Batch 1 with the rule: 7.50 -> 6.18 ms.
 WINO_MIN_ITEMS = 136
 
+# Opt-in split-precision path (use_split_bf16x3): generator stages with at least this many channels run on ov_conv1d_split3
+SPLIT_MIN_CHANNELS = 128
+
 
 def wino_items(cout, dil, B, L):
     """Work items of one ov_conv1d_wino_f32 launch (csrc/conv1d_wino.h: 256 columns per matrix wave at dilation 1,
@@ -814,12 +817,13 @@ class ConverterEngine:
         return self
 
     def use_split_bf16x3(self, enable=True, products=6):
-        """Run the MRF ResBlocks of every generator stage that has split-precision instances (C = 64 / 128 / 256: stages
-        0-2 of the released configuration, 80 % of a conversion's FLOPs) on ``ov_conv1d_split3``: every fp32 operand
+        """Run the MRF ResBlocks of the generator stages with C >= 128 (``SPLIT_MIN_CHANNELS``; stages 0-1 of the released
+        configuration; instances exist down to C = 64) on ``ov_conv1d_split3``: every fp32 operand
         carried as three bf16 planes (lossless), every product as the six plane products of weight >= 2^-18 on the bf16
         matrix pipe with fp32 accumulation -- fp32-level results (against float64 the error is BELOW the fp32 MFMA
-        kernels' on every shape, profiles/r05_s2_split3_table_all_shapes.txt) at 1.3-2.1x their speed: 103-104 instead of
-        139.5-140.5 ms per batch-32 conversion.  ``products=3`` uses the hi / mid planes only (16-bit operands, ~2e-5 per
+        kernels' on every shape, profiles/r05_s2_split3_table_all_shapes.txt) at 1.3-2.1x the DIRECT fp32 kernels' speed.  Since
+        round 6 the default path runs these convs in the Winograd domain, and the two are within 1 % of each other: 102.8
+        (this path) vs 103.8 ms per batch-32 conversion.  ``products=3`` uses the hi / mid planes only (16-bit operands, ~2e-5 per
         conv, 80 ms).  Off by default: the contract path is the fp32 kernels
         (reference: openvoice/modules.py:296-309, models.py:280-286)."""
         if products not in (6, 3):
@@ -834,7 +838,9 @@ class ConverterEngine:
                 ch //= 2
                 ok = all(split3.supported(ch, ch, rk, d) and split3.supported(ch, ch, rk, 1)
                          for rk, rd in zip(kernels, dils) for d in rd)
-                if not ok:
+                # C = 64 (stage 2) stays on the fp32 Winograd launches: its split convs tie with them (20.9 vs 21.5 ms) and
+                # cost two layout passes over the stage's tensors (1.3 ms): 104.3 -> 102.8 ms (profiles/r06_s34_*)
+                if not ok or ch < SPLIT_MIN_CHANNELS:
                     stages.append(None)
                     continue
                 stage = []
