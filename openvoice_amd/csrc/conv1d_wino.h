@@ -170,6 +170,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
   static_assert(DIL == 1 || NF == 2, "dilated instances run two fragments per wave");
   static_assert(KR % 4 == 0 && CI % 2 == 0, "k-rows in whole k-step pairs");
   constexpr int NPR = CI / 2;            // input-channel pairs per chunk (a pair = one k-step of each group)
+  constexpr int NITEM = NPR * RW4;       // staging items per chunk: (channel pair, 4 columns) = two 16-byte vectors
   constexpr int RAWBUF = CI * RW;        // floats per raw buffer: raw[pair][raw index][channel of the pair]
   constexpr int VBUF = KR * NT * 6;      // floats per V buffer: V[k-row = g * CI + channel][tile][6]
   __shared__ __attribute__((aligned(16))) float raw[2 * RAWBUF];
@@ -262,57 +263,25 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
     const float slope = p.in_slope;
     const uint32_t ldx = (uint32_t)p.x_ld;
     const int hl = (wave - 4) * 64 + lane;
-    // Staging items.  A raw row is MV "main" 16-byte vectors (one per Winograd tile of the N-block) + HV halo vectors (DIL = 1: two
-    // on each side; DIL > 1: the window tail of the last tiles), so a chunk's (channel pair, vector) items are NOT a whole number of
-    // helper-lane rounds -- and a round costs the same whether 16 or 256 of its lanes carry an item (a helper's cost is its
-    // instruction count: the last, nearly empty round of the old layout was 5-23 % of a launch, profiles/r06_s36).  So the rounds of
-    // a chunk carry the main vectors only (NPR MV items: whole rounds for every instance) and the halo vectors of HG consecutive
-    // chunks are gathered into ONE extra round, requested with the group's first chunk and kept in registers; per chunk the one
-    // wave that holds its halo items writes them (4 stores under an execution mask).
-    constexpr int MV = RW4 < NT ? RW4 : NT;             // main vectors per pair-row (a dilated row can be shorter than NT vectors)
-    constexpr int C0 = DIL == 1 ? 2 : 0;                // raw vector index of the first main vector
-    constexpr int HV = RW4 - MV;                        // halo vectors per pair-row
-    static_assert(HV <= 16 && (RW4 < NT || (NPR * MV) % (64 * NHELP) == 0), "main vectors fill whole staging rounds");
-    constexpr int NMAIN = NPR * MV;
-    constexpr int NLOAD = (NMAIN + 64 * NHELP - 1) / (64 * NHELP);
-    constexpr int IPC = HV * NPR;                       // halo items per chunk
-    constexpr int HG = IPC > 0 ? (64 * NHELP) / IPC : 1;   // chunks per halo group
-    static_assert(HG >= 1, "a chunk's halo items fit one round");
+    constexpr int NLOAD = (NITEM + 64 * NHELP - 1) / (64 * NHELP);
     // TWO register sets: the vectors of chunk c travel in set c & 1 and are requested a whole chunk period before they are
     // written to LDS -- with one set, request and use sat in the same period, and a chunk could not be shorter than an
     // HBM round trip under load (~2.5 us: the floor of every instance whose k-loop is shorter, profiles/r06_s16)
     f32x4 sa[2][NLOAD], sb[2][NLOAD];    // the staged vector of the pair's first / second channel
     uint32_t sbyte[NLOAD];               // byte offset of (row 2 pr, raw index 4 c4) from (first row of the chunk, raw index 0)
-    uint32_t sdst[NLOAD];                // byte offset of raw[pr][4 c4][0] in a raw buffer
     int scol[NLOAD];                     // 4 c4
     uint32_t hasbits = 0, okbits[2] = {0, 0};
     bool edge[2] = {false, false};
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
       const int idx = i * (64 * NHELP) + hl;
-      const int pr = idx / MV, c4 = C0 + (idx - pr * MV);
-      const bool has = idx < NMAIN;
+      const int pr = idx / RW4, c4 = idx - pr * RW4;
+      const bool has = idx < NITEM;
       hasbits |= (has ? 1u : 0u) << i;
       scol[i] = 4 * c4;
       sbyte[i] = has ? 4u * (2u * (uint32_t)pr * ldx + 4u * (uint32_t)c4) : 0u;
-      sdst[i] = 32u * (uint32_t)(pr * RW4 + c4);
     }
-    // halo item of this lane: chunk hcig of the group, pair hpr, halo vector hv
-    const int hcig = IPC > 0 ? hl / IPC : 0;
-    const int hrem = IPC > 0 ? hl - hcig * IPC : 0;
-    const int hpr = HV > 0 ? hrem / HV : 0, hv = HV > 0 ? hrem - hpr * HV : 0;
-    const int hc4 = DIL == 1 ? (hv < 2 ? hv : MV + hv) : MV + hv;
-    const bool hlane = hcig < HG;
-    const uint32_t hbyte = 4u * ((uint32_t)(hcig * CI + 2 * hpr) * ldx + 4u * (uint32_t)hc4);
-    const uint32_t hdst = 32u * (uint32_t)(hpr * RW4 + hc4);
-    const int hcol = 4 * hc4;
-    const int hlo = IPC > 0 ? __builtin_amdgcn_readfirstlane(((wave - 4) * 64) / IPC) : 0;          // chunks of a group whose items
-    const int hhi = IPC > 0 ? __builtin_amdgcn_readfirstlane(((wave - 4) * 64 + 63) / IPC) : -1;    // ... sit in this wave
-    f32x4 ha = {0.f, 0.f, 0.f, 0.f}, hb = {0.f, 0.f, 0.f, 0.f};
-    bool hok = false;
-    int hleft = 0, hglen_new = 0;        // request side: chunks of the current group still to be requested; its length
-    int wcig = 0, wglen = 0, wpos = 0;   // write side: chunk of the group, group length, chunks written
-    const uint32_t raw_lds = lds_addr(raw);
+    const uint32_t raw_lds = lds_addr(raw) + 32u * (uint32_t)hl;   // this lane's item of staging round 0: 8 floats per item
     const uint32_t v_lds = lds_addr(Vs);
     int lwid = wid0, lchunk = 0, lpos = 0;                   // position of the staging stream
     int lb, ltile, lmblk;
@@ -348,20 +317,6 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
         }
         okbits[S] = okb;
       }
-      if constexpr (IPC > 0) {
-        if (live) {
-          if (hleft == 0) {                                  // this chunk opens a halo group: one round for its next HG chunks
-            const int rest = nchunks - lchunk;
-            hglen_new = hleft = rest < HG ? rest : HG;
-            const int t = tb + hcol;
-            hok = hlane && hcig < hglen_new && t >= 0 && t < L;
-            const uint32_t off = hok ? hbyte + 4u * (uint32_t)tb : 0u;
-            ha = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xrow) + off);
-            hb = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xrow + ldx) + off);
-          }
-          --hleft;
-        }
-      }
       ++lpos;
       if (++lchunk == nchunks) {
         lchunk = 0;
@@ -377,41 +332,23 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
       asm("v_max_f32 %0, %1, %2" : "=v"(r[1]) : "v"(v[1]), "v"(sv[1]));
       return r;
     };
-    // one item into raw[pair][4 c4 + e][channel] at LDS byte address ad: activated, or zero outside [0, L)
-    auto put_item = [&](uint32_t ad, const f32x4& va, const f32x4& vb, bool zero) {
-      f32x2 a01 = {va[0], va[1]}, a23 = {va[2], va[3]};
-      f32x2 b01 = {vb[0], vb[1]}, b23 = {vb[2], vb[3]};
-      if (slope != 1.f) {
-        a01 = act2(a01); a23 = act2(a23); b01 = act2(b01); b23 = act2(b23);
-      }
-      if (zero) a01 = a23 = b01 = b23 = f32x2{0.f, 0.f};
-      asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(ad), "v"(a01[0]), "v"(b01[0]) : "memory");
-      asm volatile("ds_write2_b32 %0, %1, %2 offset0:2 offset1:3" ::"v"(ad), "v"(a01[1]), "v"(b01[1]) : "memory");
-      asm volatile("ds_write2_b32 %0, %1, %2 offset0:4 offset1:5" ::"v"(ad), "v"(a23[0]), "v"(b23[0]) : "memory");
-      asm volatile("ds_write2_b32 %0, %1, %2 offset0:6 offset1:7" ::"v"(ad), "v"(a23[1]), "v"(b23[1]) : "memory");
-    };
     auto write_raw = [&](int buf, auto setc) {
       constexpr int S = decltype(setc)::value;
       const uint32_t base = raw_lds + (uint32_t)buf * (RAWBUF * 4);
 #pragma unroll
-      for (int i = 0; i < NLOAD; ++i)
-        if (NMAIN % (64 * NHELP) == 0 || ((hasbits >> i) & 1u))
-          put_item(base + sdst[i], sa[S][i], sb[S][i], edge[S] && !((okbits[S] >> i) & 1u));
-    };
-    // the halo vectors of the next chunk in stream order (the one write_raw stages next) into raw[buf]; called BEFORE the
-    // period's requests: a request that opens a new group overwrites the registers the last chunk of the old one still needs
-    auto write_halo = [&](int buf) {
-      if constexpr (IPC > 0) {
-        if (wpos < nstream) {
-          if (wcig == wglen) {
-            wcig = 0;
-            wglen = hglen_new;
+      for (int i = 0; i < NLOAD; ++i) {
+        if ((hasbits >> i) & 1u) {
+          f32x2 a01 = {sa[S][i][0], sa[S][i][1]}, a23 = {sa[S][i][2], sa[S][i][3]};
+          f32x2 b01 = {sb[S][i][0], sb[S][i][1]}, b23 = {sb[S][i][2], sb[S][i][3]};
+          if (slope != 1.f) {
+            a01 = act2(a01); a23 = act2(a23); b01 = act2(b01); b23 = act2(b23);
           }
-          if (wcig >= hlo && wcig <= hhi) {                    // (wave-uniform: this wave holds items of that chunk)
-            if (hlane && hcig == wcig) put_item(raw_lds + (uint32_t)buf * (RAWBUF * 4) + hdst, ha, hb, !hok);
-          }
-          ++wcig;
-          ++wpos;
+          if (edge[S] && !((okbits[S] >> i) & 1u)) a01 = a23 = b01 = b23 = f32x2{0.f, 0.f};
+          const uint32_t ad = base + (uint32_t)i * (64 * NHELP * 32);   // raw[pair][4 c4 + e][channel]: item idx at 8 idx floats
+          asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(ad), "v"(a01[0]), "v"(b01[0]) : "memory");
+          asm volatile("ds_write2_b32 %0, %1, %2 offset0:2 offset1:3" ::"v"(ad), "v"(a01[1]), "v"(b01[1]) : "memory");
+          asm volatile("ds_write2_b32 %0, %1, %2 offset0:4 offset1:5" ::"v"(ad), "v"(a23[0]), "v"(b23[0]) : "memory");
+          asm volatile("ds_write2_b32 %0, %1, %2 offset0:6 offset1:7" ::"v"(ad), "v"(a23[1]), "v"(b23[1]) : "memory");
         }
       }
     };
@@ -501,12 +438,10 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     issue_loads(S0{});
-    write_halo(0);
     write_raw(0, S0{});           // chunk 0
     issue_loads(S1{});            // chunk 1 in set 1
     hand_over();                  // (A) raw[0] complete
     transform(std::integral_constant<int, 0>{});
-    write_halo(1);
     write_raw(1, S1{});
     issue_loads(S0{});            // chunk 2 in set 0
     hand_over();                  // (B) V[0], raw[1] complete
@@ -515,7 +450,6 @@ __global__ __launch_bounds__(64 * (4 + 2 * NF), NF == 1 ? 3 : 2) void conv1d_win
     // chunk i + 2 (set i & 1, requested a period ago) to raw[i & 1]; nothing is requested beyond the stream's end
     auto period = [&](int i, auto par) {
       constexpr int P = decltype(par)::value;
-      if (OVW_EXP < 6) write_halo(P);              // (chunk i + 2, as write_raw below)
       if (OVW_EXP < 6) issue_loads(std::integral_constant<int, 1 - P>{});
       OVW_MARK(0)
       if (OVW_EXP != 2 && OVW_EXP < 6 && i + 1 < nstream) transform(std::integral_constant<int, 1 - P>{});
